@@ -1,0 +1,215 @@
+/*
+ * ldsim.h -- C-ABI of libldsim_hip.so: larnd-sim's charge/light hot path on MI355X (gfx950).
+ *
+ * The reference (DUNE/larnd-sim @2024-10-16) has no FFI for this path: the path sits behind
+ * Python call sites `module.kernel[blocks, threads](ndarray, ...)` in one driver loop
+ * (reference cli/simulate_pixels.py:732,742,797,923,944,1002,1016,1036,1057,1087,1150) plus
+ * module-global constants frozen at JIT time.  Each entry point below names the reference
+ * kernel / call site it replaces.  Conventions (same as the reference's call sites):
+ *   - the caller owns every buffer; outputs are sized by the caller;
+ *   - `tracks` is an array of records (any layout described by LdsimTrackLayout) mutated in place;
+ *   - every function returns 0 on success or a negative LDSIM_E* code; ldsim_last_error()
+ *     returns a thread-local message.  Nothing throws across the boundary.
+ *   - one ldsim_ctx per device/process; a ctx is thread-compatible, not thread-safe.
+ *
+ * Two families:
+ *   (1) stage-by-stage, HOST buffers in / out ("materialising" forms: one per reference kernel,
+ *       used by the parity tests and by a drop-in driver);
+ *   (2) device-resident chain: upload the segments once, run quench -> drift -> pixels ->
+ *       induced current -> per-pixel sum -> ADC entirely in HBM, download per-pixel results.
+ */
+#ifndef LDSIM_H
+#define LDSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDSIM_ABI_VERSION 1
+
+/* error codes */
+#define LDSIM_OK 0
+#define LDSIM_EINVAL (-1)   /* bad argument */
+#define LDSIM_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define LDSIM_ENOSPC (-3)   /* caller-provided capacity too small (required size reported) */
+#define LDSIM_ESTATE (-4)   /* call order violated (e.g. no response table set) */
+#define LDSIM_ENODEV (-5)   /* no usable GPU */
+
+/* record field dtype codes */
+enum { LDSIM_F4 = 1, LDSIM_F8 = 2, LDSIM_I4 = 3, LDSIM_U4 = 4, LDSIM_I8 = 5, LDSIM_U8 = 6 };
+
+/* hot-path record fields (reference cli/dumpTree.py:17-28 names) */
+enum ldsim_field {
+  LDSIM_X_START = 0, LDSIM_Y_START, LDSIM_Z_START, LDSIM_X_END, LDSIM_Y_END, LDSIM_Z_END,
+  LDSIM_X, LDSIM_Y, LDSIM_Z, LDSIM_DEDX, LDSIM_DE, LDSIM_T, LDSIM_T_START, LDSIM_T_END,
+  LDSIM_T0, LDSIM_T0_START, LDSIM_T0_END, LDSIM_N_ELECTRONS, LDSIM_N_PHOTONS,
+  LDSIM_LONG_DIFF, LDSIM_TRAN_DIFF, LDSIM_PIXEL_PLANE, LDSIM_NFIELDS
+};
+
+/* Where each field lives inside one record; offset < 0 = field absent (reads 0, never written). */
+typedef struct {
+  int32_t itemsize;
+  int32_t offset[LDSIM_NFIELDS];
+  int32_t dtype[LDSIM_NFIELDS];
+} LdsimTrackLayout;
+
+#define LDSIM_MAX_TPC 128
+
+/* Constants the reference keeps as module globals (larndsim/consts/{detector,light,sim,physics}.py),
+ * passed as a plain struct instead of being frozen into JIT-compiled kernels. */
+typedef struct {
+  /* physics.py */
+  double box_alpha, box_beta, birks_ab, birks_kb, w_ion;
+  /* light.py: quenching needs W_PH and SCINT_PRESCALE */
+  double w_ph, scint_prescale;
+  /* detector.py drift */
+  double e_field, lar_density, v_drift, electron_lifetime, long_diff, tran_diff;
+  /* geometry */
+  int32_t n_tpc;
+  int32_t default_plane_index;             /* 0xBEEF */
+  double tpc_borders[LDSIM_MAX_TPC][3][2]; /* [tpc][x,y,z][lo,hi]; anode = [.][2][0] */
+  int32_t n_pixels[2];
+  int32_t sampled_points;                  /* 40 */
+  int32_t n_time_ticks;                    /* len(TIME_TICKS) */
+  double pixel_pitch;
+  /* time / response */
+  double time_sampling, time_padding, time_window, time_interval[2];
+  double response_sampling, response_bin_size;
+  /* FEE */
+  double discrimination_threshold, clock_cycle, buffer_risetime, gain, v_cm, v_ref, v_pedestal;
+  int32_t adc_hold_delay, adc_busy_delay, reset_cycles, adc_counts;
+  double reset_noise_charge, uncorrelated_noise_charge, discriminator_noise;
+  int32_t max_tracks_per_pixel, max_adc_values;
+  /* light */
+  int32_t light_trig_mode, enable_lut_smearing;
+  int32_t n_op_channel, max_mc_truth_ids;
+  double light_tick_size, mc_truth_threshold;
+} LdsimConsts;
+
+typedef struct ldsim_ctx ldsim_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+const char* ldsim_last_error(void);
+int ldsim_abi_version(void);
+int ldsim_device_count(void);
+/* consts.load_properties + importlib.reload (cli/simulate_pixels.py:431,458-464) */
+int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx** out);
+int ldsim_ctx_destroy(ldsim_ctx* ctx);
+int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts);
+/* cp.load(response_file) (cli/simulate_pixels.py:436): f64 table [ni][nj][nk], host pointer */
+int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_t ni, int32_t nj, int32_t nk);
+/* light.OP_CHANNEL_EFFICIENCY / OP_CHANNEL_TO_TPC (consts/light.py:109-119) */
+int ldsim_set_light_channels(ldsim_ctx* ctx, const double* efficiency, const int32_t* op_channel_to_tpc, int32_t n);
+/* np.load(light_lut)['arr'] as SoA planes: vis,t0,t0_avg [nx*ny*nz*ndet] f32; time_dist [..*nprof] f32 */
+int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const float* t0_avg,
+                        const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet, int32_t nprof);
+/* tuning / validation knobs: "prune_log" (weights below exp(-v) of the local peak are skipped, 0 = keep all),
+ * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell) */
+int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
+int ldsim_synchronize(ldsim_ctx* ctx);
+
+/* ---- (1) stage-by-stage, host buffers ---------------------------------------------------------- */
+/* quenching.quench[bpg,tpb](tracks, mode)            -- reference larndsim/quenching.py:11-44 */
+int ldsim_quench(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout, int32_t mode);
+/* drifting.drift[bpg,tpb](tracks)                    -- larndsim/drifting.py:11-58 */
+int ldsim_drift(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout);
+/* pixels_from_track.max_pixels[bpg,tpb](tracks, n_max) -- larndsim/pixels_from_track.py:43-65 */
+int ldsim_max_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                     int64_t* n_max_pixels);
+/* pixels_from_track.get_pixels[bpg,tpb](tracks, active, neigh, nrad, n_pixels_list, radius)
+ *                                                     -- larndsim/pixels_from_track.py:67-109 */
+int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                     int32_t radius, int32_t* active_pixels, int32_t max_active,
+                     int32_t* neighboring_pixels, int32_t* neighboring_radius, int32_t max_neigh,
+                     double* n_pixels_list);
+/* detsim.time_intervals[bpg,tpb](track_starts, time_max, tracks) -- larndsim/detsim.py:18-40 */
+int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                         double* track_starts, int64_t* time_max);
+/* detsim.tracks_current[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response)
+ *                                                     -- larndsim/detsim.py:351-453 */
+int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                         const int32_t* pixels, int32_t max_neigh, float* signals, int32_t n_ticks);
+/* detsim.get_track_pixel_map2[bpg,tpb](track_pixel_map, unique_pix, pixels, distances, max_distance)
+ *                                                     -- larndsim/detsim.py:564-607 */
+int ldsim_track_pixel_map(ldsim_ctx* ctx, const int32_t* unique_pix, int64_t n_unique,
+                          const int32_t* pixels, const int32_t* distances, int64_t n, int32_t max_neigh,
+                          int32_t max_distance, int64_t* track_pixel_map, int32_t max_tracks);
+/* detsim.sum_pixel_signals[...](pixels_signals, signals, track_starts, pixel_index_map, track_pixel_map,
+ *                               pixels_tracks_signals, overflow_flag) -- larndsim/detsim.py:468-527 */
+int ldsim_sum_pixel_signals(ldsim_ctx* ctx, const float* signals, int64_t n, int32_t max_neigh, int32_t n_ticks,
+                            const double* track_starts, const int64_t* pixel_index_map,
+                            const int64_t* track_pixel_map, int32_t max_tracks, int64_t n_unique,
+                            double* pixels_signals, double* pixels_tracks_signals /* may be NULL */,
+                            double* overflow_flag);
+/* fee.get_adc_values[bpg,tpb](pixels_signals, pixels_signals_tracks, time_ticks, adc_list, adc_ticks_list,
+ *                             time_padding, rng_states, current_fractions, pixel_thresholds)
+ *                                                     -- larndsim/fee.py:517-655 (noise terms must be 0) */
+int ldsim_get_adc_values(ldsim_ctx* ctx, const double* pixels_signals, const double* pixels_signals_tracks,
+                         int64_t n_unique, int32_t n_ticks, int32_t max_tracks, const double* time_ticks,
+                         int32_t n_time_ticks, double time_padding, const double* pixel_thresholds,
+                         double* adc_list, double* adc_ticks_list, double* current_fractions /* may be NULL */);
+/* fee.digitize(integral_list, gain)                   -- larndsim/fee.py:499-515; gain NULL = GAIN*mV/e */
+int ldsim_digitize(ldsim_ctx* ctx, const double* integral_list, int64_t n, const double* gain_list, double* adcs);
+/* lightLUT.calculate_light_incidence[bpg,tpb](tracks, lut, light_incidence, voxel)
+ *                                                     -- larndsim/lightLUT.py:65-136 */
+int ldsim_light_incidence(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                          int32_t n_out_channels, float* n_photons_det, float* t0_det, int32_t* voxel);
+/* light_sim.sum_light_signals[...](segments, segment_voxel, segment_track_id, light_inc, op_channel, lut,
+ *   start_time, light_sample_inc, true_track_id, true_photons, sorted_indices, t0_profile_length)
+ *                                                     -- larndsim/light_sim.py:58-129 */
+int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                            const int32_t* voxel, const int64_t* segment_track_id,
+                            const float* n_photons_det, int32_t n_inc_channels,
+                            const int32_t* op_channel, int32_t n_det, const int32_t* sorted_indices,
+                            double start_time, int32_t n_ticks,
+                            float* light_sample_inc, int64_t* true_track_id, double* true_photons,
+                            int32_t max_truth);
+
+/* ---- (2) device-resident chain ---------------------------------------------------------------------- */
+/* Upload `n` records (H2D) and unpack them into the ctx's SoA segment store.  `batch_id[i]` is the
+ * reference's (event, TPC-group, sub-batch) batch of segment i (cli/simulate_pixels.py:864,902);
+ * segments of one batch must be contiguous and batch ids non-decreasing; batch_id < 0 = not simulated. */
+int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                          const int32_t* batch_id);
+/* Write the mutated fields (n_electrons, n_photons, pixel_plane, long_diff, tran_diff, t, t_start, t_end)
+ * back into host records (D2H). */
+int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout);
+/* quench + drift over the resident segments (cli/simulate_pixels.py:732,742) */
+int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode);
+
+typedef struct {
+  int64_t n_segments;      /* segments simulated in this call */
+  int64_t n_pairs;         /* (segment, pixel) pairs with a valid pixel id */
+  int64_t n_unique;        /* unique (batch, pixel) rows produced */
+  int64_t n_batches;
+  int64_t n_overflow;      /* pixels with more than max_tracks_per_pixel contributing segments */
+  int32_t max_active, max_neigh, max_length;
+  int32_t reserved;
+} LdsimChainStats;
+
+/* Fused a5-a16 (max_pixels .. digitize) on resident segments [seg_begin, seg_end):
+ * per unique (batch, pixel), sorted by batch then pixel id exactly like the reference's concatenated
+ * per-batch `unique_pix`.  Results stay in HBM; fetch with ldsim_chain_download(). */
+int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int32_t want_fractions,
+                       LdsimChainStats* stats);
+/* Copy the last chain call's rows [0, n_unique) to host.  Any pointer may be NULL.
+ *   unique_pix i32[U], batch i32[U], adc_list f64[U][A] (integrated charge), adc_ticks f64[U][A],
+ *   adc_digit f64[U][A] (fee.digitize), track_pixel_map i64[U][M] (segment index within the batch, -1 pad),
+ *   current_fractions f64[U][A][M] (only if want_fractions). */
+int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
+                         double* adc_list, double* adc_ticks, double* adc_digit,
+                         int64_t* track_pixel_map, double* current_fractions);
+/* Device pointers of the last chain call's compact hit list (for a collective without a host round trip):
+ * hits are (batch i32, pixel i32, adc u8-as-i32, tick f64) rows for every written ADC slot. */
+int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes);
+
+/* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
+int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDSIM_H */

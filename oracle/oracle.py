@@ -1,0 +1,226 @@
+"""
+TEST INFRASTRUCTURE ONLY -- ctypes wrapper of oracle/libldsim_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (larndsim_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+if os.path.join(_REPO, "larnd-sim_amd") not in sys.path:
+    sys.path.insert(0, os.path.join(_REPO, "larnd-sim_amd"))
+
+from larndsim_amd import consts  # noqa: E402
+from larndsim_amd.abi import LdsimConsts, pack_consts  # noqa: E402
+from larndsim_amd.layout import FIELDS, from_oracle, oracle_dtype, store_codes, to_oracle  # noqa: E402
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libldsim_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _consts(noise_zero=True):
+    return pack_consts(noise_zero=noise_zero)
+
+
+def quench(tracks, mode):
+    o = to_oracle(tracks)
+    codes, _ = store_codes(tracks.dtype)
+    c = _consts()
+    rc = lib().o_quench(_p(o), C.c_int64(len(o)), C.byref(c), C.c_int(mode), _p(codes))
+    if rc == -1:
+        raise ValueError("Invalid recombination mode: must be 'physics.BOX' or 'physics.BIRKS'")
+    if rc == -2:
+        raise RuntimeError("Invalid recombination value")
+    from_oracle(o, tracks, ["n_electrons", "n_photons"])
+    return tracks
+
+
+def drift(tracks):
+    o = to_oracle(tracks)
+    codes, _ = store_codes(tracks.dtype)
+    c = _consts()
+    lib().o_drift(_p(o), C.c_int64(len(o)), C.byref(c), _p(codes))
+    from_oracle(o, tracks, ["pixel_plane", "n_electrons", "long_diff", "tran_diff", "t", "t_start", "t_end"])
+    return tracks
+
+
+def max_pixels(tracks):
+    o = to_oracle(tracks)
+    c = _consts()
+    n = C.c_int64(0)
+    lib().o_max_pixels(_p(o), C.c_int64(len(o)), C.byref(c), C.byref(n))
+    return n.value
+
+
+def get_pixels(tracks, max_active, P, radius):
+    o = to_oracle(tracks)
+    c = _consts()
+    n = len(o)
+    active = np.full((n, max_active), -1, dtype=np.int32)
+    neigh = np.full((n, P), -1, dtype=np.int32)
+    nrad = np.full((n, P), -1, dtype=np.int32)
+    nlist = np.zeros(n)
+    lib().o_get_pixels(_p(o), C.c_int64(n), C.byref(c), C.c_int(radius), _p(active), C.c_int64(max_active),
+                       _p(neigh), _p(nrad), C.c_int64(P), _p(nlist))
+    return active, neigh, nrad, nlist
+
+
+def time_intervals(tracks):
+    o = to_oracle(tracks)
+    c = _consts()
+    starts = np.empty(len(o))
+    tmax = C.c_int64(0)
+    lib().o_time_intervals(_p(o), C.c_int64(len(o)), C.byref(c), _p(starts), C.byref(tmax))
+    return starts, tmax.value
+
+
+def tracks_current(tracks, pixels, T, response):
+    o = to_oracle(tracks)
+    c = _consts()
+    S, P = pixels.shape
+    pixels = np.ascontiguousarray(pixels, dtype=np.int32)
+    response = np.ascontiguousarray(response, dtype=np.float64)
+    signals = np.zeros((S, P, T), dtype=np.float32)
+    lib().o_tracks_current(_p(signals), _p(pixels), _p(o), C.c_int64(S), C.c_int64(P), C.c_int64(T), _p(response),
+                           C.c_int64(response.shape[0]), C.c_int64(response.shape[1]), C.c_int64(response.shape[2]),
+                           C.byref(c))
+    return signals
+
+
+def rho(point, q, start, sigmas, segment):
+    f = lib().o_rho
+    f.restype = C.c_double
+    s = np.asarray(start, dtype=np.float64); g = np.asarray(sigmas, dtype=np.float64)
+    sg = np.asarray(segment, dtype=np.float64)
+    return f(C.c_double(point[0]), C.c_double(point[1]), C.c_double(point[2]), C.c_double(q), _p(s), _p(g), _p(sg))
+
+
+def unique_pixels(neigh):
+    u = np.unique(neigh.ravel())
+    return u[u != -1].astype(np.int32)
+
+
+def pixel_index_map(neigh, unique_pix):
+    """cli/simulate_pixels.py:1019-1026 restated with searchsorted (unique_pix is sorted)."""
+    idx = np.searchsorted(unique_pix, neigh)
+    idx = np.clip(idx, 0, max(len(unique_pix) - 1, 0))
+    ok = (neigh >= 0) & (len(unique_pix) > 0)
+    ok &= unique_pix[idx] == neigh if len(unique_pix) else False
+    return np.where(ok, idx, -1).astype(np.int64)
+
+
+def track_pixel_map(unique_pix, neigh, nrad, max_distance, M):
+    U = len(unique_pix)
+    S, P = neigh.shape
+    m = np.full((U, M), -1, dtype=np.int64)
+    lib().o_track_pixel_map(_p(m), _p(np.ascontiguousarray(unique_pix, dtype=np.int32)), C.c_int64(U),
+                            _p(np.ascontiguousarray(neigh, dtype=np.int32)),
+                            _p(np.ascontiguousarray(nrad, dtype=np.int32)), C.c_int64(S), C.c_int64(P),
+                            C.c_int(max_distance), C.c_int64(M))
+    return m
+
+
+def sum_pixel_signals(signals, track_starts, pim, tpm, U, want_tracks=True):
+    c = _consts()
+    S, P, T = signals.shape
+    NT = c.n_time_ticks
+    M = tpm.shape[1]
+    ps = np.zeros((U, NT))
+    pts = np.zeros((U, NT, M)) if want_tracks else None
+    ovf = np.zeros(U)
+    lib().o_sum_pixel_signals(_p(ps), _p(np.ascontiguousarray(signals)), _p(np.ascontiguousarray(track_starts)),
+                              _p(np.ascontiguousarray(pim, dtype=np.int64)),
+                              _p(np.ascontiguousarray(tpm, dtype=np.int64)), _p(pts), _p(ovf), C.c_int64(S),
+                              C.c_int64(P), C.c_int64(T), C.c_int64(NT), C.c_int64(M), C.byref(c))
+    return ps, pts, ovf
+
+
+def get_adc_values(pixels_signals, pixels_tracks_signals, time_ticks, thresholds, time_padding=0.0,
+                   want_fractions=True):
+    c = _consts()
+    U, NT = pixels_signals.shape
+    A = c.max_adc_values
+    M = pixels_tracks_signals.shape[2] if pixels_tracks_signals is not None else c.max_tracks_per_pixel
+    adc = np.zeros((U, A)); ticks = np.zeros((U, A))
+    frac = np.zeros((U, A, M)) if (want_fractions and pixels_tracks_signals is not None) else None
+    lib().o_get_adc_values(_p(np.ascontiguousarray(pixels_signals)),
+                           _p(pixels_tracks_signals), _p(np.ascontiguousarray(time_ticks)),
+                           C.c_int64(len(time_ticks)), _p(adc), _p(ticks), C.c_double(time_padding), _p(frac),
+                           _p(np.ascontiguousarray(thresholds, dtype=np.float64)), C.c_int64(U), C.c_int64(NT),
+                           C.c_int64(M), C.byref(c))
+    return adc, ticks, frac
+
+
+def digitize(integral, gain=None):
+    c = _consts()
+    integral = np.ascontiguousarray(integral, dtype=np.float64)
+    out = np.empty_like(integral)
+    g = None if gain is None else np.ascontiguousarray(np.broadcast_to(gain, integral.shape), dtype=np.float64)
+    lib().o_digitize(_p(integral), C.c_int64(integral.size), _p(g), _p(out), C.byref(c))
+    return out
+
+
+def light_incidence(tracks, lut, n_out=None):
+    o = to_oracle(tracks)
+    c = _consts()
+    n = len(o)
+    n_out = c.n_op_channel if n_out is None else n_out
+    vis = np.ascontiguousarray(lut['vis'], dtype=np.float32)
+    t0 = np.ascontiguousarray(lut['t0'], dtype=np.float32)
+    nx, ny, nz, ndet = lut.shape
+    eff = np.ascontiguousarray(consts.light.OP_CHANNEL_EFFICIENCY, dtype=np.float64)
+    c2t = np.ascontiguousarray(consts.light.OP_CHANNEL_TO_TPC, dtype=np.int32)
+    nph = np.zeros((n, n_out), dtype=np.float32); t0d = np.zeros((n, n_out), dtype=np.float32)
+    vox = np.zeros((n, 3), dtype=np.int32)
+    lib().o_light_incidence(_p(o), C.c_int64(n), _p(vis), _p(t0), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                            C.c_int(ndet), _p(eff), _p(c2t), C.c_int(n_out), _p(nph), _p(t0d), _p(vox), C.byref(c))
+    return nph, t0d, vox
+
+
+def sum_light_signals(tracks, voxel, track_id, n_photons_det, op_channel, lut, start_time, n_ticks,
+                      sorted_indices, max_truth=0):
+    o = to_oracle(tracks)
+    c = _consts()
+    n = len(o)
+    nx, ny, nz, ndet = lut.shape
+    nprof = lut['time_dist'].shape[-1]
+    t0_avg = np.ascontiguousarray(lut['t0_avg'], dtype=np.float32)
+    td = np.ascontiguousarray(lut['time_dist'], dtype=np.float32)
+    n_det = len(op_channel)
+    out = np.zeros((n_det, n_ticks), dtype=np.float32)
+    tid = np.full((n_det, n_ticks, max(max_truth, 1)), -1, dtype=np.int64)
+    tph = np.zeros((n_det, n_ticks, max(max_truth, 1)))
+    lib().o_sum_light_signals(_p(o), C.c_int64(n), _p(np.ascontiguousarray(voxel, dtype=np.int32)),
+                              _p(np.ascontiguousarray(track_id, dtype=np.int64)),
+                              _p(np.ascontiguousarray(n_photons_det, dtype=np.float32)),
+                              C.c_int(n_photons_det.shape[1]), _p(np.ascontiguousarray(op_channel, dtype=np.int32)),
+                              C.c_int(n_det), _p(t0_avg), _p(td), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                              C.c_int(ndet), C.c_int(nprof), C.c_double(start_time),
+                              _p(np.ascontiguousarray(sorted_indices, dtype=np.int32)), C.c_int64(n_ticks), _p(out),
+                              _p(tid), _p(tph), C.c_int(max_truth), C.byref(c))
+    return out, tid[:, :, :max_truth], tph[:, :, :max_truth]

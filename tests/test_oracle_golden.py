@@ -1,0 +1,51 @@
+"""
+CPU: pin the oracle (oracle/ldsim_oracle.c) against golden vectors produced by the reference's own
+source (oracle/gen_golden.py).  Integer outputs bit-exact; f64 outputs to 1e-13 relative (same libm
+functions, same operation order).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from larndsim_amd import consts
+from oracle import oracle as O
+
+CFGS = ["module0", "2x2_no_modvar", "ndlar"]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_quench_drift(cfg):
+    H.load_cfg(cfg)
+    g = H.gold(f"qd_{cfg}.npz")
+    seg = g["segments_in"]
+    for mode, name in ((2, "birks"), (1, "box")):
+        r = H.to_ref(seg)
+        O.quench(r, mode)
+        assert np.array_equal(r["n_electrons"], g[f"{name}_n_electrons"])
+        np.testing.assert_allclose(H.f4(r["n_photons"]), g[f"{name}_n_photons"], rtol=0, atol=0)
+        if name == "birks":
+            H.round_f4(r, ["n_photons"])
+            O.drift(r)
+            assert np.array_equal(r["pixel_plane"], g["drift_pixel_plane"])
+            assert np.array_equal(r["n_electrons"], g["drift_n_electrons"])
+            for f in ("long_diff", "tran_diff", "t", "t_start", "t_end"):
+                np.testing.assert_allclose(r[f], g["drift_" + f], rtol=1e-15, atol=0, err_msg=f)
+    assert (g["drift_pixel_plane"] == consts.detector.DEFAULT_PLANE_INDEX).any() or cfg != "module0"
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_pixels_time_intervals(cfg):
+    H.load_cfg(cfg)
+    g = H.gold(f"pixels_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    assert O.max_pixels(r) == int(g["max_pixels"])
+    radius = int(g["max_radius"])
+    active, neigh, nrad, nlist = O.get_pixels(r, int(g["max_pixels"]), g["neigh"].shape[1], radius)
+    assert np.array_equal(active, g["active"])
+    assert np.array_equal(neigh, g["neigh"])
+    assert np.array_equal(nrad, g["nrad"])
+    assert np.array_equal(nlist, g["n_pixels_list"])
+    starts, tmax = O.time_intervals(r)
+    assert np.array_equal(starts, g["track_starts"])
+    assert tmax == int(g["max_length"])
+    assert (g["active"] == -1).any()        # the -1 gap quirk is exercised
