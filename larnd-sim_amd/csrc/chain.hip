@@ -1,0 +1,265 @@
+// chain.hip -- host orchestration of the device-resident charge chain (a5..a16) on the ctx stream.
+// Mirrors the body of the reference's batch loop (cli/simulate_pixels.py:917-1105) for MANY batches at
+// once: every (event, TPC-group, sub-batch) batch keeps its own unique-pixel set, max_length and
+// segment numbering because the batch id is the leading key of the pair sort.
+#include <math.h>
+
+#include <vector>
+
+#include "ldsim_args.h"
+
+int seg_launch_max_pixels(ldsim_ctx*, int64_t, int64_t, int32_t*, unsigned long long*);
+int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*);
+int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
+                   int32_t*, unsigned long long*);
+int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
+int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
+int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
+int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
+                     int32_t*, int64_t*, int64_t);
+int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
+int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*);
+int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
+                      const double*, int, int64_t, int32_t*);
+
+#define CK(x)            \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+
+static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
+  a.s = ctx->seg;
+  a.c = ctx->d_consts;
+  a.resp = ctx->d_resp;
+  a.ni = ctx->ni; a.nj = ctx->nj; a.nk = ctx->nk;
+  if (ctx->trim_response && ctx->resp_k_last >= ctx->resp_k_first) {
+    a.k_first = ctx->resp_k_first;
+    a.k_last = ctx->resp_k_last;
+  } else {
+    a.k_first = 0;
+    a.k_last = ctx->nk - 1;
+  }
+  a.prune_log = ctx->prune_log;
+}
+
+// materialising tracks_current: dense [S][P] pixel array, signals [S][P][T]
+int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T) {
+  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  unsigned long long* counters = (unsigned long long*)((char*)ctx->scratch[SB_MISC].p + 256);
+  HIPCHK(hipMemsetAsync(counters, 0, 64, ctx->stream));
+  CurArgs a{};
+  fill_cur_common(ctx, a);
+  a.pair_val = nullptr; a.pair_key = nullptr;
+  a.pixels = d_pixels;
+  a.seg_begin = 0;
+  a.P = P;
+  a.n_pairs = ctx->seg.n * (int64_t)P;
+  a.out = d_signals;
+  a.T = T;
+  a.tmax_batch = nullptr;
+  a.batch0 = 0;
+  a.counters = counters;
+  return current_launch(ctx, a);
+}
+
+int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions) {
+  const LdsimConsts& h = ctx->h_consts;
+  const int64_t n = seg_end - seg_begin;
+  ctx->stats = LdsimChainStats{};
+  ctx->stats.n_segments = n;
+  ctx->chain_U = 0;
+  ctx->chain_hits = 0;
+  ctx->want_fractions = want_fractions;
+  ctx->ms_current = ctx->ms_adc = ctx->ms_total = 0;
+  if (n == 0) return 0;
+  const int A = h.max_adc_values, M = h.max_tracks_per_pixel;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+  // ---- misc block: [0] err, [8] nmax i32, [16] tran bits u64, [256..] counters u64[8] ----------------------------
+  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  char* misc = (char*)ctx->scratch[SB_MISC].p;
+  unsigned long long* counters = (unsigned long long*)(misc + 256);
+  HIPCHK(hipMemsetAsync(misc, 0, 512, st));
+
+  // batch id range of this call (ids are non-decreasing; negative = skip)
+  int32_t b_first = 0, b_last = 0;
+  {
+    std::vector<int32_t> hb(n);
+    HIPCHK(hipMemcpyAsync(hb.data(), ctx->seg.batch + seg_begin, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    bool any = false;
+    for (int64_t i = 0; i < n; i++)
+      if (hb[i] >= 0) {
+        if (!any) { b_first = hb[i]; any = true; }
+        b_last = hb[i];
+      }
+    if (!any) return 0;
+  }
+  const int32_t batch0 = b_first;
+  const int64_t n_batches = (int64_t)b_last - b_first + 1;
+  ctx->stats.n_batches = n_batches;
+  if (n_batches >= (1 << 27)) {
+    ldsim_set_error("too many batches in one chain call");
+    return LDSIM_EINVAL;
+  }
+
+  // ---- a5 max_pixels + max tran_diff (max_radius, cli/simulate_pixels.py:918-928) ------------------------------------
+  CK(seg_launch_max_pixels(ctx, seg_begin, seg_end, (int32_t*)(misc + 8), (unsigned long long*)(misc + 16)));
+  int32_t nmax = 0;
+  unsigned long long tbits = 0;
+  HIPCHK(hipMemcpyAsync(&nmax, misc + 8, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&tbits, misc + 16, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double max_tran;
+  memcpy(&max_tran, &tbits, 8);
+  const int radius = (int)ceil(max_tran * 5 / h.pixel_pitch);
+  const int P = (2 * radius + 1) * nmax + (1 + 2 * radius) * radius * 2;
+  ctx->stats.max_active = nmax;
+  ctx->stats.max_neigh = P;
+  if (nmax == 0 || P == 0) return 0;
+
+  // ---- a6 get_pixels -----------------------------------------------------------------------------------------------------
+  const int64_t n_entries = n * P;
+  if (n_entries >= 0x7fffffffLL) {
+    ldsim_set_error("chain call too large: %lld (segment, pixel) slots; split the segment range", (long long)n_entries);
+    return LDSIM_EINVAL;
+  }
+  CK(ldsim_ensure(ctx, SB_ACTIVE, (size_t)n * nmax * 4));
+  CK(ldsim_ensure(ctx, SB_NEIGH, (size_t)n_entries * 4));
+  CK(ldsim_ensure(ctx, SB_NRAD, (size_t)n_entries * 4));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_ACTIVE].p, 0xFF, (size_t)n * nmax * 4, st));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_NEIGH].p, 0xFF, (size_t)n_entries * 4, st));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_NRAD].p, 0xFF, (size_t)n_entries * 4, st));
+  int32_t* d_neigh = (int32_t*)ctx->scratch[SB_NEIGH].p;
+  int32_t* d_nrad = (int32_t*)ctx->scratch[SB_NRAD].p;
+  CK(seg_launch_get_pixels(ctx, seg_begin, seg_end, radius, (int32_t*)ctx->scratch[SB_ACTIVE].p, nmax, d_neigh, d_nrad,
+                           P, nullptr));
+
+  // ---- a8 time_intervals per batch -------------------------------------------------------------------------------------------
+  CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8));
+  CK(ldsim_ensure(ctx, SB_NLIST, (size_t)n_batches * 8 + 64));   // [n_batches] tmax i32, [n_batches] first i32
+  int32_t* d_tmax_b = (int32_t*)ctx->scratch[SB_NLIST].p;
+  int32_t* d_first_b = d_tmax_b + n_batches;
+  HIPCHK(hipMemsetAsync(d_tmax_b, 0, (size_t)n_batches * 8, st));
+  double* d_starts = (double*)ctx->scratch[SB_STARTS].p;
+  CK(sort_tmax_batch(ctx, seg_begin, n, batch0, d_starts, d_tmax_b));
+  CK(sort_batch_first(ctx, seg_begin, n, batch0, d_first_b));
+
+  // ---- a7 unique pixels: stable radix sort of (batch, pixel, ring code) --------------------------------------------------------
+  CK(ldsim_ensure(ctx, SB_KEYS, (size_t)n_entries * 8));
+  CK(ldsim_ensure(ctx, SB_KEYS2, (size_t)n_entries * 8));
+  CK(ldsim_ensure(ctx, SB_VALS, (size_t)n_entries * 4));
+  CK(ldsim_ensure(ctx, SB_VALS2, (size_t)n_entries * 4));
+  unsigned long long* d_keys = (unsigned long long*)ctx->scratch[SB_KEYS].p;
+  unsigned long long* d_keys2 = (unsigned long long*)ctx->scratch[SB_KEYS2].p;
+  int32_t* d_vals = (int32_t*)ctx->scratch[SB_VALS].p;
+  int32_t* d_vals2 = (int32_t*)ctx->scratch[SB_VALS2].p;
+  CK(sort_make_keys(ctx, d_neigh, d_nrad, seg_begin, batch0, P, n_entries, d_keys, d_vals, counters));
+  CK(sort_pairs(ctx, d_keys, d_keys2, d_vals, d_vals2, n_entries));
+  unsigned long long n_valid_ull = 0;
+  std::vector<int32_t> h_tmax(n_batches);
+  HIPCHK(hipMemcpyAsync(&n_valid_ull, &counters[4], 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(h_tmax.data(), d_tmax_b, n_batches * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t n_valid = (int64_t)n_valid_ull;
+  ctx->stats.n_pairs = n_valid;
+  int32_t T = 0;
+  for (auto v : h_tmax) T = v > T ? v : T;
+  ctx->stats.max_length = T;
+  if (n_valid == 0 || T == 0) return 0;
+
+  CK(ldsim_ensure(ctx, SB_HEADS, (size_t)n_valid * 4 + 16));
+  CK(ldsim_ensure(ctx, SB_UOFF, (size_t)n_valid * 4 + 16));   // uidx (exclusive scan of heads)
+  int32_t* d_heads = (int32_t*)ctx->scratch[SB_HEADS].p;
+  int32_t* d_uidx = (int32_t*)ctx->scratch[SB_UOFF].p;
+  CK(sort_heads(ctx, d_keys2, n_valid, d_heads));
+  CK(sort_exclusive_scan_i32(ctx, d_heads, d_uidx, n_valid));
+  int32_t last_idx = 0, last_head = 0;
+  HIPCHK(hipMemcpyAsync(&last_idx, d_uidx + (n_valid - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&last_head, d_heads + (n_valid - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t U = (int64_t)last_idx + last_head;
+  ctx->stats.n_unique = U;
+  ctx->chain_U = U;
+
+  CK(ldsim_ensure(ctx, SB_UPIX, (size_t)U * 4));
+  CK(ldsim_ensure(ctx, SB_UBATCH, (size_t)U * 4));
+  CK(ldsim_ensure(ctx, SB_PAIRSEG, (size_t)(U + 1) * 8));     // uoff
+  int32_t* d_upix = (int32_t*)ctx->scratch[SB_UPIX].p;
+  int32_t* d_ubatch = (int32_t*)ctx->scratch[SB_UBATCH].p;
+  int64_t* d_uoff = (int64_t*)ctx->scratch[SB_PAIRSEG].p;
+  CK(sort_fill_unique(ctx, d_keys2, d_heads, d_uidx, n_valid, batch0, d_upix, d_ubatch, d_uoff, U));
+
+  // ---- a9-a12 induced current per sorted pair -------------------------------------------------------------------------------------
+  CK(ldsim_ensure(ctx, SB_WAVES, (size_t)n_valid * T * 4));
+  float* d_waves = (float*)ctx->scratch[SB_WAVES].p;
+  CurArgs a{};
+  fill_cur_common(ctx, a);
+  a.pair_val = d_vals2;
+  a.pair_key = d_keys2;
+  a.pixels = nullptr;
+  a.seg_begin = seg_begin;
+  a.P = P;
+  a.n_pairs = n_valid;
+  a.out = d_waves;
+  a.T = T;
+  a.tmax_batch = d_tmax_b;
+  a.batch0 = batch0;
+  a.counters = counters;
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  CK(current_launch(ctx, a));
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+
+  // ---- a13-a16 per-pixel sum, trigger scan, digitise ---------------------------------------------------------------------------------
+  CK(ldsim_ensure(ctx, SB_ADC, (size_t)U * A * 8));
+  CK(ldsim_ensure(ctx, SB_TICKS, (size_t)U * A * 8));
+  CK(ldsim_ensure(ctx, SB_DIGIT, (size_t)U * A * 8));
+  CK(ldsim_ensure(ctx, SB_TPM, (size_t)U * M * 8));
+  CK(ldsim_ensure(ctx, SB_PAIRPIX, (size_t)U * 8 + 16));      // hit_count i32 [U], hit_off i32 [U]
+  if (want_fractions) CK(ldsim_ensure(ctx, SB_FRAC, (size_t)U * A * M * 8));
+  int32_t* d_hitcnt = (int32_t*)ctx->scratch[SB_PAIRPIX].p;
+  int32_t* d_hitoff = d_hitcnt + U;
+  FeeArgs F{};
+  F.c = ctx->d_consts;
+  F.U = U;
+  F.upix = d_upix; F.ubatch = d_ubatch; F.uoff = d_uoff;
+  F.pair_val = d_vals2; F.pair_key = d_keys2;
+  F.P = P;
+  F.track_starts = d_starts;
+  F.waves = d_waves;
+  F.T = T;
+  F.batch_first = d_first_b;
+  F.batch0 = batch0;
+  F.threshold = h.discrimination_threshold * 1.0;   // DISCRIMINATION_THRESHOLD * units.e
+  F.time_padding = 0.0;                             // cli/simulate_pixels.py:1092
+  F.adc_list = (double*)ctx->scratch[SB_ADC].p;
+  F.adc_ticks = (double*)ctx->scratch[SB_TICKS].p;
+  F.adc_digit = (double*)ctx->scratch[SB_DIGIT].p;
+  F.tpm = (int64_t*)ctx->scratch[SB_TPM].p;
+  F.fractions = want_fractions ? (double*)ctx->scratch[SB_FRAC].p : nullptr;
+  F.counters = counters;
+  F.hit_count = d_hitcnt;
+  CK(fee_launch_chain(ctx, F));
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+
+  // ---- compact hit rows (payload of the multi-GPU all-gather) -----------------------------------------------------------------------------
+  CK(sort_exclusive_scan_i32(ctx, d_hitcnt, d_hitoff, U));
+  unsigned long long h_cnt[8] = {0};
+  HIPCHK(hipMemcpyAsync(h_cnt, counters, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ctx->stats.n_overflow = (int64_t)h_cnt[2];
+  ctx->chain_hits = (int64_t)h_cnt[3];
+  ctx->stats.reserved = (int32_t)h_cnt[0];   // slices whose response shift sat on a rounding boundary
+  CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
+  CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
+                       (int32_t*)ctx->scratch[SB_HITS].p));
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  HIPCHK(hipStreamSynchronize(st));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->ms_current = ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->ms_adc = ms;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4])); ctx->ms_total = ms;
+  return 0;
+}

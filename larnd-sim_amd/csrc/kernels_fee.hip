@@ -1,0 +1,409 @@
+// kernels_fee.hip -- a13-a16: per-pixel summation, LArPix self-trigger / ADC scan, digitisation.
+// Reference: larndsim/detsim.py:468-607 (sum_pixel_signals, get_track_pixel_map2),
+//            larndsim/fee.py:499-655 (digitize, get_adc_values).
+//
+// Chain form: one workgroup per unique (batch, pixel).  The pairs of a pixel are contiguous in the
+// sorted pair list in exactly the slot order get_track_pixel_map2 produces (ring distance, then
+// segment index), so the pixel's waveform is a register-owned sum over <= 50 compact f32 waveforms
+// (no atomics, no [U][N_t][50] slab), the trigger scan is a wave-64 prefix scan + ballot over
+// 64-tick chunks, and the per-hit backtracking fractions are wave reductions over the hit spans.
+#include "ldsim_args.h"
+
+#define FEE_THREADS 256
+#define NT_MAX 4096   // max len(TIME_TICKS) held in LDS
+#define A_MAX 64      // max MAX_ADC_VALUES
+#define M_MAX 64      // max MAX_TRACKS_PER_PIXEL handled by the chain kernel
+
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double o = __shfl_up(v, off);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return __shfl(v, 0);
+}
+
+// q(ic): buffer-convolved charge of tick ic (fee.py:566-579), taps limited by last_reset and N_t
+__device__ __forceinline__ double conv_q(const double* S, int NT, int ic, int last_reset, int ntap, const double* wtap,
+                                         double dt, bool has_rt) {
+  double q = 0;
+  if (has_rt) {
+    int cs = ic - ntap;
+    if (cs < last_reset) cs = last_reset;
+    int ce = ic + 1 < NT ? ic + 1 : NT;
+    for (int jc = cs; jc < ce; jc++) q += S[jc] * dt * wtap[ic - jc];
+  } else if (ic < NT) {
+    q = S[ic] * dt;
+  }
+  return q;
+}
+
+__device__ __forceinline__ double digitize_one(const LdsimConsts* c, double q, double gain) {
+  const double mV = 1e-3 * (1e-6 * 1.0);
+  double v = q * gain + c->v_pedestal * mV - c->v_cm * mV;
+  v = v > 0 ? v : 0;
+  v = rint(v * c->adc_counts / (c->v_ref * mV - c->v_cm * mV));
+  double top = c->adc_counts - 1;
+  return v < top ? v : top;
+}
+
+// ---- the scan itself, shared by the chain and the dense (materialising) kernels -------------------------------
+// Runs on wave 0.  S = summed pixel waveform in LDS.  Writes hits into LDS arrays; returns n_hits.
+struct HitRec {
+  int lr, b;      // span [lr, b] of ticks whose charge entered the hit
+  double q;       // integrated charge (adc_list) == true_q for zero noise
+  double tick;    // adc_ticks_list value
+};
+
+__device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double thr, double time_padding, int lane,
+                        HitRec* hits /* LDS, [A] */, const double* wtap, int ntap) {
+  const double dt = c->time_sampling;
+  const bool has_rt = c->buffer_risetime > 0;
+  const int A = c->max_adc_values;
+  const int interval = (int)py_round((3 * c->clock_cycle + c->adc_hold_delay * c->clock_cycle) / dt);
+  const int reset_ticks = (int)py_round(c->reset_cycles * c->clock_cycle / dt);
+  const int busy_ticks = (int)py_round(c->adc_busy_delay * c->clock_cycle / dt);
+  const int n_time_ticks = NT + 1;  // time_ticks = linspace(0, n_ev*TIME_INTERVAL[1], N_t+1), cli/simulate_pixels.py:1072
+  const double tstep = (1 * c->time_interval[1]) / (double)NT;
+  int ic = 0, iadc = 0, adc_busy = 0, last_reset = 0;
+  double q_sum = 0;
+  while ((ic < NT || adc_busy > 0) && iadc < A) {
+    // one chunk of 64 consecutive ticks
+    int my_ic = ic + lane;
+    int busy_before = adc_busy - lane;           // busy value seen at the top of this lane's iteration
+    bool live = (my_ic < NT) || (busy_before > 0);
+    // liveness must be contiguous from lane 0: once a lane is dead the loop has ended
+    unsigned long long live_mask = __ballot(live);
+    int n_live = (live_mask == ~0ull) ? 64 : __ffsll((long long)~live_mask) - 1;
+    double q = (lane < n_live) ? conv_q(S, NT, my_ic, last_reset, ntap, wtap, dt, has_rt) : 0.0;
+    double qs = q_sum + wave_incl_scan(q, lane);
+    int busy_after = busy_before > 0 ? busy_before - 1 : 0;
+    bool trig = (lane < n_live) && (qs + 0.0 >= thr + 0.0) && (busy_after == 0);
+    unsigned long long tm = __ballot(trig);
+    if (tm == 0) {
+      if (n_live < 64) break;
+      q_sum = __shfl(qs, 63);
+      ic += 64;
+      adc_busy = adc_busy > 64 ? adc_busy - 64 : 0;
+      continue;
+    }
+    int f = __ffsll((long long)tm) - 1;
+    q_sum = __shfl(qs, f);
+    int ict = ic + f;
+    int integrate_end = ict + interval;
+    // integrate the next `interval` ticks (fee.py:590-614)
+    double qi = 0;
+    for (int base = ict + 1; base <= integrate_end; base += 64) {
+      int t = base + lane;
+      double v = (t <= integrate_end) ? conv_q(S, NT, t, last_reset, ntap, wtap, dt, has_rt) : 0.0;
+      qi += wave_sum(v);
+    }
+    q_sum += qi;
+    ic = integrate_end + 1;
+    double adc = q_sum + 0.0;
+    if (adc < thr + 0.0) {  // fee.py:619-628
+      ic += reset_ticks;
+      q_sum = 0;
+      last_reset = ic;
+      adc_busy = 0;
+      continue;
+    }
+    if (lane == 0) {
+      int crossing = ic < n_time_ticks - 1 ? ic : n_time_ticks - 1;
+      int post = ic - crossing > 0 ? ic - crossing : 0;
+      double tt = (crossing == NT) ? (1 * c->time_interval[1]) : crossing * tstep;
+      hits[iadc].lr = last_reset;
+      hits[iadc].b = integrate_end;
+      hits[iadc].q = adc;
+      hits[iadc].tick = tt + time_padding - 2 + post;
+    }
+    ic += reset_ticks;
+    last_reset = ic;
+    adc_busy = busy_ticks;
+    q_sum = 0;
+    iadc++;
+  }
+  return iadc;
+}
+
+// ---- chain kernel ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
+  const LdsimConsts* c = F.c;
+  const int64_t u = blockIdx.x;
+  if (u >= F.U) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NT = c->n_time_ticks;
+  const int A = c->max_adc_values, M = c->max_tracks_per_pixel;
+  const double dt = c->time_sampling, rt = c->buffer_risetime;
+
+  __shared__ double S[NT_MAX];
+  __shared__ HitRec hits[A_MAX];
+  __shared__ int s_start[M_MAX];
+  __shared__ int64_t s_row[M_MAX];
+  __shared__ double wtap[64], G[64];
+  __shared__ int s_nh;
+
+  const int64_t p0 = F.uoff[u], p1 = F.uoff[u + 1];
+  // slots: pairs whose ring code is valid (key low nibble != 15), at most M (detsim.py:582-607)
+  int n_valid = 0;
+  {
+    // keys are sorted, invalid-distance pairs (nibble 15) sit at the end of the group
+    int64_t lo = p0, hi = p1;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if ((F.pair_key[mid] & 15ull) == 15ull) hi = mid; else lo = mid + 1;
+    }
+    n_valid = (int)(lo - p0);
+  }
+  const int n_slots = n_valid < M ? n_valid : M;
+  const bool overflow = (p1 - p0) > n_slots;
+  const int ubatch = F.ubatch[u];
+  const int bfirst = F.batch_first[ubatch - F.batch0];
+  if (tid < n_slots) {
+    int32_t v = F.pair_val[p0 + tid];
+    int r = v / F.P;
+    s_start[tid] = (int)py_round(F.track_starts[r] / dt);   // detsim.py:506
+    s_row[tid] = p0 + tid;
+    F.tpm[u * M + tid] = r - bfirst;
+  } else if (tid < M) {
+    F.tpm[u * M + tid] = -1;
+  }
+  const int ntap = rt > 0 ? (int)ceil(10 * rt / dt) : 0;  // floor(ic - 10*rt/dt) == ic - ceil(10*rt/dt)
+  if (tid <= ntap && rt > 0) {
+    // w(d) = exp(-d*dt/rt) * (1 - exp(-dt/rt))   (fee.py:569)
+    wtap[tid] = exp((-tid) * dt / rt) * (1 - exp(-dt / rt));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // G[n] = dt * sum_{d=0..n} w(d): weight of a tick n ticks before the end of a hit span
+    double acc = 0;
+    for (int d = 0; d <= ntap; d++) {
+      acc += (rt > 0 ? wtap[d] : 1.0) * dt;
+      G[d] = acc;
+    }
+  }
+  // ---- summed waveform: each thread owns ticks tid, tid+256, ...  (detsim.py:516-520) -----------------------------
+  for (int t = tid; t < NT; t += FEE_THREADS) {
+    double acc = 0;
+    for (int k = 0; k < n_slots; k++) {
+      int it = t - s_start[k];
+      if (it >= 0 && it < F.T) acc += (double)F.waves[s_row[k] * (int64_t)F.T + it];
+    }
+    S[t] = acc;
+  }
+  __syncthreads();
+  // ---- trigger scan on wave 0 ----------------------------------------------------------------------------------------
+  if (wv == 0) {
+    int nh = adc_scan(c, S, NT, F.threshold, F.time_padding, lane, hits, wtap, ntap);
+    if (lane == 0) s_nh = nh;
+  }
+  __syncthreads();
+  const int nh = s_nh;
+  const double gain = c->gain * (1e-3 * (1e-6 * 1.0)) / 1.0;   // GAIN * mV / e
+  for (int h = tid; h < A; h += FEE_THREADS) {
+    double q = h < nh ? hits[h].q : 0.0;
+    F.adc_list[u * A + h] = q;
+    F.adc_ticks[u * A + h] = h < nh ? hits[h].tick : 0.0;
+    F.adc_digit[u * A + h] = digitize_one(c, q, gain);
+  }
+  if (tid == 0) {
+    F.hit_count[u] = nh;
+    if (overflow) atomicAdd(&F.counters[2], 1ull);
+    if (nh) atomicAdd(&F.counters[3], (unsigned long long)nh);
+  }
+  // ---- backtracking fractions (fee.py:572-573, 633-635): sum_jc sig_k[jc]*G[min(ntap, b-jc)] / true_q ------------
+  if (F.fractions) {
+    double* fr = F.fractions + u * (int64_t)A * M;
+    for (int i = tid; i < A * M; i += FEE_THREADS) fr[i] = 0;
+    __syncthreads();
+    for (int k = wv; k < n_slots; k += FEE_THREADS / 64) {
+      const float* wf = F.waves + s_row[k] * (int64_t)F.T;
+      const int st = s_start[k];
+      for (int h = 0; h < nh; h++) {
+        int lr = hits[h].lr, b = hits[h].b;
+        int hi = b < NT - 1 ? b : NT - 1;
+        double acc = 0;
+        for (int jc = lr + lane; jc <= hi; jc += 64) {
+          int it = jc - st;
+          if (it >= 0 && it < F.T) {
+            int d = b - jc;
+            acc += (double)wf[it] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
+          }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) fr[h * M + k] = hits[h].q > 0 ? acc / hits[h].q : acc;
+      }
+    }
+  }
+}
+
+extern "C++" int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F) {
+  if (F.U == 0) return 0;
+  const LdsimConsts& h = ctx->h_consts;
+  if (h.n_time_ticks > NT_MAX || h.max_adc_values > A_MAX || h.max_tracks_per_pixel > M_MAX ||
+      (h.buffer_risetime > 0 && 10 * h.buffer_risetime / h.time_sampling > 62)) {
+    ldsim_set_error("FEE constants exceed the kernel's static tiles");
+    return LDSIM_EINVAL;
+  }
+  hipLaunchKernelGGL(pixel_adc_kernel, dim3((unsigned)F.U), dim3(FEE_THREADS), 0, ctx->stream, F);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- materialising forms (parity API) ----------------------------------------------------------------------------------
+// get_track_pixel_map2, literal (detsim.py:564-607): one thread per unique pixel
+__global__ void track_pixel_map_kernel(int64_t* map, const int32_t* unique_pix, int64_t U, const int32_t* pixels,
+                                       const int32_t* dist, int64_t S, int P, int max_distance, int M) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  int32_t upix = unique_pix[u];
+  int64_t* row = map + u * M;
+  for (int target = 0; target < max_distance; target++)
+    for (int64_t itrk = 0; itrk < S; itrk++)
+      for (int ipix = 0; ipix < P; ipix++) {
+        if (upix != pixels[itrk * P + ipix]) continue;
+        if (dist[itrk * P + ipix] == target) {
+          int imap = 0;
+          while (imap < M) {
+            if (row[imap] == itrk) { imap = -1; break; }
+            if (row[imap] == -1) break;
+            imap++;
+          }
+          if (imap >= 0 && imap < M) row[imap] = itrk;
+        }
+        break;
+      }
+}
+
+// sum_pixel_signals, literal incl. f64 atomics (detsim.py:468-527): thread per (itrk, ipix, itick)
+__global__ void sum_pixel_signals_kernel(double* pixels_signals, const float* signals, const double* track_starts,
+                                         const int64_t* pim, const int64_t* tpm, double* pts, double* overflow,
+                                         int64_t S, int P, int T, int NT, int M, double dt) {
+  int64_t pairi = blockIdx.x;
+  int64_t itrk = pairi / P;
+  int64_t pidx = pim[pairi];
+  if (pidx < 0) return;
+  int start_tick = (int)py_round(track_starts[itrk] / dt);
+  int counter = -99;
+  for (int k = 0; k < M; k++)
+    if (itrk == tpm[pidx * M + k]) { counter = k; break; }
+  if (counter < 0) {
+    if (threadIdx.x == 0) overflow[pidx] = 1;
+    return;
+  }
+  for (int itick = threadIdx.x; itick < T; itick += blockDim.x) {
+    int itime = start_tick + itick;
+    if (itime < NT && itime > -1) {
+      double v = signals[pairi * T + itick];
+      atomicAdd(&pixels_signals[pidx * NT + itime], v);
+      if (pts) atomicAdd(&pts[(pidx * NT + itime) * M + counter], v);
+    }
+  }
+}
+
+// get_adc_values on dense arrays (fee.py:517-655): workgroup per pixel, same scan as the chain
+__global__ void __launch_bounds__(FEE_THREADS) adc_dense_kernel(const LdsimConsts* c, const double* pixels_signals,
+                                                                const double* pts, int64_t U, int NT, int M,
+                                                                const double* thresholds, double time_padding,
+                                                                double* adc_list, double* adc_ticks, double* fractions) {
+  const int64_t u = blockIdx.x;
+  if (u >= U) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int A = c->max_adc_values;
+  const double dt = c->time_sampling, rt = c->buffer_risetime;
+  __shared__ double S[NT_MAX];
+  __shared__ HitRec hits[A_MAX];
+  __shared__ double wtap[64], G[64];
+  __shared__ int s_nh;
+  const int ntap = rt > 0 ? (int)ceil(10 * rt / dt) : 0;  // floor(ic - 10*rt/dt) == ic - ceil(10*rt/dt)
+  if (tid <= ntap && rt > 0) wtap[tid] = exp((-tid) * dt / rt) * (1 - exp(-dt / rt));
+  for (int t = tid; t < NT; t += FEE_THREADS) S[t] = pixels_signals[u * NT + t];
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0;
+    for (int d = 0; d <= ntap; d++) {
+      acc += (rt > 0 ? wtap[d] : 1.0) * dt;
+      G[d] = acc;
+    }
+  }
+  if (wv == 0) {
+    int nh = adc_scan(c, S, NT, thresholds[u], time_padding, lane, hits, wtap, ntap);
+    if (lane == 0) s_nh = nh;
+  }
+  __syncthreads();
+  const int nh = s_nh;
+  for (int h = tid; h < A; h += FEE_THREADS) {
+    adc_list[u * A + h] = h < nh ? hits[h].q : 0.0;
+    adc_ticks[u * A + h] = h < nh ? hits[h].tick : 0.0;
+  }
+  if (fractions && pts) {
+    double* fr = fractions + u * (int64_t)A * M;
+    for (int i = tid; i < A * M; i += FEE_THREADS) fr[i] = 0;
+    __syncthreads();
+    for (int k = wv; k < M; k += FEE_THREADS / 64)
+      for (int h = 0; h < nh; h++) {
+        int lr = hits[h].lr, b = hits[h].b;
+        int hi = b < NT - 1 ? b : NT - 1;
+        double acc = 0;
+        for (int jc = lr + lane; jc <= hi; jc += 64) {
+          int d = b - jc;
+          acc += pts[(u * NT + jc) * M + k] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) fr[h * M + k] = hits[h].q > 0 ? acc / hits[h].q : acc;
+      }
+  }
+}
+
+__global__ void digitize_kernel(const LdsimConsts* c, const double* q, const double* gain_list, double* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double gain = gain_list ? gain_list[i] : c->gain * (1e-3 * (1e-6 * 1.0)) / 1.0;
+  out[i] = digitize_one(c, q[i], gain);
+}
+
+extern "C++" {
+int fee_launch_track_pixel_map(ldsim_ctx* ctx, int64_t* map, const int32_t* upix, int64_t U, const int32_t* pixels,
+                               const int32_t* dist, int64_t S, int P, int max_distance, int M) {
+  if (U == 0) return 0;
+  hipLaunchKernelGGL(track_pixel_map_kernel, dim3((unsigned)((U + 63) / 64)), dim3(64), 0, ctx->stream, map, upix, U,
+                     pixels, dist, S, P, max_distance, M);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int fee_launch_sum_pixel_signals(ldsim_ctx* ctx, double* ps, const float* signals, const double* starts,
+                                 const int64_t* pim, const int64_t* tpm, double* pts, double* ovf, int64_t S, int P,
+                                 int T, int NT, int M) {
+  if (S * P == 0) return 0;
+  hipLaunchKernelGGL(sum_pixel_signals_kernel, dim3((unsigned)(S * P)), dim3(256), 0, ctx->stream, ps, signals, starts,
+                     pim, tpm, pts, ovf, S, P, T, NT, M, ctx->h_consts.time_sampling);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int fee_launch_adc_dense(ldsim_ctx* ctx, const double* ps, const double* pts, int64_t U, int NT, int M,
+                         const double* thr, double time_padding, double* adc, double* ticks, double* frac) {
+  if (U == 0) return 0;
+  const LdsimConsts& h = ctx->h_consts;
+  if (NT > NT_MAX || h.max_adc_values > A_MAX || (h.buffer_risetime > 0 && 10 * h.buffer_risetime / h.time_sampling > 62)) {
+    ldsim_set_error("FEE constants exceed the kernel's static tiles");
+    return LDSIM_EINVAL;
+  }
+  hipLaunchKernelGGL(adc_dense_kernel, dim3((unsigned)U), dim3(FEE_THREADS), 0, ctx->stream, ctx->d_consts, ps, pts, U,
+                     NT, M, thr, time_padding, adc, ticks, frac);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int fee_launch_digitize(ldsim_ctx* ctx, const double* q, const double* gain, double* out, int64_t n) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(digitize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_consts, q,
+                     gain, out, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}

@@ -1,0 +1,612 @@
+// ldsim_abi.hip -- the C-ABI of libldsim_hip.so (include/ldsim.h): context, host-buffer stage API,
+// device-resident chain orchestration.  No compute happens on the host: every entry point only moves
+// buffers and launches the HIP kernels in kernels_*.hip / sort.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ldsim_dev.h"
+
+// ---- launchers defined in the kernel translation units ----------------------------------------------------
+struct CurArgs;
+struct FeeArgs;
+int seg_launch_unpack(ldsim_ctx*, const LdsimTrackLayout*, int64_t);
+int seg_launch_repack(ldsim_ctx*, const LdsimTrackLayout*, int64_t);
+int seg_launch_quench_drift(ldsim_ctx*, int, int, int, int*);
+int seg_launch_max_pixels(ldsim_ctx*, int64_t, int64_t, int32_t*, unsigned long long*);
+int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*);
+int seg_launch_time_intervals(ldsim_ctx*, int64_t, int64_t, double*, int32_t*);
+int fee_launch_track_pixel_map(ldsim_ctx*, int64_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t,
+                               int, int, int);
+int fee_launch_sum_pixel_signals(ldsim_ctx*, double*, const float*, const double*, const int64_t*, const int64_t*,
+                                 double*, double*, int64_t, int, int, int, int);
+int fee_launch_adc_dense(ldsim_ctx*, const double*, const double*, int64_t, int, int, const double*, double, double*,
+                         double*, double*);
+int fee_launch_digitize(ldsim_ctx*, const double*, const double*, double*, int64_t);
+int light_launch_incidence(ldsim_ctx*, int, float*, float*, int32_t*);
+int light_launch_sum(ldsim_ctx*, const int32_t*, const int64_t*, const float*, int, const int32_t*, int, const int32_t*,
+                     double, int64_t, float*, int64_t*, double*, int);
+int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
+                   int32_t*, unsigned long long*);
+int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
+int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
+int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
+int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
+                     int32_t*, int64_t*, int64_t);
+int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
+int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*);
+int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
+                      const double*, int, int64_t, int32_t*);
+// chain glue implemented in chain.hip (needs the kernel argument structs)
+int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions);
+int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T);
+
+// ---- errors ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void ldsim_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ldsim_last_error(void) { return g_err; }
+extern "C" int ldsim_abi_version(void) { return LDSIM_ABI_VERSION; }
+extern "C" int ldsim_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ldsim_ensure_buf(ldsim_ctx* ctx, DevBuf* b, size_t bytes) {
+  (void)ctx;
+  if (bytes <= b->bytes && b->p) return 0;
+  if (b->p) HIPCHK(hipFree(b->p));
+  b->p = nullptr;
+  b->bytes = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  HIPCHK(hipMalloc(&b->p, want));
+  b->bytes = want;
+  return 0;
+}
+int ldsim_ensure(ldsim_ctx* ctx, int slot, size_t bytes) { return ldsim_ensure_buf(ctx, &ctx->scratch[slot], bytes); }
+
+// temporary device buffer for the host-buffer API
+struct Tmp {
+  void* p = nullptr;
+  ~Tmp() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    HIPCHK(hipMalloc(&p, bytes ? bytes : 8));
+    return 0;
+  }
+  template <class T>
+  T* as() { return (T*)p; }
+};
+
+#define CK(x)                \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_) return rc_;     \
+  } while (0)
+#define NEED(cond, msg)            \
+  do {                             \
+    if (!(cond)) {                 \
+      ldsim_set_error("%s", msg);  \
+      return LDSIM_EINVAL;         \
+    }                              \
+  } while (0)
+
+// ---- context ------------------------------------------------------------------------------------------------------
+extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx** out) {
+  NEED(consts && out, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    ldsim_set_error("no HIP device visible: libldsim_hip.so has no CPU fallback");
+    return LDSIM_ENODEV;
+  }
+  NEED(device >= 0 && device < n, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  ldsim_ctx* ctx = new ldsim_ctx();
+  ctx->device = device;
+  HIPCHK(hipStreamCreate(&ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
+  for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+  *out = ctx;
+  return ldsim_set_consts(ctx, consts);
+}
+
+extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
+  NEED(ctx && consts, "null argument");
+  NEED(consts->n_tpc >= 0 && consts->n_tpc <= LDSIM_MAX_TPC, "n_tpc out of range");
+  ctx->h_consts = *consts;
+  HIPCHK(hipMemcpyAsync(ctx->d_consts, &ctx->h_consts, sizeof(LdsimConsts), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
+                  ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& b : ctx->scratch)
+    if (b.p) (void)hipFree(b.p);
+  for (int i = 0; i < 6; i++)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) {
+  NEED(ctx && name, "null argument");
+  if (!strcmp(name, "prune_log")) ctx->prune_log = value;
+  else if (!strcmp(name, "trim_response")) ctx->trim_response = value != 0;
+  else {
+    ldsim_set_error("unknown option %s", name);
+    return LDSIM_EINVAL;
+  }
+  return 0;
+}
+
+extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_t ni, int32_t nj, int32_t nk) {
+  NEED(ctx && response && ni > 0 && nj > 0 && nk > 0, "bad response table");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->d_resp) HIPCHK(hipFree(ctx->d_resp));
+  size_t bytes = (size_t)ni * nj * nk * sizeof(double);
+  HIPCHK(hipMalloc((void**)&ctx->d_resp, bytes));
+  HIPCHK(hipMemcpy(ctx->d_resp, response, bytes, hipMemcpyHostToDevice));
+  ctx->ni = ni; ctx->nj = nj; ctx->nk = nk;
+  // support of the table along k over all cells: entries that are exactly 0.0 for every (i, j)
+  int first = nk, last = -1;
+  for (int64_t c = 0; c < (int64_t)ni * nj; c++) {
+    const double* row = response + c * nk;
+    int f = 0;
+    while (f < first && row[f] == 0.0) f++;
+    if (f < first) first = f;
+    int l = nk - 1;
+    while (l > last && row[l] == 0.0) l--;
+    if (l > last) last = l;
+  }
+  if (last < first) { first = 0; last = -1; }
+  ctx->resp_k_first = first;
+  ctx->resp_k_last = last;
+  return 0;
+}
+
+extern "C" int ldsim_set_light_channels(ldsim_ctx* ctx, const double* eff, const int32_t* ch2tpc, int32_t n) {
+  NEED(ctx && n >= 0, "bad light channels");
+  if (ctx->d_eff) HIPCHK(hipFree(ctx->d_eff));
+  if (ctx->d_ch2tpc) HIPCHK(hipFree(ctx->d_ch2tpc));
+  ctx->d_eff = nullptr; ctx->d_ch2tpc = nullptr; ctx->n_light_ch = n;
+  if (n == 0) return 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_eff, n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&ctx->d_ch2tpc, n * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(ctx->d_eff, eff, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_ch2tpc, ch2tpc, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const float* t0_avg,
+                                   const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet,
+                                   int32_t nprof) {
+  NEED(ctx && vis && t0 && t0_avg && time_dist, "null LUT plane");
+  size_t nv = (size_t)nx * ny * nz * ndet;
+  float** dst[] = {&ctx->d_lut_vis, &ctx->d_lut_t0, &ctx->d_lut_t0avg, &ctx->d_lut_td};
+  const float* src[] = {vis, t0, t0_avg, time_dist};
+  size_t cnt[] = {nv, nv, nv, nv * nprof};
+  for (int i = 0; i < 4; i++) {
+    if (*dst[i]) HIPCHK(hipFree(*dst[i]));
+    HIPCHK(hipMalloc((void**)dst[i], cnt[i] * sizeof(float)));
+    HIPCHK(hipMemcpy(*dst[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice));
+  }
+  ctx->lut_nx = nx; ctx->lut_ny = ny; ctx->lut_nz = nz; ctx->lut_ndet = ndet; ctx->lut_nprof = nprof;
+  return 0;
+}
+
+// ---- resident segments ----------------------------------------------------------------------------------------------
+static int seg_reserve(ldsim_ctx* ctx, int64_t n) {
+  if (n > ctx->seg.cap) {
+    int64_t cap = n + n / 8 + 64;
+    size_t bytes = (size_t)cap * ((LDSIM_NFIELDS - 1) * sizeof(double) + 2 * sizeof(int32_t));
+    CK(ldsim_ensure_buf(ctx, &ctx->seg_block, bytes));
+    char* p = (char*)ctx->seg_block.p;
+    for (int f = 0; f < LDSIM_NFIELDS - 1; f++) {
+      ctx->seg.f[f] = (double*)p;
+      p += cap * sizeof(double);
+    }
+    ctx->seg.pixel_plane = (int32_t*)p;
+    p += cap * sizeof(int32_t);
+    ctx->seg.batch = (int32_t*)p;
+    ctx->seg.cap = cap;
+  }
+  return 0;
+}
+
+static int upload_tracks(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* lay,
+                         const int32_t* batch_id) {
+  NEED(ctx && lay && n >= 0 && (tracks || n == 0), "bad tracks argument");
+  NEED(lay->itemsize > 0, "bad layout");
+  HIPCHK(hipSetDevice(ctx->device));
+  CK(seg_reserve(ctx, n));
+  ctx->seg.n = n;
+  for (int f = 0; f < LDSIM_NFIELDS; f++) ctx->seg.store_code[f] = lay->offset[f] >= 0 ? lay->dtype[f] : LDSIM_F8;
+  if (n == 0) return 0;
+  size_t bytes = (size_t)n * lay->itemsize;
+  CK(ldsim_ensure_buf(ctx, &ctx->raw, bytes));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, tracks, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CK(seg_launch_unpack(ctx, lay, n));
+  if (batch_id)
+    HIPCHK(hipMemcpyAsync(ctx->seg.batch, batch_id, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  else
+    HIPCHK(hipMemsetAsync(ctx->seg.batch, 0, n * sizeof(int32_t), ctx->stream));
+  return 0;
+}
+
+static int download_tracks(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* lay) {
+  NEED(n == ctx->seg.n, "record count differs from the resident segment count");
+  if (n == 0) return 0;
+  size_t bytes = (size_t)n * lay->itemsize;
+  NEED(ctx->raw.bytes >= bytes, "staging buffer missing");
+  // the staging buffer still holds the uploaded bytes of every untouched field
+  CK(seg_launch_repack(ctx, lay, n));
+  HIPCHK(hipMemcpyAsync(tracks, ctx->raw.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                     const int32_t* batch_id) {
+  if (batch_id)
+    for (int64_t i = 1; i < n; i++)
+      if (batch_id[i] >= 0 && batch_id[i - 1] >= 0 && batch_id[i] < batch_id[i - 1]) {
+        ldsim_set_error("batch ids must be non-decreasing (segment %lld)", (long long)i);
+        return LDSIM_EINVAL;
+      }
+  CK(upload_tracks(ctx, tracks, n, layout, batch_id));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
+  NEED(ctx && tracks && layout, "null argument");
+  return download_tracks(ctx, tracks, n, layout);
+}
+
+static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {
+  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  int* d_err = (int*)ctx->scratch[SB_MISC].p;
+  HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+  CK(seg_launch_quench_drift(ctx, mode, do_q, do_d, d_err));
+  int h_err = 0;
+  HIPCHK(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (h_err == 1) {
+    ldsim_set_error("Invalid recombination mode: must be 'physics.BOX' or 'physics.BIRKS'");
+    return LDSIM_EINVAL;
+  }
+  if (h_err == 2) {
+    ldsim_set_error("Invalid recombination value");
+    return LDSIM_EINVAL;
+  }
+  return 0;
+}
+
+extern "C" int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode) {
+  NEED(ctx, "null ctx");
+  return run_quench_drift(ctx, mode, 1, 1);
+}
+
+// ---- (1) stage-by-stage host-buffer API ---------------------------------------------------------------------------
+extern "C" int ldsim_quench(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout, int32_t mode) {
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  CK(run_quench_drift(ctx, mode, 1, 0));
+  return download_tracks(ctx, tracks, n, layout);
+}
+
+extern "C" int ldsim_drift(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  CK(run_quench_drift(ctx, 2, 0, 1));
+  return download_tracks(ctx, tracks, n, layout);
+}
+
+extern "C" int ldsim_max_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                int64_t* n_max_pixels) {
+  NEED(n_max_pixels, "null output");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  char* m = (char*)ctx->scratch[SB_MISC].p;
+  HIPCHK(hipMemsetAsync(m, 0, 64, ctx->stream));
+  CK(seg_launch_max_pixels(ctx, 0, n, (int32_t*)(m + 8), (unsigned long long*)(m + 16)));
+  int32_t h = 0;
+  HIPCHK(hipMemcpyAsync(&h, m + 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (h > *n_max_pixels) *n_max_pixels = h;  // cuda.atomic.max into the caller's array
+  return 0;
+}
+
+extern "C" int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                int32_t radius, int32_t* active, int32_t max_active, int32_t* neigh, int32_t* nrad,
+                                int32_t P, double* n_list) {
+  NEED(active && neigh && nrad && max_active >= 0 && P >= 0 && radius >= 0, "bad get_pixels arguments");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  size_t ba = (size_t)n * max_active * 4, bn = (size_t)n * P * 4;
+  CK(ldsim_ensure(ctx, SB_ACTIVE, ba));
+  CK(ldsim_ensure(ctx, SB_NEIGH, bn));
+  CK(ldsim_ensure(ctx, SB_NRAD, bn));
+  CK(ldsim_ensure(ctx, SB_NLIST, (size_t)n * 8));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_ACTIVE].p, 0xFF, ba, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_NEIGH].p, 0xFF, bn, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_NRAD].p, 0xFF, bn, ctx->stream));
+  CK(seg_launch_get_pixels(ctx, 0, n, radius, (int32_t*)ctx->scratch[SB_ACTIVE].p, max_active,
+                           (int32_t*)ctx->scratch[SB_NEIGH].p, (int32_t*)ctx->scratch[SB_NRAD].p, P,
+                           (double*)ctx->scratch[SB_NLIST].p));
+  if (ba) HIPCHK(hipMemcpyAsync(active, ctx->scratch[SB_ACTIVE].p, ba, hipMemcpyDeviceToHost, ctx->stream));
+  if (bn) HIPCHK(hipMemcpyAsync(neigh, ctx->scratch[SB_NEIGH].p, bn, hipMemcpyDeviceToHost, ctx->stream));
+  if (bn) HIPCHK(hipMemcpyAsync(nrad, ctx->scratch[SB_NRAD].p, bn, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_list && n) HIPCHK(hipMemcpyAsync(n_list, ctx->scratch[SB_NLIST].p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                    double* track_starts, int64_t* time_max) {
+  NEED(track_starts && time_max, "null output");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8 + 8));
+  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  char* m = (char*)ctx->scratch[SB_MISC].p;
+  HIPCHK(hipMemsetAsync(m, 0, 64, ctx->stream));
+  CK(seg_launch_time_intervals(ctx, 0, n, (double*)ctx->scratch[SB_STARTS].p, (int32_t*)(m + 24)));
+  int32_t h = 0;
+  if (n) HIPCHK(hipMemcpyAsync(track_starts, ctx->scratch[SB_STARTS].p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&h, m + 24, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (h > *time_max) *time_max = h;
+  return 0;
+}
+
+extern "C" int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                    const int32_t* pixels, int32_t P, float* signals, int32_t T) {
+  NEED(pixels && signals && P >= 0 && T >= 0, "bad tracks_current arguments");
+  NEED(ctx && ctx->d_resp, "no response table set (ldsim_set_response)");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  size_t bp = (size_t)n * P * 4, bs = (size_t)n * P * T * 4;
+  if (bs == 0) return 0;
+  CK(ldsim_ensure(ctx, SB_NEIGH, bp));
+  CK(ldsim_ensure(ctx, SB_WAVES, bs));
+  HIPCHK(hipMemcpyAsync(ctx->scratch[SB_NEIGH].p, pixels, bp, hipMemcpyHostToDevice, ctx->stream));
+  CK(chain_tracks_current(ctx, (const int32_t*)ctx->scratch[SB_NEIGH].p, P, (float*)ctx->scratch[SB_WAVES].p, T));
+  HIPCHK(hipMemcpyAsync(signals, ctx->scratch[SB_WAVES].p, bs, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_track_pixel_map(ldsim_ctx* ctx, const int32_t* unique_pix, int64_t U, const int32_t* pixels,
+                                     const int32_t* distances, int64_t n, int32_t P, int32_t max_distance,
+                                     int64_t* track_pixel_map, int32_t M) {
+  NEED(ctx && track_pixel_map && (unique_pix || U == 0), "bad track_pixel_map arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  Tmp du, dp, dd, dm;
+  CK(du.alloc(U * 4)); CK(dp.alloc((size_t)n * P * 4)); CK(dd.alloc((size_t)n * P * 4)); CK(dm.alloc((size_t)U * M * 8));
+  if (U) HIPCHK(hipMemcpyAsync(du.p, unique_pix, U * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n * P) {
+    HIPCHK(hipMemcpyAsync(dp.p, pixels, (size_t)n * P * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dd.p, distances, (size_t)n * P * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (U * M) HIPCHK(hipMemcpyAsync(dm.p, track_pixel_map, (size_t)U * M * 8, hipMemcpyHostToDevice, ctx->stream));
+  CK(fee_launch_track_pixel_map(ctx, dm.as<int64_t>(), du.as<int32_t>(), U, dp.as<int32_t>(), dd.as<int32_t>(), n, P,
+                                max_distance, M));
+  if (U * M) HIPCHK(hipMemcpyAsync(track_pixel_map, dm.p, (size_t)U * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_sum_pixel_signals(ldsim_ctx* ctx, const float* signals, int64_t n, int32_t P, int32_t T,
+                                       const double* track_starts, const int64_t* pim, const int64_t* tpm, int32_t M,
+                                       int64_t U, double* pixels_signals, double* pts, double* overflow) {
+  NEED(ctx && signals && track_starts && pim && tpm && pixels_signals && overflow, "null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int NT = ctx->h_consts.n_time_ticks;
+  Tmp ds, dst, dpim, dtpm, dps, dpts, dov;
+  size_t bs = (size_t)n * P * T * 4;
+  CK(ds.alloc(bs)); CK(dst.alloc(n * 8)); CK(dpim.alloc((size_t)n * P * 8)); CK(dtpm.alloc((size_t)U * M * 8));
+  CK(dps.alloc((size_t)U * NT * 8)); CK(dov.alloc(U * 8));
+  if (pts) CK(dpts.alloc((size_t)U * NT * M * 8));
+  HIPCHK(hipMemcpyAsync(ds.p, signals, bs, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst.p, track_starts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dpim.p, pim, (size_t)n * P * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dtpm.p, tpm, (size_t)U * M * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(dps.p, 0, (size_t)U * NT * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(dov.p, 0, U * 8, ctx->stream));
+  if (pts) HIPCHK(hipMemsetAsync(dpts.p, 0, (size_t)U * NT * M * 8, ctx->stream));
+  CK(fee_launch_sum_pixel_signals(ctx, dps.as<double>(), ds.as<float>(), dst.as<double>(), dpim.as<int64_t>(),
+                                  dtpm.as<int64_t>(), pts ? dpts.as<double>() : nullptr, dov.as<double>(), n, P, T, NT,
+                                  M));
+  HIPCHK(hipMemcpyAsync(pixels_signals, dps.p, (size_t)U * NT * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(overflow, dov.p, U * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (pts) HIPCHK(hipMemcpyAsync(pts, dpts.p, (size_t)U * NT * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_get_adc_values(ldsim_ctx* ctx, const double* ps, const double* pts, int64_t U, int32_t NT,
+                                    int32_t M, const double* time_ticks, int32_t n_time_ticks, double time_padding,
+                                    const double* thresholds, double* adc_list, double* adc_ticks, double* fractions) {
+  NEED(ctx && ps && thresholds && adc_list && adc_ticks, "null argument");
+  NEED(ctx->h_consts.reset_noise_charge == 0 && ctx->h_consts.uncorrelated_noise_charge == 0 &&
+           ctx->h_consts.discriminator_noise == 0,
+       "FEE noise must be 0: the reference's Numba xoroshiro128p stream is not reproduced");
+  NEED(n_time_ticks == NT + 1 && time_ticks, "time_ticks must be linspace(0, stop, N_t+1)");
+  // the kernel regenerates linspace(0, stop, N_t+1); honour the caller's stop value
+  HIPCHK(hipSetDevice(ctx->device));
+  LdsimConsts saved = ctx->h_consts;
+  LdsimConsts tmp = saved;
+  tmp.time_interval[1] = time_ticks[NT];
+  tmp.n_time_ticks = NT;
+  CK(ldsim_set_consts(ctx, &tmp));
+  const int A = saved.max_adc_values;
+  Tmp dps, dpts, dthr, dadc, dtk, dfr;
+  CK(dps.alloc((size_t)U * NT * 8)); CK(dthr.alloc(U * 8)); CK(dadc.alloc((size_t)U * A * 8)); CK(dtk.alloc((size_t)U * A * 8));
+  if (pts) CK(dpts.alloc((size_t)U * NT * M * 8));
+  if (fractions) CK(dfr.alloc((size_t)U * A * M * 8));
+  HIPCHK(hipMemcpyAsync(dps.p, ps, (size_t)U * NT * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dthr.p, thresholds, U * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (pts) HIPCHK(hipMemcpyAsync(dpts.p, pts, (size_t)U * NT * M * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (fractions) HIPCHK(hipMemsetAsync(dfr.p, 0, (size_t)U * A * M * 8, ctx->stream));
+  int rc = fee_launch_adc_dense(ctx, dps.as<double>(), pts ? dpts.as<double>() : nullptr, U, NT, M, dthr.as<double>(),
+                                time_padding, dadc.as<double>(), dtk.as<double>(),
+                                (fractions && pts) ? dfr.as<double>() : nullptr);
+  if (!rc) {
+    HIPCHK(hipMemcpyAsync(adc_list, dadc.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(adc_ticks, dtk.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (fractions) HIPCHK(hipMemcpyAsync(fractions, dfr.p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  int rc2 = ldsim_set_consts(ctx, &saved);
+  return rc ? rc : rc2;
+}
+
+extern "C" int ldsim_digitize(ldsim_ctx* ctx, const double* integral, int64_t n, const double* gain, double* adcs) {
+  NEED(ctx && integral && adcs, "null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  Tmp di, dg, dout;
+  CK(di.alloc(n * 8)); CK(dout.alloc(n * 8));
+  if (gain) CK(dg.alloc(n * 8));
+  if (n) HIPCHK(hipMemcpyAsync(di.p, integral, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (gain && n) HIPCHK(hipMemcpyAsync(dg.p, gain, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  CK(fee_launch_digitize(ctx, di.as<double>(), gain ? dg.as<double>() : nullptr, dout.as<double>(), n));
+  if (n) HIPCHK(hipMemcpyAsync(adcs, dout.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_light_incidence(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                     int32_t n_out, float* nph, float* t0det, int32_t* voxel) {
+  NEED(ctx && nph && t0det && voxel && n_out >= 0, "null argument");
+  NEED(ctx->d_lut_vis && ctx->d_eff, "light LUT / channel tables not set");
+  NEED(n_out <= ctx->n_light_ch, "more output channels than light channels configured");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  Tmp dn, dt, dv;
+  size_t bc = (size_t)n * n_out * 4;
+  CK(dn.alloc(bc)); CK(dt.alloc(bc)); CK(dv.alloc((size_t)n * 12));
+  HIPCHK(hipMemsetAsync(dn.p, 0, bc, ctx->stream));
+  HIPCHK(hipMemsetAsync(dt.p, 0, bc, ctx->stream));
+  HIPCHK(hipMemsetAsync(dv.p, 0, (size_t)n * 12, ctx->stream));
+  CK(light_launch_incidence(ctx, n_out, dn.as<float>(), dt.as<float>(), dv.as<int32_t>()));
+  if (bc) {
+    HIPCHK(hipMemcpyAsync(nph, dn.p, bc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t0det, dt.p, bc, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (n) HIPCHK(hipMemcpyAsync(voxel, dv.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                       const int32_t* voxel, const int64_t* track_id, const float* nph, int32_t n_inc,
+                                       const int32_t* op_channel, int32_t n_det, const int32_t* sorted_indices,
+                                       double start_time, int32_t n_ticks, float* out, int64_t* true_id,
+                                       double* true_ph, int32_t max_truth) {
+  NEED(ctx && voxel && track_id && nph && op_channel && sorted_indices && out, "null argument");
+  NEED(ctx->d_lut_t0avg, "light LUT not set");
+  NEED(max_truth == 0 || (true_id && true_ph), "truth arrays missing");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  Tmp dv, dti, dn, dop, dsi, dout, dtid, dtph;
+  size_t bo = (size_t)n_det * n_ticks;
+  CK(dv.alloc((size_t)n * 12)); CK(dti.alloc(n * 8)); CK(dn.alloc((size_t)n * n_inc * 4)); CK(dop.alloc(n_det * 4));
+  CK(dsi.alloc((size_t)n_det * n * 4)); CK(dout.alloc(bo * 4)); CK(dtid.alloc(bo * max_truth * 8 + 8));
+  CK(dtph.alloc(bo * max_truth * 8 + 8));
+  if (n) {
+    HIPCHK(hipMemcpyAsync(dv.p, voxel, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dti.p, track_id, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dn.p, nph, (size_t)n * n_inc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dsi.p, sorted_indices, (size_t)n_det * n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipMemcpyAsync(dop.p, op_channel, n_det * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dout.p, out, bo * 4, hipMemcpyHostToDevice, ctx->stream));   // accumulates into the caller's array
+  if (max_truth) {
+    HIPCHK(hipMemcpyAsync(dtid.p, true_id, bo * max_truth * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dtph.p, true_ph, bo * max_truth * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  CK(light_launch_sum(ctx, dv.as<int32_t>(), dti.as<int64_t>(), dn.as<float>(), n_inc, dop.as<int32_t>(), n_det,
+                      dsi.as<int32_t>(), start_time, n_ticks, dout.as<float>(), dtid.as<int64_t>(), dtph.as<double>(),
+                      max_truth));
+  HIPCHK(hipMemcpyAsync(out, dout.p, bo * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (max_truth) {
+    HIPCHK(hipMemcpyAsync(true_id, dtid.p, bo * max_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(true_ph, dtph.p, bo * max_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- (2) chain -------------------------------------------------------------------------------------------------------
+extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int32_t want_fractions,
+                                  LdsimChainStats* stats) {
+  NEED(ctx, "null ctx");
+  NEED(ctx->d_resp, "no response table set (ldsim_set_response)");
+  NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
+  NEED(ctx->h_consts.reset_noise_charge == 0 && ctx->h_consts.uncorrelated_noise_charge == 0 &&
+           ctx->h_consts.discriminator_noise == 0,
+       "FEE noise must be 0: the reference's Numba xoroshiro128p stream is not reproduced");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = chain_run(ctx, seg_begin, seg_end, want_fractions);
+  if (stats) *stats = ctx->stats;
+  return rc;
+}
+
+extern "C" int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
+                                    double* adc_list, double* adc_ticks, double* adc_digit, int64_t* tpm,
+                                    double* fractions) {
+  NEED(ctx, "null ctx");
+  const int64_t U = ctx->chain_U;
+  if (capacity < U) {
+    ldsim_set_error("capacity %lld < required %lld rows", (long long)capacity, (long long)U);
+    return LDSIM_ENOSPC;
+  }
+  if (U == 0) return 0;
+  const int A = ctx->h_consts.max_adc_values, M = ctx->h_consts.max_tracks_per_pixel;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (unique_pix) HIPCHK(hipMemcpyAsync(unique_pix, ctx->scratch[SB_UPIX].p, U * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (batch) HIPCHK(hipMemcpyAsync(batch, ctx->scratch[SB_UBATCH].p, U * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (adc_list) HIPCHK(hipMemcpyAsync(adc_list, ctx->scratch[SB_ADC].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (adc_ticks) HIPCHK(hipMemcpyAsync(adc_ticks, ctx->scratch[SB_TICKS].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (adc_digit) HIPCHK(hipMemcpyAsync(adc_digit, ctx->scratch[SB_DIGIT].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (tpm) HIPCHK(hipMemcpyAsync(tpm, ctx->scratch[SB_TPM].p, (size_t)U * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (fractions) {
+    NEED(ctx->want_fractions, "fractions were not requested in the last ldsim_charge_chain call");
+    HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes) {
+  NEED(ctx && dev_rows && n_rows && row_bytes, "null argument");
+  *dev_rows = ctx->scratch[SB_HITS].p;
+  *n_rows = ctx->chain_hits;
+  *row_bytes = 24;
+  return 0;
+}
+
+extern "C" int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms) {
+  NEED(ctx, "null ctx");
+  if (current_ms) *current_ms = ctx->ms_current;
+  if (adc_ms) *adc_ms = ctx->ms_adc;
+  if (total_ms) *total_ms = ctx->ms_total;
+  return 0;
+}

@@ -1,0 +1,54 @@
+// ldsim_args.h -- kernel argument blocks shared by the kernel translation units and the chain glue.
+#pragma once
+#include "ldsim_dev.h"
+
+struct CurArgs {
+  SegStore s;
+  const LdsimConsts* c;
+  const double* resp;
+  int32_t ni, nj, nk;
+  int32_t k_first, k_last;       // response support (exact zeros outside), or [0, nk-1]
+  const int32_t* pair_val;       // sorted pair list: value = r*P + ipix   (chain mode) or NULL (dense mode)
+  const unsigned long long* pair_key;  // key carrying the pixel id            (chain mode)
+  const int32_t* pixels;         // dense mode: pixels[S][P]
+  int64_t seg_begin;             // first resident segment of this call (r is relative to it)
+  int32_t P;
+  int64_t n_pairs;
+  float* out;                    // [n_pairs][T]
+  int32_t T;                     // row stride == max ticks
+  const int32_t* tmax_batch;     // per-batch max_length (chain) or NULL -> T
+  int32_t batch0;
+  double prune_log;
+  unsigned long long* counters;  // [0] ambiguous-rounding slices, [1] degenerate pairs
+};
+
+struct FeeArgs {
+  const LdsimConsts* c;
+  // unique pixels
+  int64_t U;
+  const int32_t* upix;
+  const int32_t* ubatch;
+  const int64_t* uoff;        // [U+1] offsets into the sorted pair list
+  // sorted pairs
+  const int32_t* pair_val;    // r*P + ipix
+  const unsigned long long* pair_key;
+  int32_t P;
+  const double* track_starts; // [n_seg] relative index r
+  const float* waves;         // [n_pairs][T]
+  int32_t T;
+  const int32_t* batch_first; // [n_batches] first relative segment index of each batch
+  int32_t batch0;
+  double threshold;
+  double time_padding;
+  // outputs
+  double* adc_list;           // [U][A]
+  double* adc_ticks;          // [U][A]
+  double* adc_digit;          // [U][A]
+  int64_t* tpm;               // [U][M]
+  double* fractions;          // [U][A][M] or NULL
+  unsigned long long* counters;  // [2] overflow pixels, [3] hits
+  int32_t* hit_count;         // [U]
+};
+
+int current_launch(ldsim_ctx* ctx, const CurArgs& args);
+int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F);

@@ -1,0 +1,132 @@
+// ldsim_dev.h -- shared host/device declarations for libldsim_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/ldsim.h"
+
+#define LDSIM_WAVE 64
+
+// ---- segment store: struct of arrays in HBM, one f64 column per hot-path field -------------------
+// Values are held "as stored": after a kernel mutates a field the column holds the value narrowed
+// through the record's storage dtype (f4 rounding / u4 truncation), exactly what the next reference
+// kernel would read back from the record.
+struct SegStore {
+  double* f[LDSIM_NFIELDS - 1];  // all float-like fields (index = enum ldsim_field), n_electrons included
+  int32_t* pixel_plane;
+  int32_t* batch;                // (event, TPC-group, sub-batch) id; <0 = not simulated
+  int32_t store_code[LDSIM_NFIELDS];
+  int64_t n;
+  int64_t cap;
+};
+
+// ---- Python / Numba scalar semantics on device -----------------------------------------------------
+__device__ __forceinline__ double py_round(double x) { return rint(x); }  // half-to-even (v_rndne_f64)
+
+// Python float floor division (CPython float_divmod algorithm, which Numba reproduces)
+__device__ __forceinline__ double py_floordiv(double vx, double wx) {
+  double mod = fmod(vx, wx);
+  double div = (vx - mod) / wx;
+  if (mod != 0.0) {
+    if ((wx < 0) != (mod < 0)) {
+      mod += wx;
+      div -= 1.0;
+    }
+  }
+  double fd;
+  if (div != 0.0) {
+    fd = floor(div);
+    if (div - fd > 0.5) fd += 1.0;
+  } else {
+    fd = copysign(0.0, vx / wx);
+  }
+  return fd;
+}
+
+__device__ __forceinline__ int64_t ifloordiv(int64_t a, int64_t b) {
+  int64_t q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) q -= 1;
+  return q;
+}
+__device__ __forceinline__ int64_t ifloormod(int64_t a, int64_t b) { return a - ifloordiv(a, b) * b; }
+
+__device__ __forceinline__ double narrow_store(double v, int code) {
+  switch (code) {
+    case LDSIM_F4: return (double)(float)v;
+    case LDSIM_I4: return (double)(int32_t)v;
+    case LDSIM_U4: return (double)(uint32_t)v;
+    case LDSIM_I8: return (double)(int64_t)v;
+    case LDSIM_U8: return (double)(uint64_t)v;
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ int64_t pixel2id(const LdsimConsts* c, int64_t px, int64_t py, int64_t plane) {
+  return px + c->n_pixels[0] * (py + c->n_pixels[1] * plane);
+}
+__device__ __forceinline__ void id2pixel(const LdsimConsts* c, int64_t pid, int64_t& px, int64_t& py, int64_t& plane) {
+  px = ifloormod(pid, c->n_pixels[0]);
+  py = ifloormod(ifloordiv(pid, c->n_pixels[0]), c->n_pixels[1]);
+  plane = ifloordiv(pid, (int64_t)c->n_pixels[0] * c->n_pixels[1]);
+}
+__device__ __forceinline__ bool pix_in_range(const LdsimConsts* c, int64_t x, int64_t y, int64_t plane) {
+  return 0 <= x && x < c->n_pixels[0] && 0 <= y && y < c->n_pixels[1] && 0 <= plane && plane < c->n_tpc;
+}
+
+// ---- host-side context --------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct ldsim_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  LdsimConsts h_consts;
+  LdsimConsts* d_consts = nullptr;
+  // response table
+  double* d_resp = nullptr;
+  int32_t ni = 0, nj = 0, nk = 0;
+  int32_t resp_k_first = 0, resp_k_last = -1;  // support of the table over all cells (exact zeros outside)
+  // light
+  double* d_eff = nullptr;
+  int32_t* d_ch2tpc = nullptr;
+  int32_t n_light_ch = 0;
+  float *d_lut_vis = nullptr, *d_lut_t0 = nullptr, *d_lut_t0avg = nullptr, *d_lut_td = nullptr;
+  int32_t lut_nx = 0, lut_ny = 0, lut_nz = 0, lut_ndet = 0, lut_nprof = 0;
+  // options
+  double prune_log = 30.0;
+  int trim_response = 1;
+  // resident segments
+  SegStore seg{};
+  DevBuf seg_block;
+  DevBuf raw;          // AoS staging (H2D/D2H)
+  DevBuf scratch[24];  // named scratch buffers, grown on demand
+  // chain results
+  LdsimChainStats stats{};
+  int64_t chain_U = 0, chain_hits = 0;
+  int want_fractions = 0;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double ms_current = 0, ms_adc = 0, ms_total = 0;
+};
+
+// scratch slots
+enum {
+  SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
+  SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS
+};
+
+void ldsim_set_error(const char* fmt, ...);
+int ldsim_ensure(ldsim_ctx* ctx, int slot, size_t bytes);
+int ldsim_ensure_buf(ldsim_ctx* ctx, DevBuf* b, size_t bytes);
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      ldsim_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return LDSIM_EHIP;                                                                  \
+    }                                                                                     \
+  } while (0)

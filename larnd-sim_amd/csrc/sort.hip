@@ -1,0 +1,173 @@
+// sort.hip -- device-wide sort / scan steps of the chain (rocPRIM), and the small glue kernels around them.
+// a7 (cli/simulate_pixels.py:952-957,1019-1026): unique pixel set + index map, here as a stable radix sort
+// of (batch, pixel, ring-code) keys whose value is the pair's position in segment order.
+#include <string.h>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "ldsim_dev.h"
+
+// key = batch(24) | pixel(32) | ringcode(4, 15 = invalid) ; invalid pairs get ~0 and sort last
+__global__ void make_keys_kernel(const int32_t* __restrict__ neigh, const int32_t* __restrict__ nrad,
+                                 const int32_t* __restrict__ batch, int64_t seg_begin, int32_t batch0, int P,
+                                 int64_t n_entries, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals,
+                                 unsigned long long* __restrict__ counters) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int valid = 0;
+  if (i < n_entries) {
+    int32_t pix = neigh[i];
+    int64_t r = i / P;
+    int32_t b = batch[seg_begin + r];
+    unsigned long long key = ~0ull;
+    if (pix >= 0 && b >= 0) {
+      int32_t d = nrad[i];
+      unsigned long long dn = (d < 0 || d > 14) ? 15ull : (unsigned long long)d;
+      key = ((unsigned long long)(uint32_t)(b - batch0) << 36) | ((unsigned long long)(uint32_t)pix << 4) | dn;
+      valid = 1;
+    }
+    keys[i] = key;
+    vals[i] = (int32_t)i;
+  }
+  unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[4], (unsigned long long)__popcll(m));
+}
+
+__global__ void heads_kernel(const unsigned long long* __restrict__ keys, int64_t n_valid, int32_t* __restrict__ heads) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_valid) return;
+  heads[i] = (i == 0 || (keys[i] >> 4) != (keys[i - 1] >> 4)) ? 1 : 0;
+}
+
+__global__ void fill_unique_kernel(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ heads,
+                                   const int32_t* __restrict__ uidx, int64_t n_valid, int32_t batch0,
+                                   int32_t* __restrict__ upix, int32_t* __restrict__ ubatch, int64_t* __restrict__ uoff,
+                                   int64_t U) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) uoff[U] = n_valid;
+  if (i >= n_valid || !heads[i]) return;
+  int32_t u = uidx[i];
+  upix[u] = (int32_t)((keys[i] >> 4) & 0xFFFFFFFFull);
+  ubatch[u] = (int32_t)(keys[i] >> 36) + batch0;
+  uoff[u] = i;
+}
+
+// first relative segment index of every batch in [seg_begin, seg_end)
+__global__ void batch_first_kernel(const int32_t* __restrict__ batch, int64_t seg_begin, int64_t n, int32_t batch0,
+                                   int32_t* __restrict__ first) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int32_t b = batch[seg_begin + r];
+  if (b < 0) return;
+  if (r == 0 || batch[seg_begin + r - 1] != b) first[b - batch0] = (int32_t)r;
+}
+
+__global__ void tmax_batch_kernel(SegStore s, const LdsimConsts* __restrict__ c, int64_t begin, int64_t n, int32_t batch0,
+                                  double* __restrict__ starts, int32_t* __restrict__ tmax_b) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int64_t i = begin + r;
+  double t_end = py_round((s.f[LDSIM_T_END][i] + 1) / c->time_sampling) * c->time_sampling;
+  double t_start = py_round((s.f[LDSIM_T_START][i] - c->time_padding) / c->time_sampling) * c->time_sampling;
+  starts[r] = t_start;
+  int32_t b = s.batch[i];
+  if (b < 0) return;
+  double len = ceil((t_end - t_start) / c->time_sampling);
+  if (len > 0 && len < 2.0e9) atomicMax(&tmax_b[b - batch0], (int32_t)len);
+}
+
+// compact hit rows for the multi-GPU all-gather: {batch i32, pixel i32, adc i32, tick f64-bits hi/lo}
+__global__ void compact_hits_kernel(const int32_t* __restrict__ upix, const int32_t* __restrict__ ubatch,
+                                    const int32_t* __restrict__ hit_count, const int32_t* __restrict__ hit_off,
+                                    const double* __restrict__ digit, const double* __restrict__ ticks, int A, int64_t U,
+                                    int32_t* __restrict__ rows) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  int n = hit_count[u];
+  int64_t o = hit_off[u];
+  for (int h = 0; h < n; h++) {
+    int32_t* r = rows + (o + h) * 6;
+    r[0] = ubatch[u];
+    r[1] = upix[u];
+    r[2] = (int32_t)digit[u * A + h];
+    r[3] = h;
+    double t = ticks[u * A + h];
+    *(double*)(r + 4) = t;
+  }
+}
+
+extern "C++" {
+static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
+
+int sort_make_keys(ldsim_ctx* ctx, const int32_t* neigh, const int32_t* nrad, int64_t seg_begin, int32_t batch0, int P,
+                   int64_t n_entries, unsigned long long* keys, int32_t* vals, unsigned long long* counters) {
+  if (n_entries == 0) return 0;
+  hipLaunchKernelGGL(make_keys_kernel, dim3(nblk(n_entries, 256)), dim3(256), 0, ctx->stream, neigh, nrad,
+                     ctx->seg.batch, seg_begin, batch0, P, n_entries, keys, vals, counters);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_pairs(ldsim_ctx* ctx, unsigned long long* keys_in, unsigned long long* keys_out, int32_t* vals_in,
+               int32_t* vals_out, int64_t n) {
+  if (n == 0) return 0;
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 64, ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, tmp);
+  if (rc) return rc;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->scratch[SB_SORTTMP].p, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
+                                   64, ctx->stream));
+  return 0;
+}
+
+int sort_exclusive_scan_i32(ldsim_ctx* ctx, const int32_t* in, int32_t* out, int64_t n) {
+  if (n == 0) return 0;
+  size_t tmp = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, tmp, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, tmp);
+  if (rc) return rc;
+  HIPCHK(rocprim::exclusive_scan(ctx->scratch[SB_SORTTMP].p, tmp, in, out, (int32_t)0, (size_t)n,
+                                 rocprim::plus<int32_t>(), ctx->stream));
+  return 0;
+}
+
+int sort_heads(ldsim_ctx* ctx, const unsigned long long* keys, int64_t n_valid, int32_t* heads) {
+  if (n_valid == 0) return 0;
+  hipLaunchKernelGGL(heads_kernel, dim3(nblk(n_valid, 256)), dim3(256), 0, ctx->stream, keys, n_valid, heads);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_fill_unique(ldsim_ctx* ctx, const unsigned long long* keys, const int32_t* heads, const int32_t* uidx,
+                     int64_t n_valid, int32_t batch0, int32_t* upix, int32_t* ubatch, int64_t* uoff, int64_t U) {
+  hipLaunchKernelGGL(fill_unique_kernel, dim3(nblk(n_valid > 0 ? n_valid : 1, 256)), dim3(256), 0, ctx->stream, keys,
+                     heads, uidx, n_valid, batch0, upix, ubatch, uoff, U);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_batch_first(ldsim_ctx* ctx, int64_t seg_begin, int64_t n, int32_t batch0, int32_t* first) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(batch_first_kernel, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->seg.batch, seg_begin, n,
+                     batch0, first);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_tmax_batch(ldsim_ctx* ctx, int64_t seg_begin, int64_t n, int32_t batch0, double* starts, int32_t* tmax_b) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(tmax_batch_kernel, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->seg, ctx->d_consts,
+                     seg_begin, n, batch0, starts, tmax_b);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_compact_hits(ldsim_ctx* ctx, const int32_t* upix, const int32_t* ubatch, const int32_t* hit_count,
+                      const int32_t* hit_off, const double* digit, const double* ticks, int A, int64_t U, int32_t* rows) {
+  if (U == 0) return 0;
+  hipLaunchKernelGGL(compact_hits_kernel, dim3(nblk(U, 256)), dim3(256), 0, ctx->stream, upix, ubatch, hit_count,
+                     hit_off, digit, ticks, A, U, rows);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}

@@ -1,0 +1,79 @@
+"""
+Device-resident charge chain: segments stay in HBM from quench to ADC.
+
+Replaces the body of the reference's batch loop (cli/simulate_pixels.py:917-1105: max_pixels ->
+get_pixels -> unique -> time_intervals -> tracks_current -> pixel_index_map -> get_track_pixel_map2 ->
+sum_pixel_signals -> get_adc_values -> digitize) for any number of (event, TPC-group) batches per call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import consts, lib
+from .abi import LdsimChainStats
+from .layout import make_layout
+
+
+class ChargeChain:
+    def __init__(self, response=None, device=None):
+        self.ctx = lib.context(device=device, noise_zero=False)
+        self.n = 0
+        if response is not None:
+            lib.set_response(response, self.ctx)
+
+    def upload(self, tracks, batch_id=None):
+        """H2D + unpack into the SoA segment store. ``batch_id``: int32 per segment, non-decreasing, <0 = skip."""
+        lay = make_layout(tracks.dtype)
+        self._layout = lay
+        b = None if batch_id is None else np.ascontiguousarray(batch_id, dtype=np.int32)
+        tr = np.ascontiguousarray(tracks)
+        lib.check(lib.load().ldsim_segments_upload(self.ctx, lib.ptr(tr), C.c_int64(tr.shape[0]), C.byref(lay),
+                                                   lib.ptr(b)))
+        self.n = tr.shape[0]
+
+    def quench_drift(self, mode=None):
+        mode = consts.physics.BIRKS if mode is None else mode
+        lib.check(lib.load().ldsim_dev_quench_drift(self.ctx, C.c_int32(int(mode))))
+
+    def download_segments(self, tracks):
+        lay = make_layout(tracks.dtype)
+        lib.check(lib.load().ldsim_segments_download(self.ctx, lib.ptr(tracks), C.c_int64(tracks.shape[0]),
+                                                     C.byref(lay)))
+        return tracks
+
+    def run(self, seg_begin=0, seg_end=None, want_fractions=False):
+        seg_end = self.n if seg_end is None else seg_end
+        st = LdsimChainStats()
+        lib.check(lib.load().ldsim_charge_chain(self.ctx, C.c_int64(seg_begin), C.c_int64(seg_end),
+                                                C.c_int32(int(want_fractions)), C.byref(st)))
+        self.stats = st
+        self._want_fractions = bool(want_fractions)
+        return st
+
+    def kernel_ms(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib.check(lib.load().ldsim_chain_kernel_ms(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(current_ms=a.value, adc_ms=b.value, total_ms=c.value)
+
+    def download(self, fractions=None):
+        """Per-unique-(batch, pixel) results of the last run(), reference dtypes."""
+        U = int(self.stats.n_unique)
+        A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
+        out = dict(unique_pix=np.zeros(U, dtype=np.int32), batch=np.zeros(U, dtype=np.int32),
+                   adc_list=np.zeros((U, A)), adc_ticks_list=np.zeros((U, A)), adc_digit=np.zeros((U, A)),
+                   track_pixel_map=np.full((U, M), -1, dtype=np.int64))
+        fr = None
+        if fractions if fractions is not None else self._want_fractions:
+            fr = np.zeros((U, A, M))
+            out['current_fractions'] = fr
+        lib.check(lib.load().ldsim_chain_download(self.ctx, C.c_int64(U), lib.ptr(out['unique_pix']),
+                                                  lib.ptr(out['batch']), lib.ptr(out['adc_list']),
+                                                  lib.ptr(out['adc_ticks_list']), lib.ptr(out['adc_digit']),
+                                                  lib.ptr(out['track_pixel_map']), lib.ptr(fr)))
+        return out
+
+    def compact_hits(self):
+        """(device pointer, n_rows, row_bytes) of the compact hit list of the last run()."""
+        p, n, rb = C.c_void_p(), C.c_int64(), C.c_int32()
+        lib.check(lib.load().ldsim_chain_compact_hits(self.ctx, C.byref(p), C.byref(n), C.byref(rb)))
+        return p.value, n.value, rb.value

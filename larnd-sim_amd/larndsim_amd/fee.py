@@ -1,0 +1,41 @@
+"""Front-end electronics: self-trigger scan and digitisation -- mirrors larndsim/fee.py get_adc_values
+(:517-655) and digitize (:499-515).  Packet export (fee.py:30-497) is out of scope."""
+import ctypes as C
+
+import numpy as np
+
+from . import consts, lib
+from ._kernel import kernel
+
+
+def digitize(integral_list, gain=None):
+    """``fee.digitize(integral_list, gain=GAIN*mV/e)``: ADC counts (f64), half-even rounding, clipped to 0..255."""
+    q = np.ascontiguousarray(integral_list, dtype=np.float64)
+    out = np.empty_like(q)
+    g = None if gain is None else np.ascontiguousarray(np.broadcast_to(gain, q.shape), dtype=np.float64)
+    lib.check(lib.load().ldsim_digitize(lib.context(), lib.ptr(q), C.c_int64(q.size), lib.ptr(g), lib.ptr(out)))
+    return out
+
+
+@kernel
+def get_adc_values(pixels_signals, pixels_signals_tracks, time_ticks, adc_list, adc_ticks_list, time_padding,
+                   rng_states, current_fractions, pixel_thresholds):
+    """``get_adc_values[bpg, tpb](...)`` with the reference's argument order.  ``rng_states`` is ignored: the
+    FEE noise constants must be 0 (the Numba xoroshiro128p stream is not reproduced); a non-zero noise
+    constant raises."""
+    ps = np.ascontiguousarray(pixels_signals, dtype=np.float64)
+    U, NT = ps.shape
+    pts = None if pixels_signals_tracks is None else np.ascontiguousarray(pixels_signals_tracks, dtype=np.float64)
+    M = pts.shape[2] if pts is not None else (current_fractions.shape[2] if current_fractions is not None else 0)
+    tt = np.ascontiguousarray(time_ticks, dtype=np.float64)
+    thr = np.ascontiguousarray(pixel_thresholds, dtype=np.float64)
+    adc = np.zeros(adc_list.shape); tk = np.zeros(adc_ticks_list.shape)
+    fr = np.zeros(current_fractions.shape) if current_fractions is not None else None
+    lib.check(lib.load().ldsim_get_adc_values(lib.context(), lib.ptr(ps), lib.ptr(pts), C.c_int64(U), C.c_int32(NT),
+                                              C.c_int32(M), lib.ptr(tt), C.c_int32(len(tt)),
+                                              C.c_double(float(time_padding)), lib.ptr(thr), lib.ptr(adc), lib.ptr(tk),
+                                              lib.ptr(fr)))
+    adc_list[:] = adc
+    adc_ticks_list[:] = tk
+    if fr is not None:
+        current_fractions[:] = fr

@@ -1,0 +1,118 @@
+"""
+ctypes loader of ``libldsim_hip.so`` (the C-ABI in include/ldsim.h) and the process-wide context.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, every compute
+entry point raises ``LdsimError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import consts
+from .abi import LdsimChainStats, LdsimConsts, LdsimTrackLayout, pack_consts
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldsim_hip.so")
+
+
+class LdsimError(RuntimeError):
+    pass
+
+
+_lib = None
+_ctx = None
+_ctx_device = None
+
+EXPORTS = [
+    "ldsim_last_error", "ldsim_abi_version", "ldsim_device_count", "ldsim_ctx_create", "ldsim_ctx_destroy",
+    "ldsim_set_consts", "ldsim_set_response", "ldsim_set_light_channels", "ldsim_set_light_lut", "ldsim_set_option",
+    "ldsim_synchronize", "ldsim_quench", "ldsim_drift", "ldsim_max_pixels", "ldsim_get_pixels",
+    "ldsim_time_intervals", "ldsim_tracks_current", "ldsim_track_pixel_map", "ldsim_sum_pixel_signals",
+    "ldsim_get_adc_values", "ldsim_digitize", "ldsim_light_incidence", "ldsim_sum_light_signals",
+    "ldsim_segments_upload", "ldsim_segments_download", "ldsim_dev_quench_drift", "ldsim_charge_chain",
+    "ldsim_chain_download", "ldsim_chain_compact_hits", "ldsim_chain_kernel_ms",
+]
+
+
+def load():
+    """dlopen the HIP library (does not touch the GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LdsimError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C larnd-sim_amd/csrc). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ldsim_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(_lib, name)   # fail loudly on a missing symbol
+    return _lib
+
+
+def device_count():
+    return int(load().ldsim_device_count())
+
+
+def check(rc):
+    if rc != 0:
+        raise LdsimError(f"ldsim error {rc}: {load().ldsim_last_error().decode()}")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def context(device=None, refresh_consts=True, noise_zero=False):
+    """The process-wide ldsim_ctx (created on first use); constants re-frozen from ``consts`` each call."""
+    global _ctx, _ctx_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _ctx is None else _ctx_device
+    if _ctx is not None and device != _ctx_device:
+        lib.ldsim_ctx_destroy(_ctx)
+        _ctx = None
+    c = pack_consts(noise_zero=noise_zero)
+    if _ctx is None:
+        h = C.c_void_p()
+        check(lib.ldsim_ctx_create(C.c_int(device), C.byref(c), C.byref(h)))
+        _ctx, _ctx_device = h, device
+    elif refresh_consts:
+        check(lib.ldsim_set_consts(_ctx, C.byref(c)))
+    return _ctx
+
+
+def destroy_context():
+    global _ctx
+    if _ctx is not None:
+        load().ldsim_ctx_destroy(_ctx)
+        _ctx = None
+
+
+def set_response(response, ctx=None):
+    ctx = ctx or context()
+    r = np.ascontiguousarray(response, dtype=np.float64)
+    if r.ndim != 3:
+        raise ValueError("response must be [ni][nj][nk]")
+    check(load().ldsim_set_response(ctx, ptr(r), C.c_int32(r.shape[0]), C.c_int32(r.shape[1]), C.c_int32(r.shape[2])))
+
+
+def set_option(name, value, ctx=None):
+    ctx = ctx or context()
+    check(load().ldsim_set_option(ctx, name.encode(), C.c_double(value)))
+
+
+def set_light(lut=None, ctx=None):
+    """Upload light channel tables (from ``consts.light``) and, if given, the LUT (structured array)."""
+    ctx = ctx or context()
+    lib = load()
+    eff = np.ascontiguousarray(consts.light.OP_CHANNEL_EFFICIENCY, dtype=np.float64)
+    c2t = np.ascontiguousarray(consts.light.OP_CHANNEL_TO_TPC, dtype=np.int32)
+    check(lib.ldsim_set_light_channels(ctx, ptr(eff), ptr(c2t), C.c_int32(len(eff))))
+    if lut is not None:
+        vis = np.ascontiguousarray(lut['vis'], dtype=np.float32)
+        t0 = np.ascontiguousarray(lut['t0'], dtype=np.float32)
+        t0a = np.ascontiguousarray(lut['t0_avg'], dtype=np.float32)
+        td = np.ascontiguousarray(lut['time_dist'], dtype=np.float32)
+        nx, ny, nz, nd = lut.shape
+        check(lib.ldsim_set_light_lut(ctx, ptr(vis), ptr(t0), ptr(t0a), ptr(td), C.c_int32(nx), C.c_int32(ny),
+                                      C.c_int32(nz), C.c_int32(nd), C.c_int32(td.shape[-1])))

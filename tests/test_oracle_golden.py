@@ -49,3 +49,22 @@ def test_pixels_time_intervals(cfg):
     assert np.array_equal(starts, g["track_starts"])
     assert tmax == int(g["max_length"])
     assert (g["active"] == -1).any()        # the -1 gap quirk is exercised
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_tracks_current_sampled(cfg):
+    """Induced current at sampled ticks for diverse (segment, pixel) pairs incl. the pID == -1 quirk slots."""
+    H.load_cfg(cfg)
+    g = H.gold(f"sampled_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    neigh = g["neigh"]
+    T = int(g["max_length"])
+    resp = H.response_for(g["response_kind"])
+    sig = O.tracks_current(r, neigh, T, resp)
+    got = sig[:, :, g["ticks"]]
+    ref = g["signals"]
+    assert (ref != 0).sum() > 500
+    # same operation order as the reference -> f32 outputs agree to the last bit or two
+    np.testing.assert_allclose(got, ref, rtol=3e-7, atol=0)
+    nz = ref != 0
+    assert np.array_equal(got != 0, nz)
