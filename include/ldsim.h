@@ -177,6 +177,9 @@ int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const L
 /* Write the mutated fields (n_electrons, n_photons, pixel_plane, long_diff, tran_diff, t, t_start, t_end)
  * back into host records (D2H). */
 int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout);
+/* Re-unpack the uploaded (device-resident) records into the SoA store, discarding what quench/drift wrote:
+ * lets a caller re-run the path on the same resident input without another H2D copy. */
+int ldsim_segments_reset(ldsim_ctx* ctx);
 /* quench + drift over the resident segments (cli/simulate_pixels.py:732,742) */
 int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode);
 
@@ -187,7 +190,8 @@ typedef struct {
   int64_t n_batches;
   int64_t n_overflow;      /* pixels with more than max_tracks_per_pixel contributing segments */
   int32_t max_active, max_neigh, max_length;
-  int32_t reserved;
+  int32_t n_ambiguous;     /* z slices whose response shift sat within 1e-7 of a rounding boundary */
+  int64_t n_dfma;          /* f64 FMAs issued by the induced-current correlation loop (lanes x instructions) */
 } LdsimChainStats;
 
 /* Fused a5-a16 (max_pixels .. digitize) on resident segments [seg_begin, seg_end):

@@ -251,7 +251,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipStreamSynchronize(st));
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
-  ctx->stats.reserved = (int32_t)h_cnt[0];   // slices whose response shift sat on a rounding boundary
+  ctx->stats.n_ambiguous = (int32_t)h_cnt[0];
+  ctx->stats.n_dfma = (int64_t)h_cnt[5];
   CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
   CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
                        (int32_t*)ctx->scratch[SB_HITS].p));

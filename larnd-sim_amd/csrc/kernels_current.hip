@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   const bool do_prune = A.prune_log > 0;
   const double cut = -A.prune_log;
 
+  unsigned long long n_blocks = 0;   // 8-shift MAC blocks executed (each = 64 DFMA per lane)
   for (int tile0 = 0; tile0 < T; tile0 += TILE_TICKS) {
     double acc[TPL];
 #pragma unroll
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
             s_row[r] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
           }
           __syncthreads();
+          n_blocks += NU8 / 8;
           const double* Aj = &s_A[jj * NU_MAX];
           const double* rw = &s_row[M * TPL * tid];
           double w[M * (TPL - 1) + 8 + 1];
@@ -477,6 +479,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
     }
     __syncthreads();
   }
+  if (tid == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * CUR_THREADS);
 }
 
 extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {

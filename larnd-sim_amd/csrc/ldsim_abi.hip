@@ -243,6 +243,7 @@ static int upload_tracks(ldsim_ctx* ctx, const void* tracks, int64_t n, const Ld
   HIPCHK(hipSetDevice(ctx->device));
   CK(seg_reserve(ctx, n));
   ctx->seg.n = n;
+  ctx->seg_layout = *lay;
   for (int f = 0; f < LDSIM_NFIELDS; f++) ctx->seg.store_code[f] = lay->offset[f] >= 0 ? lay->dtype[f] : LDSIM_F8;
   if (n == 0) return 0;
   size_t bytes = (size_t)n * lay->itemsize;
@@ -284,6 +285,13 @@ extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t
 extern "C" int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
   NEED(ctx && tracks && layout, "null argument");
   return download_tracks(ctx, tracks, n, layout);
+}
+
+extern "C" int ldsim_segments_reset(ldsim_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  NEED(ctx->seg.n == 0 || ctx->raw.p, "no uploaded records");
+  HIPCHK(hipSetDevice(ctx->device));
+  return seg_launch_unpack(ctx, &ctx->seg_layout, ctx->seg.n);
 }
 
 static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {

@@ -102,6 +102,7 @@ struct ldsim_ctx {
   SegStore seg{};
   DevBuf seg_block;
   DevBuf raw;          // AoS staging (H2D/D2H)
+  LdsimTrackLayout seg_layout{};
   DevBuf scratch[24];  // named scratch buffers, grown on demand
   // chain results
   LdsimChainStats stats{};

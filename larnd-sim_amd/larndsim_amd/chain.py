@@ -31,6 +31,13 @@ class ChargeChain:
                                                    lib.ptr(b)))
         self.n = tr.shape[0]
 
+    def reset(self):
+        """Re-unpack the resident records (undo quench/drift) without another H2D copy."""
+        lib.check(lib.load().ldsim_segments_reset(self.ctx))
+
+    def synchronize(self):
+        lib.check(lib.load().ldsim_synchronize(self.ctx))
+
     def quench_drift(self, mode=None):
         mode = consts.physics.BIRKS if mode is None else mode
         lib.check(lib.load().ldsim_dev_quench_drift(self.ctx, C.c_int32(int(mode))))

@@ -319,11 +319,14 @@ double o_rho(double x, double y, double z, double q, const double* start, const 
 static double signf(double x) { return x >= 0 ? 1.0 : -1.0; } /* detsim.py:455-466 */
 
 /* ---- a9: tracks_current  (detsim.py:351-453; helpers :161-218) -------------------------------- */
+// pairs are independent: OpenMP over (segment, pixel) only parallelises the cpu_baseline timing
 int o_tracks_current(float* signals, const int32_t* pixels, const OTrack* tr, int64_t S, int64_t P, int64_t T,
                      const double* response, int64_t ni, int64_t nj, int64_t nk, const LdsimConsts* c) {
   const int NS = c->sampled_points;
-  for (int64_t itrk = 0; itrk < S; itrk++)
-    for (int64_t ipix = 0; ipix < P; ipix++) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t pr = 0; pr < S * P; pr++) {
+    {
+      const int64_t itrk = pr / P, ipix = pr % P;
       const OTrack* t = &tr[itrk];
       int64_t pID = pixels[itrk * P + ipix];
       int64_t px, py, pplane;
@@ -420,6 +423,7 @@ int o_tracks_current(float* signals, const int32_t* pixels, const OTrack* tr, in
       }
       free(charge); free(ii); free(jj); free(t0s);
     }
+  }
   return 0;
 }
 
