@@ -41,6 +41,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
     a.k_last = ctx->nk - 1;
   }
   a.prune_log = ctx->prune_log;
+  a.debug_phases = ctx->debug_phases;
 }
 
 // materialising tracks_current: dense [S][P] pixel array, signals [S][P][T]

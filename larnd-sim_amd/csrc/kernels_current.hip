@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
         }
         __syncthreads();
         // ---- (1) weights: rho*dV of every sample of this column, binned by (j, shift) ---------------------
-        const int total = nix * NS * n_sl;
+        const int total = (A.debug_phases & 1) ? nix * NS * n_sl : 0;
+        if (!(A.debug_phases & 1) && tid < NJ) { s_jflag[tid] = 1; s_A[tid * NU_MAX] = 1.0; }
         for (int idx = tid; idx < total; idx += CUR_THREADS) {
           int sl = idx % n_sl;
           int rest = idx / n_sl;
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
         __syncthreads();
         // ---- (2) per cell: stage the response row, sliding-window correlation ---------------------------------
         for (int jj = 0; jj < NJ; jj++) {
-          if (!s_jflag[jj]) continue;
+          if (!s_jflag[jj] || !(A.debug_phases & 2)) continue;
           const double* rrow = A.resp + ((int64_t)ci * A.nj + (jmin + jj)) * A.nk;
           // row element r  <->  response index k = kb + r,  kb = M*tile0 + u_min
           const int kb = M * tile0 + u_min;

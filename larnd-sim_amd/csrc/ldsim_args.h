@@ -19,6 +19,7 @@ struct CurArgs {
   const int32_t* tmax_batch;     // per-batch max_length (chain) or NULL -> T
   int32_t batch0;
   double prune_log;
+  int32_t debug_phases;
   unsigned long long* counters;  // [0] ambiguous-rounding slices, [1] degenerate pairs
 };
 

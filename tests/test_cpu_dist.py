@@ -1,0 +1,65 @@
+"""CPU: the multi-rank plumbing with gloo, world_size 2 (sharding is disjoint + complete, gather reassembles)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(REPO, "larnd-sim_amd"))
+    import torch
+    import torch.distributed as dist
+    from larndsim_amd import batching, consts, dist as ldist, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    consts.load_snapshot("2x2")
+    seg = synth.make_segments(9000, seed=5, segs_per_event=1500, spill=True)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    idx, my_bid = ldist.shard_segments(bid, order, table, rank, world)
+    assert (np.diff(my_bid) >= 0).all() and (my_bid >= 0).all()
+    # stand-in for the chain's compact hit rows: one row per owned segment {batch, segment index, ...}
+    rows = torch.zeros((len(idx), 6), dtype=torch.int32)
+    rows[:, 0] = torch.from_numpy(my_bid.astype(np.int32))
+    rows[:, 1] = torch.from_numpy(idx.astype(np.int32))
+    gathered, counts = ldist.allgather_rows(rows)
+    t = torch.tensor([float(len(idx))], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    q.put((rank, idx, gathered.numpy(), counts, float(t.item()), int((bid >= 0).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_allgather_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    (_, idx0, g0, c0, tot0, nsim), (_, idx1, g1, c1, tot1, _) = res
+    assert len(np.intersect1d(idx0, idx1)) == 0                 # disjoint shards
+    assert len(idx0) + len(idx1) == nsim == int(tot0) == int(tot1)
+    assert abs(len(idx0) - len(idx1)) <= 1500                   # balanced to within one batch
+    assert np.array_equal(g0, g1) and c0 == c1 == [len(idx0), len(idx1)]
+    assert np.array_equal(np.sort(g0[:, 1]), np.sort(np.r_[idx0, idx1]))
+    # rank order == batch order: the concatenation is sorted by batch id, like a single-GPU run
+    assert (np.diff(g0[:, 0]) >= 0).all()
