@@ -16,13 +16,17 @@
 #include "ldsim_args.h"
 
 #define CUR_THREADS 256
+#define NWAVE 4
 #define TPL 8                    // ticks per lane
-#define TILE_TICKS (CUR_THREADS * TPL)
+#define WTILE (64 * TPL)         // ticks per wave tile
+#define TILE_TICKS (NWAVE * WTILE)
 #define ZC 64                    // max z slices per chunk
 #define NU_MAX 64                // max distinct response shifts per chunk
 #define NJ_MAX 48                // max distinct j cells (response table <= 48 wide in j)
 #define NS_MAX 64                // max SAMPLED_POINTS
-#define NEDGE 4                  // edge k's: k=0 and up to 3 at the top of the window
+#define NEDGE 3                  // partially valid edge k's: k=0 and up to 2 at the top of the window
+#define ARENA 4608               // f64 weight entries held in LDS per column group
+#define CELLS_MAX 512            // response cells per column group
 
 
 struct PairGeo {
@@ -159,10 +163,16 @@ __device__ __forceinline__ bool slice_valid_at(const LdsimConsts* c, double t_st
   return (t0 < time_tick) && (time_tick < t0 + c->time_window);
 }
 
+
+// LDS row layout: one pad double per 8*M elements so that the 8*M-element lane stride of the sliding window
+// becomes 8*M+1 doubles -> conflict-free ds_read_b64 (MI355X_MICROARCH.md, LDS banking)
+template <int M>
+__device__ __forceinline__ int rpos(int r) { return r + (r >> (M == 1 ? 3 : 4)); }
+
 template <int M>
 __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   const LdsimConsts* c = A.c;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t pair = blockIdx.x;
   if (pair >= A.n_pairs) return;
 
@@ -191,80 +201,109 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   const double bin = c->response_bin_size;
 
   // ---- LDS -----------------------------------------------------------------------------------------
-  __shared__ double s_row[M * TILE_TICKS + NU_MAX + 16];
-  __shared__ double s_A[NJ_MAX * NU_MAX];
-  __shared__ double s_corr[TILE_TICKS];
-  __shared__ double s_C[NEDGE][NU_MAX];
-  __shared__ double s_Redge[NEDGE][NJ_MAX];
-  __shared__ double s_t0[ZC];
-  __shared__ double s_z[ZC];
-  __shared__ int s_shift[ZC];
-  __shared__ int s_inval[ZC];       // bit e set: slice NOT valid at edge e (needs a correction)
-  __shared__ int s_icell[NS_MAX], s_jcell[NS_MAX];
-  __shared__ int s_cols[NS_MAX], s_colcnt[NS_MAX];
-  __shared__ unsigned char s_colix[NS_MAX][NS_MAX];
-  __shared__ int s_jflag[NJ_MAX];
-  __shared__ int s_misc[8];
+  constexpr int ROWLEN = M * WTILE + NU_MAX + 16;
+  constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
+  __shared__ double s_row[NWAVE][ROWBUF];       // wave-private staged response rows
+  __shared__ double s_A[ARENA];                 // weights A[cell][u] of the current column group
+  __shared__ double s_Redge[NEDGE][CELLS_MAX];  // response at the partially valid edge k's, per cell
+  __shared__ double s_C[NEDGE][NU_MAX];         // weight*response of slices that are NOT valid at an edge
+  __shared__ double s_px[NS_MAX][2], s_py[NS_MAX][2], s_pz[ZC][2];   // separable parts of b and delta
+  __shared__ int s_shift[ZC], s_inval[ZC];
+  __shared__ short s_icell[NS_MAX], s_jcell[NS_MAX];
+  __shared__ short s_colof[NS_MAX];             // column slot of every ix (-1: outside the table)
+  __shared__ short s_coli[NS_MAX];              // response index i of every column slot
+  __shared__ unsigned char s_ixord[NS_MAX];     // ix values ordered by column slot
+  __shared__ short s_colstart[NS_MAX + 1];      // first position in s_ixord of every column
+  __shared__ unsigned short s_list[CELLS_MAX];  // active cells of the group, deterministic order
+  __shared__ unsigned char s_culo[CELLS_MAX], s_cuhi[CELLS_MAX];
+  __shared__ int s_misc[16];
 
-  // ---- sample -> response cell maps (detsim.py:434-446, :211-212) ------------------------------------
-  if (tid < NS) {
-    double x = g.x_start + g.sgnx * (tid * g.x_step - 4 * g.sT);
-    double xd = fabs(g.x_p - x);
-    int i = -1;
-    if (!(xd > bin * A.ni)) {
-      i = (int)py_round(xd / bin - 0.5);
-      if (i < 0 || i >= A.ni) i = -1;
-    }
-    s_icell[tid] = i;
-    double y = g.y_start + g.sgny * (tid * g.y_step - 4 * g.sT);
-    double yd = fabs(g.y_p - y);
-    int j = -1;
-    if (!(yd > bin * A.nj)) {
-      j = (int)py_round(yd / bin - 0.5);
-      if (j < 0 || j >= A.nj) j = -1;
-    }
-    s_jcell[tid] = j;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int ncol = 0, jmin = 1 << 30, jmax = -1;
-    for (int ix = 0; ix < NS; ix++) {
-      int i = s_icell[ix];
-      if (i < 0) continue;
-      int cidx = -1;
-      for (int q = 0; q < ncol; q++)
-        if (s_cols[q] == i) {
-          cidx = q;
-          break;
-        }
-      if (cidx < 0) {
-        cidx = ncol++;
-        s_cols[cidx] = i;
-        s_colcnt[cidx] = 0;
+  // ---- sample -> response cell maps (detsim.py:434-446, :211-212), columns = distinct i -------------------
+  if (wv == 0) {
+    int i = -1, j = -1;
+    if (lane < NS) {
+      double x = g.x_start + g.sgnx * (lane * g.x_step - 4 * g.sT);
+      double xd = fabs(g.x_p - x);
+      if (!(xd > bin * A.ni)) {
+        i = (int)py_round(xd / bin - 0.5);
+        if (i < 0 || i >= A.ni) i = -1;
       }
-      s_colix[cidx][s_colcnt[cidx]++] = ix;
+      double y = g.y_start + g.sgny * (lane * g.y_step - 4 * g.sT);
+      double yd = fabs(g.y_p - y);
+      if (!(yd > bin * A.nj)) {
+        j = (int)py_round(yd / bin - 0.5);
+        if (j < 0 || j >= A.nj) j = -1;
+      }
+      s_icell[lane] = (short)i;
+      s_jcell[lane] = (short)j;
+      // separable parts of rho's b and delta (detsim.py:114-118,146-148)
+      double ddx = x - g.sx, ddy = y - g.sy;
+      double iT2 = 1.0 / (g.sT * g.sT), i2T = 1.0 / (2 * g.sT * g.sT);
+      s_px[lane][0] = ddx * iT2 * (g.Dx / g.Dr);
+      s_px[lane][1] = ddx * ddx * i2T;
+      s_py[lane][0] = ddy * iT2 * (g.Dy / g.Dr);
+      s_py[lane][1] = ddy * ddy * i2T;
     }
-    for (int iy = 0; iy < NS; iy++) {
-      int j = s_jcell[iy];
-      if (j < 0) continue;
-      jmin = min(jmin, j);
-      jmax = max(jmax, j);
+    // leader of a column = first ix with that i; column slot = rank of the leader
+    int leader = lane;
+    for (int q = 0; q < NS; q++) {
+      int iq = __shfl(i, q);
+      if (q < leader && iq == i) leader = q;
     }
-    s_misc[0] = ncol;
-    s_misc[1] = jmin;
-    s_misc[2] = jmax;
+    bool is_leader = (lane < NS) && (i >= 0) && (leader == lane);
+    unsigned long long lm = __ballot(is_leader);
+    int slot = __popcll(lm & ((1ull << lane) - 1ull));
+    int myslot = __shfl(slot, leader);
+    if (i < 0 || lane >= NS) myslot = -1;
+    int ncol = __popcll(lm);
+    if (lane < NS) s_colof[lane] = (short)myslot;
+    if (is_leader) s_coli[slot] = (short)i;
+    // order ix by column slot: position = #ix with smaller slot + #earlier ix of the same slot
+    int posn = 0;
+    for (int q = 0; q < NS; q++) {
+      int sq = __shfl(myslot, q);
+      if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
+    }
+    if (myslot >= 0) s_ixord[posn] = (unsigned char)lane;
+    if (is_leader) s_colstart[slot] = (short)posn;
+    int nvalid = __popcll(__ballot(myslot >= 0));
+    int jmin = (j >= 0) ? j : (1 << 20), jmax = j;
+    for (int off = 32; off > 0; off >>= 1) {
+      jmin = min(jmin, __shfl_down(jmin, off));
+      jmax = max(jmax, __shfl_down(jmax, off));
+    }
+    if (lane == 0) {
+      s_colstart[ncol] = (short)nvalid;
+      s_misc[0] = ncol;
+      s_misc[1] = jmin;
+      s_misc[2] = jmax;
+    }
   }
   __syncthreads();
   const int ncol = s_misc[0], jmin = s_misc[1], jmax = s_misc[2];
   const int NJ = jmax - jmin + 1;
+  if (ncol == 0 || NJ <= 0) {
+    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
+    return;
+  }
 
   // ---- window-edge bookkeeping ----------------------------------------------------------------------
-  // val = (time_tick - t0)/dtr lies in (0, V) when the slice is in its window; k = round(val).
-  // k in [1, KC] is valid for every slice; k = 0 and k in (KC, KC+3] depend on the slice.
+  // val = (time_tick - t0)/dtr lies in (0, V) while a slice is inside its window; k = round(val).
+  // k = 0 is valid only for slices with val > 0; at the top, k is always valid if k + 0.5 < V, never if
+  // k - 0.5 >= V, and depends on the slice in between (at most two such k).
   const double V = TW / dtr;
-  const int KC = (int)ceil(V - 0.5) - 2;
-  int edge_k[NEDGE] = {0, KC + 1, KC + 2, KC + 3};
-  const int k_stage_hi = min(min(KC + 3, A.nk - 1), A.k_last);
+  int edge_k[NEDGE] = {0, -1, -1};
+  int k_top;   // last response index any slice can use
+  {
+    int ka = (int)floor(V - 0.5 - 1e-6);          // k <= ka: always valid
+    if ((double)ka + 0.5 >= V - 1e-6) ka--;
+    int kn = (int)ceil(V + 0.5 + 1e-6);           // k >= kn: never valid
+    k_top = kn - 1;
+    int ne = 1;
+    for (int k = ka + 1; k <= k_top && ne < NEDGE; k++) edge_k[ne++] = k;
+    if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;   // cannot happen for |fuzz| << 1
+  }
+  const int k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
   const int k_stage_lo = max(0, A.k_first);
 
   // first tick with time_tick >= 0 (detsim.py:418-420)
@@ -290,7 +329,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   // per-pair constants of rho (detsim.py:135-148)
   const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
   const double i2T = 1.0 / (2 * g.sT * g.sT), i2L = 1.0 / (2 * g.sL * g.sL);
-  const double iT2 = 1.0 / (g.sT * g.sT), iL2 = 1.0 / (g.sL * g.sL);
+  const double iL2 = 1.0 / (g.sL * g.sL);
   const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
   const double factor = g.q / g.Dr / (g.sT * g.sT * g.sL * sqrt(8 * M_PI * M_PI * M_PI));
   const double sqrt_a_2 = 2 * sqrt(a);
@@ -300,187 +339,291 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   const bool do_prune = A.prune_log > 0;
   const double cut = -A.prune_log;
 
-  unsigned long long n_blocks = 0;   // 8-shift MAC blocks executed (each = 64 DFMA per lane)
-  for (int tile0 = 0; tile0 < T; tile0 += TILE_TICKS) {
+  // response shift of a slice from the exact expression at a reference tick in the middle of its window
+  auto slice_shift = [&](int iz, double& z, double& t0, bool count) -> int {
+    z = g.z_start_int + iz * g.z_step;
+    t0 = fabs(z - g.z_anode) / c->v_drift - TW;
+    int it_ref = (int)((t0 + 0.5 * TW - g.t_start) / dt);
+    if (it_ref < 0) it_ref = 0;
+    double tt = g.t_start + it_ref * dt;
+    double val = (tt - t0) / dtr;
+    double kr = py_round(val);
+    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
+    return (int)kr - M * it_ref;
+  };
+
+  // ---- tick window that can see a non-zero response: fixed wave <-> tile assignment per pair --------------
+  {
+    int smin = 1 << 30, smax = -(1 << 30);
+    for (int iz = iz_lo + tid; iz <= iz_hi; iz += CUR_THREADS) {
+      double z, t0;
+      int sh = slice_shift(iz, z, t0, false);
+      smin = min(smin, sh);
+      smax = max(smax, sh);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      smin = min(smin, __shfl_down(smin, off));
+      smax = max(smax, __shfl_down(smax, off));
+    }
+    if (lane == 0) {
+      s_misc[8 + wv] = smin;
+      s_misc[12 + wv] = smax;
+    }
+  }
+  __syncthreads();
+  const int sh_min = min(min(s_misc[8], s_misc[9]), min(s_misc[10], s_misc[11]));
+  const int sh_max = max(max(s_misc[12], s_misc[13]), max(s_misc[14], s_misc[15]));
+  int it_w0 = it0, it_w1 = T;
+  if (sh_min <= sh_max) {
+    // k = M*it + s in [k_stage_lo, k_stage_hi]
+    int lo = (k_stage_lo - sh_max) / M - 1, hi = (k_stage_hi - sh_min) / M + 2;
+    it_w0 = max(it_w0, lo);
+    it_w1 = min(it_w1, hi);
+  }
+  if (sh_min > sh_max || it_w1 <= it_w0 || k_stage_hi < k_stage_lo) {
+    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
+    return;
+  }
+  unsigned long long n_blocks = 0;   // 8-shift MAC blocks executed by this lane's wave (each = 64 DFMA per lane)
+
+  for (int sup0 = it_w0; sup0 < it_w1; sup0 += TILE_TICKS) {
+    const int wlen = min(it_w1 - sup0, TILE_TICKS);
+    const int ntt = (wlen + WTILE - 1) / WTILE;            // 512-tick tiles in this super tile
+    // wave -> (tile, share rank): 4 tiles: one each; 2 tiles: two waves per tile; 1 tile: all four waves
+    int my_tile, share_rank, nshare;
+    if (ntt >= 3) { my_tile = wv; share_rank = 0; nshare = 1; }
+    else if (ntt == 2) { my_tile = wv >> 1; share_rank = wv & 1; nshare = 2; }
+    else { my_tile = 0; share_rank = wv; nshare = 4; }
+    const bool tile_live = my_tile < ntt;
+    const int tb = sup0 + my_tile * WTILE;                   // first tick of this wave's tile
     double acc[TPL];
 #pragma unroll
     for (int j = 0; j < TPL; j++) acc[j] = 0;
-    for (int i = tid; i < TILE_TICKS; i += CUR_THREADS) s_corr[i] = 0;
 
     int iz_next = iz_lo;
     while (iz_next <= iz_hi) {
-      // ---- slice chunk: shifts, validity ---------------------------------------------------------------
+      // ---- slice chunk: shifts, edge validity, separable z parts -------------------------------------------
       __syncthreads();
-      if (tid < ZC && iz_next + tid <= iz_hi) {
-        int iz = iz_next + tid;
-        double z = g.z_start_int + iz * g.z_step;
-        double t0 = fabs(z - g.z_anode) / c->v_drift - TW;
-        s_z[tid] = z;
-        s_t0[tid] = t0;
-        // shift from the exact expression at a reference tick in the middle of the window
-        int it_ref = (int)((t0 + 0.5 * TW - g.t_start) / dt);
-        if (it_ref < 0) it_ref = 0;
-        double tt = g.t_start + it_ref * dt;
-        double val = (tt - t0) / dtr;
-        double kr = py_round(val);
-        if (fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
-        int sh = (int)kr - M * it_ref;
-        s_shift[tid] = sh;
-        int inval = 0;
-#pragma unroll
-        for (int e = 0; e < NEDGE; e++) {
-          int num = edge_k[e] - sh;
-          bool ok = false;
-          if (num >= 0 && (num % M) == 0) {
-            int64_t kk;
-            ok = slice_valid_at(c, g.t_start, t0, num / M, kk) && kk == edge_k[e];
-          }
-          if (!ok) inval |= 1 << e;
-        }
-        s_inval[tid] = inval;
-      }
-      __syncthreads();
-      if (tid == 0) {
+      if (wv == 0) {
         int nmax = min(ZC, iz_hi - iz_next + 1);
-        int lo = s_shift[0], hi = s_shift[0], n = 1;
-        while (n < nmax) {
-          int sh = s_shift[n];
-          int nlo = min(lo, sh), nhi = max(hi, sh);
-          if (nhi - nlo + 1 > NU_MAX) break;
-          lo = nlo;
-          hi = nhi;
-          n++;
+        int sh = 0, inval = 0;
+        if (lane < nmax) {
+          int iz = iz_next + lane;
+          double z, t0;
+          sh = slice_shift(iz, z, t0, sup0 == it_w0);
+          double ddz = z - g.sz;
+          s_pz[lane][0] = ddz * iL2 * uz;
+          s_pz[lane][1] = ddz * ddz * i2L;
+          s_shift[lane] = sh;
+#pragma unroll
+          for (int e = 0; e < NEDGE; e++) {
+            bool ok = false;
+            int num = edge_k[e] - sh;
+            if (edge_k[e] >= 0 && num >= 0 && (num % M) == 0) {
+              int64_t kk;
+              ok = slice_valid_at(c, g.t_start, t0, num / M, kk) && kk == edge_k[e];
+            }
+            if (!ok) inval |= 1 << e;
+          }
+          s_inval[lane] = inval;
         }
-        s_misc[3] = n;
-        s_misc[4] = lo;
-        s_misc[5] = hi;
+        // longest prefix of slices whose shifts span <= NU_MAX values
+        int pmin = lane < nmax ? sh : (1 << 30), pmax = lane < nmax ? sh : -(1 << 30);
+        for (int off = 1; off < 64; off <<= 1) {
+          int a1 = __shfl_up(pmin, off), a2 = __shfl_up(pmax, off);
+          if (lane >= off) { pmin = min(pmin, a1); pmax = max(pmax, a2); }
+        }
+        bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
+        unsigned long long fm = __ballot(fits);
+        int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
+        int lo = __shfl(pmin, n - 1), hi = __shfl(pmax, n - 1);
+        if (lane == 0) { s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi; }
       }
       __syncthreads();
       const int n_sl = s_misc[3], u_min = s_misc[4];
       const int NU = s_misc[5] - u_min + 1;
       const int NU8 = (NU + 7) & ~7;
       for (int i = tid; i < NEDGE * NU_MAX; i += CUR_THREADS) (&s_C[0][0])[i] = 0;
+      const int cols_per_group = max(1, min(ARENA / (NJ * NU8), CELLS_MAX / NJ));
 
-      // ---- columns of response cells sharing i ------------------------------------------------------------
-      for (int col = 0; col < ncol; col++) {
-        const int ci = s_cols[col];
-        const int nix = s_colcnt[col];
+      for (int col0 = 0; col0 < ncol; col0 += cols_per_group) {
+        const int gcols = min(cols_per_group, ncol - col0);
+        const int ncell = gcols * NJ;
+        const int g_ix0 = s_colstart[col0], g_nix = s_colstart[col0 + gcols] - g_ix0;
         __syncthreads();
-        for (int i = tid; i < NJ * NU_MAX; i += CUR_THREADS) s_A[i] = 0;
-        if (tid < NJ_MAX) s_jflag[tid] = 0;
-        for (int i = tid; i < NEDGE * NJ; i += CUR_THREADS) {
-          int e = i / NJ, jj = i % NJ;
+        for (int i = tid; i < ncell * NU8; i += CUR_THREADS) s_A[i] = 0;
+        for (int i = tid; i < NEDGE * ncell; i += CUR_THREADS) {
+          int e = i / ncell, cell = i % ncell;
           int k = edge_k[e];
           double r = 0;
-          if (k >= k_stage_lo && k <= k_stage_hi) r = A.resp[((int64_t)ci * A.nj + (jmin + jj)) * A.nk + k];
-          s_Redge[e][jj] = r;
+          if (k >= k_stage_lo && k <= k_stage_hi)
+            r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + k];
+          s_Redge[e][cell] = r;
         }
         __syncthreads();
-        // ---- (1) weights: rho*dV of every sample of this column, binned by (j, shift) ---------------------
-        const int total = (A.debug_phases & 1) ? nix * NS * n_sl : 0;
-        if (!(A.debug_phases & 1) && tid < NJ) { s_jflag[tid] = 1; s_A[tid * NU_MAX] = 1.0; }
-        for (int idx = tid; idx < total; idx += CUR_THREADS) {
-          int sl = idx % n_sl;
-          int rest = idx / n_sl;
-          int iy = rest % NS;
-          int ixc = rest / NS;
-          int j = s_jcell[iy];
-          if (j < 0) continue;
-          int ix = s_colix[col][ixc];
-          double x = g.x_start + g.sgnx * (ix * g.x_step - 4 * g.sT);
-          double y = g.y_start + g.sgny * (iy * g.y_step - 4 * g.sT);
-          double z = s_z[sl];
-          double ddx = x - g.sx, ddy = y - g.sy, ddz = z - g.sz;
-          double b = -(ddx * iT2 * ux + ddy * iT2 * uy + ddz * iL2 * uz);
-          double delta = ddx * ddx * i2T + ddy * ddy * i2T + ddz * ddz * i2L;
-          double E = b * b * inv4a - delta;
-          double lo = b * inv_sa2, hi = lo + hi_off;
-          if (do_prune) {
-            double E2 = E;
-            if (lo > 0) E2 -= lo * lo;
-            else if (hi < 0) E2 -= hi * hi;
-            if (E2 < cut) continue;
-          }
-          double integral = erf(hi) - erf(lo);
-          if (integral == 0) continue;
-          double w = pref * integral * exp(E);
-          int u = s_shift[sl] - u_min;
-          int jj = j - jmin;
-          atomicAdd(&s_A[jj * NU_MAX + u], w);
-          s_jflag[jj] = 1;
-          int inval = s_inval[sl];
-          if (inval) {
+        // ---- (1) weights: every (iy, slice) of the chunk owned by one lane, sweeping the ix of the group ------
+        if (A.debug_phases & 1) {
+          const int npz = NS * n_sl;
+          for (int p = tid; p < npz; p += CUR_THREADS) {
+            int iy = p / n_sl, sl = p - iy * n_sl;
+            int j = s_jcell[iy];
+            if (j < 0) continue;
+            const int jj = j - jmin;
+            const int u = s_shift[sl] - u_min;
+            const int inval = s_inval[sl];
+            const double byz = s_py[iy][0] + s_pz[sl][0], dyz = s_py[iy][1] + s_pz[sl][1];
+            double wsum = 0, csum[NEDGE] = {0, 0, 0};
+            int cur_col = -1;
+            for (int gi = 0; gi < g_nix; gi++) {
+              const int ix = s_ixord[g_ix0 + gi];
+              const int colslot = s_colof[ix] - col0;
+              if (colslot != cur_col) {
+                if (wsum != 0) {
+                  int cell = cur_col * NJ + jj;
+                  atomicAdd(&s_A[cell * NU8 + u], wsum);
+                  if (inval) {
 #pragma unroll
-            for (int e = 0; e < NEDGE; e++)
-              if (inval & (1 << e)) {
-                double r = s_Redge[e][jj];
-                if (r != 0) atomicAdd(&s_C[e][u], w * r);
+                    for (int e = 0; e < NEDGE; e++)
+                      if (inval & (1 << e)) csum[e] = fma(wsum, s_Redge[e][cell], csum[e]);
+                  }
+                }
+                wsum = 0;
+                cur_col = colslot;
               }
+              double b = -(s_px[ix][0] + byz);
+              double delta = s_px[ix][1] + dyz;
+              double E = b * b * inv4a - delta;
+              double lo = b * inv_sa2, hi = lo + hi_off;
+              if (do_prune) {
+                double E2 = E;
+                if (lo > 0) E2 -= lo * lo;
+                else if (hi < 0) E2 -= hi * hi;
+                if (E2 < cut) continue;
+              }
+              double integral = erf(hi) - erf(lo);
+              if (integral == 0) continue;
+              wsum += pref * integral * exp(E);
+            }
+            if (wsum != 0) {
+              int cell = cur_col * NJ + jj;
+              atomicAdd(&s_A[cell * NU8 + u], wsum);
+              if (inval) {
+#pragma unroll
+                for (int e = 0; e < NEDGE; e++)
+                  if (inval & (1 << e)) csum[e] = fma(wsum, s_Redge[e][cell], csum[e]);
+              }
+            }
+            if (inval) {
+#pragma unroll
+              for (int e = 0; e < NEDGE; e++)
+                if (csum[e] != 0) atomicAdd(&s_C[e][u], csum[e]);
+            }
+          }
+        } else if (tid < ncell) {
+          s_A[tid * NU8] = 1.0;
+        }
+        __syncthreads();
+        // ---- active cells + their shift range, in deterministic (cell index) order -----------------------------
+        for (int cell = wv; cell < ncell; cell += NWAVE) {
+          double v = (lane < NU8) ? s_A[cell * NU8 + lane] : 0.0;
+          unsigned long long nz = __ballot(v != 0.0);
+          if (lane == 0) {
+            s_culo[cell] = nz ? (unsigned char)(__ffsll((long long)nz) - 1) : (unsigned char)255;
+            s_cuhi[cell] = nz ? (unsigned char)(63 - __clzll((long long)nz)) : (unsigned char)0;
           }
         }
         __syncthreads();
-        // ---- (2) per cell: stage the response row, sliding-window correlation ---------------------------------
-        for (int jj = 0; jj < NJ; jj++) {
-          if (!s_jflag[jj] || !(A.debug_phases & 2)) continue;
-          const double* rrow = A.resp + ((int64_t)ci * A.nj + (jmin + jj)) * A.nk;
-          // row element r  <->  response index k = kb + r,  kb = M*tile0 + u_min
-          const int kb = M * tile0 + u_min;
-          const int nrow = M * TILE_TICKS + NU8 + 8;
-          __syncthreads();
-          for (int r = tid; r < nrow; r += CUR_THREADS) {
-            int k = kb + r;
-            s_row[r] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
+        if (wv == 0) {
+          int nact = 0;
+          for (int base = 0; base < ncell; base += 64) {
+            int cell = base + lane;
+            bool act = (cell < ncell) && (s_culo[cell] != 255);
+            unsigned long long am = __ballot(act);
+            if (act) s_list[nact + __popcll(am & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            nact += __popcll(am);
           }
-          __syncthreads();
-          n_blocks += NU8 / 8;
-          const double* Aj = &s_A[jj * NU_MAX];
-          const double* rw = &s_row[M * TPL * tid];
-          double w[M * (TPL - 1) + 8 + 1];
-#pragma unroll
-          for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rw[q];
-          for (int u0 = 0; u0 < NU8; u0 += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rw[u0 + M * (TPL - 1) + 1 + q];
-#pragma unroll
-            for (int du = 0; du < 8; du++) {
-              double av = Aj[u0 + du];
-#pragma unroll
-              for (int j = 0; j < TPL; j++) acc[j] = fma(av, w[M * j + du], acc[j]);
+          if (lane == 0) s_misc[6] = nact;
+        }
+        __syncthreads();
+        // ---- (2) per cell: stage the response row (wave-private), sliding-window correlation ---------------------
+        const int nact = s_misc[6];
+        if (tile_live && (A.debug_phases & 2)) {
+          double* rowp = s_row[wv];
+          for (int li = share_rank; li < nact; li += nshare) {
+            const int cell = s_list[li];
+            const int ulo8 = s_culo[cell] & ~7;
+            const int nblk = (s_cuhi[cell] - ulo8) / 8 + 1;
+            const double* rrow = A.resp + ((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk;
+            // row element r  <->  response index k = kb + r
+            const int kb = M * tb + u_min + ulo8;
+            const int nrow = M * WTILE + nblk * 8 + 8;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int r = lane; r < nrow; r += 64) {
+              int k = kb + r;
+              rowp[rpos<M>(r)] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const double* Aj = &s_A[cell * NU8 + ulo8];
+            const int rl = M * TPL * lane;
+            double w[M * (TPL - 1) + 8 + 1];
 #pragma unroll
-            for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
+            for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rowp[rpos<M>(rl + q)];
+            for (int b8 = 0; b8 < nblk; b8++) {
+              const int u0 = b8 * 8;
+#pragma unroll
+              for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rowp[rpos<M>(rl + u0 + M * (TPL - 1) + 1 + q)];
+#pragma unroll
+              for (int du = 0; du < 8; du++) {
+                double av = Aj[u0 + du];
+#pragma unroll
+                for (int j = 0; j < TPL; j++) acc[j] = fma(av, w[M * j + du], acc[j]);
+              }
+#pragma unroll
+              for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
+            }
+            n_blocks += nblk;
           }
         }
       }
-      // ---- (3) window-edge corrections of this chunk -------------------------------------------------------------
+      // ---- (3) window-edge corrections of this chunk: tick it <-> shift u = k_e - M*it - u_min ------------------------
       __syncthreads();
-      for (int e = 0; e < NEDGE; e++) {
-        if (tid < NU) {
-          double cv = s_C[e][tid];
-          if (cv != 0) {
-            int num = edge_k[e] - (u_min + tid);
-            if (num >= 0 && (num % M) == 0) {
-              int it = num / M - tile0;
-              if (it >= 0 && it < TILE_TICKS) s_corr[it] += cv;
-            }
+      if (tile_live && share_rank == 0) {
+#pragma unroll
+        for (int e = 0; e < NEDGE; e++) {
+          if (edge_k[e] < 0) continue;
+#pragma unroll
+          for (int j = 0; j < TPL; j++) {
+            int it = tb + TPL * lane + j;
+            int u = edge_k[e] - M * it - u_min;
+            if (u >= 0 && u < NU) acc[j] -= s_C[e][u];
           }
         }
-        __syncthreads();
       }
       iz_next += n_sl;
     }
-    // ---- output: f32 store like the reference's `signals` (cli/simulate_pixels.py:1007-1009) ---------------------
+    // ---- output: combine the waves sharing a tile, f32 store like the reference's `signals` ---------------------------
     __syncthreads();
+    double* s_out = s_A;   // TILE_TICKS doubles
+    for (int rnk = 0; rnk < nshare; rnk++) {
+      if (tile_live && share_rank == rnk) {
 #pragma unroll
-    for (int j = 0; j < TPL; j++) s_row[TPL * tid + j] = acc[j] - s_corr[TPL * tid + j];
-    __syncthreads();
-    for (int i = tid; i < TILE_TICKS; i += CUR_THREADS) {
-      int it = tile0 + i;
-      if (it < A.T) out[it] = (it >= it0 && it < T) ? (float)s_row[i] : 0.f;
+        for (int j = 0; j < TPL; j++) {
+          int idx = my_tile * WTILE + TPL * lane + j;
+          s_out[idx] = (rnk == 0) ? acc[j] : s_out[idx] + acc[j];
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < wlen; i += CUR_THREADS) {
+      int it = sup0 + i;
+      if (it < A.T) out[it] = (it >= it0 && it < T) ? (float)s_out[i] : 0.f;
     }
     __syncthreads();
   }
-  if (tid == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * CUR_THREADS);
+  // ticks outside the response-visible window are exactly zero
+  for (int it = tid; it < A.T; it += CUR_THREADS)
+    if (it < it_w0 || it >= it_w1) out[it] = 0.f;
+  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
 }
 
 extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {
