@@ -25,7 +25,8 @@
 #define NJ_MAX 48                // max distinct j cells (response table <= 48 wide in j)
 #define NS_MAX 64                // max SAMPLED_POINTS
 #define NEDGE 3                  // partially valid edge k's: k=0 and up to 2 at the top of the window
-#define ARENA 4608               // f64 weight entries held in LDS per column group
+#define ARENA 4352               // f64 weight entries held in LDS per column group
+#define QLEN 128                 // survivor queue entries per wave
 #define CELLS_MAX 512            // response cells per column group
 
 
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   __shared__ short s_colstart[NS_MAX + 1];      // first position in s_ixord of every column
   __shared__ unsigned short s_list[CELLS_MAX];  // active cells of the group, deterministic order
   __shared__ unsigned char s_culo[CELLS_MAX], s_cuhi[CELLS_MAX];
+  __shared__ unsigned int s_q[NWAVE][QLEN];     // per-wave queue of samples that passed the cheap bound
   __shared__ int s_misc[16];
 
   // ---- sample -> response cell maps (detsim.py:434-446, :211-212), columns = distinct i -------------------
@@ -461,64 +463,69 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
           s_Redge[e][cell] = r;
         }
         __syncthreads();
-        // ---- (1) weights: every (iy, slice) of the chunk owned by one lane, sweeping the ix of the group ------
+        // ---- (1) weights.  Pass A (all lanes busy): the cheap bound on every sample, survivors pushed to a
+        //      wave-private queue.  Pass B (dense lanes): 2 erf + exp per survivor, f64 ds_add into A[cell][u]. ------
         if (A.debug_phases & 1) {
-          const int npz = NS * n_sl;
-          for (int p = tid; p < npz; p += CUR_THREADS) {
-            int iy = p / n_sl, sl = p - iy * n_sl;
-            int j = s_jcell[iy];
-            if (j < 0) continue;
-            const int jj = j - jmin;
-            const int u = s_shift[sl] - u_min;
-            const int inval = s_inval[sl];
-            const double byz = s_py[iy][0] + s_pz[sl][0], dyz = s_py[iy][1] + s_pz[sl][1];
-            double wsum = 0, csum[NEDGE] = {0, 0, 0};
-            int cur_col = -1;
-            for (int gi = 0; gi < g_nix; gi++) {
-              const int ix = s_ixord[g_ix0 + gi];
-              const int colslot = s_colof[ix] - col0;
-              if (colslot != cur_col) {
-                if (wsum != 0) {
-                  int cell = cur_col * NJ + jj;
-                  atomicAdd(&s_A[cell * NU8 + u], wsum);
-                  if (inval) {
-#pragma unroll
-                    for (int e = 0; e < NEDGE; e++)
-                      if (inval & (1 << e)) csum[e] = fma(wsum, s_Redge[e][cell], csum[e]);
-                  }
-                }
-                wsum = 0;
-                cur_col = colslot;
-              }
-              double b = -(s_px[ix][0] + byz);
-              double delta = s_px[ix][1] + dyz;
+          unsigned int* q = s_q[wv];
+          int qhead = 0, qn = 0;     // wave-uniform
+          auto process = [&](int n) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < n) {
+              unsigned int en = q[(qhead + lane) & (QLEN - 1)];
+              const int ix = en >> 12, iy = (en >> 6) & 63, sl = en & 63;
+              double b = -(s_px[ix][0] + s_py[iy][0] + s_pz[sl][0]);
+              double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
               double E = b * b * inv4a - delta;
               double lo = b * inv_sa2, hi = lo + hi_off;
-              if (do_prune) {
-                double E2 = E;
+              double integral = erf(hi) - erf(lo);
+              if (integral != 0) {
+                double w = pref * integral * exp(E);
+                const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
+                const int u = s_shift[sl] - u_min;
+                atomicAdd(&s_A[cell * NU8 + u], w);
+                const int inval = s_inval[sl];
+                if (inval) {
+#pragma unroll
+                  for (int e = 0; e < NEDGE; e++)
+                    if (inval & (1 << e)) {
+                      double r = s_Redge[e][cell];
+                      if (r != 0) atomicAdd(&s_C[e][u], w * r);
+                    }
+                }
+              }
+            }
+            qhead = (qhead + n) & (QLEN - 1);
+            qn -= n;
+          };
+          const int npz = NS * n_sl;
+          const int npz_pad = (npz + 63) & ~63;
+          for (int p0 = wv * 64; p0 < npz_pad; p0 += CUR_THREADS) {
+            const int p = p0 + lane;
+            bool pv = p < npz;
+            const int iy = pv ? p / n_sl : 0, sl = pv ? p - iy * n_sl : 0;
+            pv = pv && (s_jcell[iy] >= 0);
+            const double byz = s_py[iy][0] + s_pz[sl][0], dyz = s_py[iy][1] + s_pz[sl][1];
+            const unsigned int tag = ((unsigned)iy << 6) | (unsigned)sl;
+            for (int gi = 0; gi < g_nix; gi++) {
+              const int ix = s_ixord[g_ix0 + gi];
+              bool keep = pv;
+              if (do_prune && keep) {
+                double b = -(s_px[ix][0] + byz);
+                double E2 = b * b * inv4a - (s_px[ix][1] + dyz);
+                double lo = b * inv_sa2, hi = lo + hi_off;
                 if (lo > 0) E2 -= lo * lo;
                 else if (hi < 0) E2 -= hi * hi;
-                if (E2 < cut) continue;
+                keep = !(E2 < cut);
               }
-              double integral = erf(hi) - erf(lo);
-              if (integral == 0) continue;
-              wsum += pref * integral * exp(E);
-            }
-            if (wsum != 0) {
-              int cell = cur_col * NJ + jj;
-              atomicAdd(&s_A[cell * NU8 + u], wsum);
-              if (inval) {
-#pragma unroll
-                for (int e = 0; e < NEDGE; e++)
-                  if (inval & (1 << e)) csum[e] = fma(wsum, s_Redge[e][cell], csum[e]);
+              unsigned long long m = __ballot(keep);
+              if (m) {
+                if (keep) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
+                qn += __popcll(m);
+                if (qn >= 64) process(64);
               }
-            }
-            if (inval) {
-#pragma unroll
-              for (int e = 0; e < NEDGE; e++)
-                if (csum[e] != 0) atomicAdd(&s_C[e][u], csum[e]);
             }
           }
+          if (qn > 0) process(qn);
         } else if (tid < ncell) {
           s_A[tid * NU8] = 1.0;
         }
