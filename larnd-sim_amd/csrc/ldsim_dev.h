@@ -98,7 +98,7 @@ struct ldsim_ctx {
   // options
   double prune_log = 30.0;
   int trim_response = 1;
-  int debug_phases = 3;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
+  int debug_phases = 15;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments
   SegStore seg{};
   DevBuf seg_block;
