@@ -209,8 +209,30 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   a.tmax_batch = d_tmax_b;
   a.batch0 = batch0;
   a.counters = counters;
+  a.only_flagged = nullptr;
+  a.flag_stride = 0;
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  CK(current_launch(ctx, a));
+  bool split_done = false;
+  if (ctx->split_kernels) {
+    size_t ib, hb, cb;
+    split_sizes(&ib, &hb, &cb);
+    const unsigned long long wcap = (unsigned long long)n_valid * (unsigned long long)ctx->wbuf_doubles_per_pair;
+    CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
+    CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));
+    CK(ldsim_ensure(ctx, SB_CORR, (size_t)n_valid * cb));
+    CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
+    int rc = split_launch(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
+                          (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      // pairs that overflowed the split path's fixed capacities: recompute with the monolithic kernel
+      a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
+      a.flag_stride = (int32_t)(hb / 4);
+      CK(current_launch(ctx, a));
+      split_done = true;
+    }
+  }
+  if (!split_done) CK(current_launch(ctx, a));
   HIPCHK(hipEventRecord(ctx->ev[2], st));
 
   // ---- a13-a16 per-pixel sum, trigger scan, digitise ---------------------------------------------------------------------------------
@@ -254,6 +276,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   ctx->chain_hits = (int64_t)h_cnt[3];
   ctx->stats.n_ambiguous = (int32_t)h_cnt[0];
   ctx->stats.n_dfma = (int64_t)h_cnt[5];
+  ctx->n_fallback = (int64_t)h_cnt[6];
+  ctx->stats.n_fallback = (int64_t)h_cnt[6];
   CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
   CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
                        (int32_t*)ctx->scratch[SB_HITS].p));

@@ -13,204 +13,7 @@
 //       depends on the individual slice, with exact per-slice predicates,
 // and writes the f32 waveform.  All arithmetic is f64 (the reference's arithmetic type); only the
 // store narrows to f32 like the reference's `signals` array.
-#include "ldsim_args.h"
-#include "erfcx_table.h"
-
-#define CUR_THREADS 256
-#define NWAVE 4
-#define TPL 8                    // ticks per lane
-#define WTILE (64 * TPL)         // ticks per wave tile
-#define TILE_TICKS (NWAVE * WTILE)
-#define ZC 64                    // max z slices per chunk
-#define NU_MAX 64                // max distinct response shifts per chunk
-#define NJ_MAX 48                // max distinct j cells (response table <= 48 wide in j)
-#define NS_MAX 64                // max SAMPLED_POINTS
-#define NEDGE 3                  // partially valid edge k's: k=0 and up to 2 at the top of the window
-#define ARENA 4352               // f64 weight entries held in LDS per column group
-#define QLEN 128                 // survivor queue entries per wave
-#define CELLS_MAX 512            // response cells per column group
-
-
-struct PairGeo {
-  double x_p, y_p;
-  double sx, sy, sz;       // z-ordered start
-  double Dx, Dy, Dz, Dr;   // segment and its length
-  double dirx, diry, dirz;
-  double sT, sL, q;
-  double z_start_int, z_step, x_step, y_step, x_start, y_start, sgnx, sgny;
-  double t_start, z_anode, dV;
-  int z_steps;
-  bool ok;
-};
-
-__device__ __forceinline__ double sgn(double x) { return x >= 0 ? 1.0 : -1.0; }
-
-// detsim.py:42-112
-__device__ __forceinline__ void z_interval(const double* sp, const double* ep, double x_p, double y_p, double tol,
-                                           double& z_poca, double& z_lo, double& z_hi) {
-  const double *start, *end;
-  z_poca = z_lo = z_hi = 0;
-  if (sp[0] > ep[0]) {
-    start = ep;
-    end = sp;
-  } else if (sp[0] < ep[0]) {
-    start = sp;
-    end = ep;
-  } else {
-    return;
-  }
-  double xs = start[0], ys = start[1], xe = end[0], ye = end[1];
-  double m = (ye - ys) / (xe - xs);
-  double q = (xe * ys - xs * ye) / (xe - xs);
-  double a = m, b = -1, cc = q;
-  double x_poca = (b * (b * x_p - a * y_p) - a * cc) / (a * a + b * b);
-  double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
-  double length = sqrt(dx * dx + dy * dy + dz * dz);
-  double d0 = dx / length, d2 = dz / length;
-  double doca;
-  if (x_poca < start[0]) {
-    doca = sqrt((x_p - start[0]) * (x_p - start[0]) + (y_p - start[1]) * (y_p - start[1]));
-    x_poca = start[0];
-  } else if (x_poca > end[0]) {
-    doca = sqrt((x_p - end[0]) * (x_p - end[0]) + (y_p - end[1]) * (y_p - end[1]));
-    x_poca = end[0];
-  } else {
-    doca = fabs(a * x_p + b * y_p + cc) / sqrt(a * a + b * b);
-  }
-  double zp = start[2] + (x_poca - start[0]) / d0 * d2;
-  if (tol > doca) {
-    double length2D = sqrt((xe - xs) * (xe - xs) + (ye - ys) * (ye - ys));
-    double dir2x = (end[0] - start[0]) / length2D;
-    double deltaL2D = sqrt(tol * tol - doca * doca);
-    double x_plus = x_poca + deltaL2D * dir2x;
-    double x_minus = x_poca - deltaL2D * dir2x;
-    double plusL = (x_plus - start[0]) / d0;
-    double minusL = (x_minus - start[0]) / d0;
-    double plusZ = start[2] + d2 * plusL;
-    double minusZ = start[2] + d2 * minusL;
-    z_poca = zp;
-    z_lo = fmin(minusZ, plusZ);
-    z_hi = fmax(minusZ, plusZ);
-  }
-}
-
-// detsim.py:366-414: everything that does not depend on the tick or the sample
-__device__ void pair_geometry(const CurArgs& A, int64_t seg, int64_t pID, PairGeo& g) {
-  const LdsimConsts* c = A.c;
-  const SegStore& s = A.s;
-  g.ok = false;
-  int64_t px, py, pplane;
-  id2pixel(c, pID, px, py, pplane);
-  if (!(px >= 0 && py >= 0)) return;
-  int64_t bplane = pplane < 0 ? pplane + c->n_tpc : pplane;  // Python/Numba negative index wrap (pID == -1)
-  if (bplane < 0 || bplane >= c->n_tpc) return;
-  int32_t tplane = s.pixel_plane[seg];
-  if (tplane < 0 || tplane >= c->n_tpc) return;
-  const double(*pb)[2] = c->tpc_borders[bplane];
-  double x_p = px * c->pixel_pitch + pb[0][0];
-  double y_p = py * c->pixel_pitch + pb[1][0];
-  x_p += c->pixel_pitch / 2;
-  y_p += c->pixel_pitch / 2;
-  double start[3], end[3];
-  double xs = s.f[LDSIM_X_START][seg], ys = s.f[LDSIM_Y_START][seg], zs = s.f[LDSIM_Z_START][seg];
-  double xe = s.f[LDSIM_X_END][seg], ye = s.f[LDSIM_Y_END][seg], ze = s.f[LDSIM_Z_END][seg];
-  if (zs < ze) {
-    start[0] = xs; start[1] = ys; start[2] = zs; end[0] = xe; end[1] = ye; end[2] = ze;
-  } else {
-    end[0] = xs; end[1] = ys; end[2] = zs; start[0] = xe; start[1] = ye; start[2] = ze;
-  }
-  g.Dx = end[0] - start[0]; g.Dy = end[1] - start[1]; g.Dz = end[2] - start[2];
-  double length = sqrt(g.Dx * g.Dx + g.Dy * g.Dy + g.Dz * g.Dz);
-  g.Dr = length;
-  g.dirx = g.Dx / length; g.diry = g.Dy / length; g.dirz = g.Dz / length;
-  g.sT = s.f[LDSIM_TRAN_DIFF][seg];
-  g.sL = s.f[LDSIM_LONG_DIFF][seg];
-  g.q = s.f[LDSIM_N_ELECTRONS][seg];
-  double impact = fmax(sqrt((5 * g.sT) * (5 * g.sT) + (5 * g.sT) * (5 * g.sT)),
-                       sqrt(c->pixel_pitch * c->pixel_pitch + c->pixel_pitch * c->pixel_pitch) / 2) * 2;
-  double z_poca, z_s, z_e;
-  z_interval(start, end, x_p, y_p, impact, z_poca, z_s, z_e);
-  if (z_poca == 0) return;
-  g.x_p = x_p; g.y_p = y_p;
-  g.sx = start[0]; g.sy = start[1]; g.sz = start[2];
-  g.z_start_int = z_s - 4 * g.sL;
-  double z_end_int = z_e + 4 * g.sL;
-  double l0 = (z_s - start[2]) / g.dirz, l1 = (z_e - start[2]) / g.dirz;
-  g.x_start = start[0] + l0 * g.dirx; g.y_start = start[1] + l0 * g.diry;
-  double x_end = start[0] + l1 * g.dirx, y_end = start[1] + l1 * g.diry;
-  const int NS = c->sampled_points;
-  g.y_step = (fabs(y_end - g.y_start) + 8 * g.sT) / (NS - 1);
-  g.x_step = (fabs(x_end - g.x_start) + 8 * g.sT) / (NS - 1);
-  double z_sampling = c->time_sampling / 2.;
-  double zs_f = ceil(fabs(z_end_int - g.z_start_int) / z_sampling);
-  if (!(zs_f < 1.0e7)) return;   // NaN / absurd geometry: the reference's behaviour is undefined
-  g.z_steps = (int)fmax((double)NS, zs_f);
-  g.z_step = (z_end_int - g.z_start_int) / (g.z_steps - 1);
-  g.t_start = py_round((s.f[LDSIM_T_START][seg] - s.f[LDSIM_T0_START][seg] - c->time_padding) / c->time_sampling) *
-              c->time_sampling;
-  g.z_anode = c->tpc_borders[tplane][2][0];
-  g.sgnx = sgn(g.dirx); g.sgny = sgn(g.diry);
-  g.dV = fabs(g.x_step) * fabs(g.y_step) * fabs(g.z_step);
-  // anything non-finite -> no signal (reference: NaN propagation / undefined)
-  double chk = g.x_step + g.y_step + g.z_step + g.x_start + g.y_start + g.t_start + g.q + g.Dr;
-  if (!(fabs(chk) < 1e300) || !(g.sT > 0) || !(g.sL > 0) || !(g.Dr > 0)) return;
-  g.ok = true;
-}
-
-// exact reference predicates for one slice at one tick (detsim.py:418-428 + get_closest_waveform :213)
-__device__ __forceinline__ bool slice_valid_at(const LdsimConsts* c, double t_start, double t0, int it, int64_t& k) {
-  double time_tick = t_start + it * c->time_sampling;
-  k = (int64_t)py_round((time_tick - t0) / c->response_sampling);
-  if (time_tick < 0.) return false;
-  return (t0 < time_tick) && (time_tick < t0 + c->time_window);
-}
-
-
-// ---- rho without catastrophic cancellation and with one exp on the common path ----------------------------------
-// The reference evaluates exp(b^2/4a - delta + log(factor) + log(integral)) with
-// integral ~ erf(hi) - erf(lo) (detsim.py:150-157).  Same value, restated through erfcx(x) = exp(x^2) erfc(x)
-// (piecewise degree-9 polynomials, 1 ulp, tools/gen_erfcx_table.py): for lo, hi of the same sign
-//   exp(E) (erf(hi) - erf(lo)) = exp(E - A1^2) [erfcx(A1) - exp(-(A2^2 - A1^2)) erfcx(A2)],  A1 <= A2 the magnitudes,
-// which is accurate where the literal difference cancels (checked against 40-digit arithmetic: <= 5e-14 relative).
-__device__ __forceinline__ double tab_eval(const double (*T)[ERFCX_DEG + 1], int n, double x) {
-  int i = (int)(x * 8.0);
-  i = i < n - 1 ? i : n - 1;
-  const double s = (x - (i * 0.125 + 0.0625)) * 16.0;
-  const double* c = T[i];
-  double p = c[ERFCX_DEG];
-#pragma unroll
-  for (int d = ERFCX_DEG - 1; d >= 0; d--) p = fma(p, s, c[d]);
-  return p;
-}
-__device__ __forceinline__ double erfcx_pos(double x) {   // x >= 0
-  if (x < 16.0) return tab_eval(erfcx_tab, ERFCX_N, x);
-  const double t = 1.0 / (2 * x * x);
-  double acc = 1.0, term = 1.0;
-#pragma unroll
-  for (int m = 1; m < 9; m++) {
-    term = -term * (2 * m - 1) * t;
-    acc += term;
-  }
-  return acc / (x * 1.7724538509055160273);
-}
-__device__ __forceinline__ double erf_pos(double x) { return x >= 6.0 ? 1.0 : tab_eval(erf_tab, ERF_N, x); }
-
-// exp(E) * (erf(hi) - erf(lo)),  hi > lo
-__device__ __forceinline__ double exp_erf_diff(double E, double lo, double hi) {
-  if (lo < 0 && hi > 0) return exp(E) * (erf_pos(hi) + erf_pos(-lo));
-  const double al = fabs(lo), ah = fabs(hi);
-  const double A1 = fmin(al, ah), A2 = fmax(al, ah);
-  if (A1 < 2.0) return exp(E) * (erf_pos(A2) - erf_pos(A1));
-  const double e1 = exp(E - A1 * A1);
-  const double t = (A2 - A1) * (A2 + A1);
-  const double tail = t < 45.0 ? exp(-t) * erfcx_pos(A2) : 0.0;
-  return e1 * (erfcx_pos(A1) - tail);
-}
-
-// LDS row layout: one pad double per 8*M elements so that the 8*M-element lane stride of the sliding window
-// becomes 8*M+1 doubles -> conflict-free ds_read_b64 (MI355X_MICROARCH.md, LDS banking)
-template <int M>
-__device__ __forceinline__ int rpos(int r) { return r + (r >> (M == 1 ? 3 : 4)); }
+#include "current_common.h"
 
 template <int M>
 __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
@@ -218,6 +21,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t pair = blockIdx.x;
   if (pair >= A.n_pairs) return;
+  if (A.only_flagged && A.only_flagged[pair * A.flag_stride + 7] == 0) return;
 
   // ---- which (segment, pixel) -------------------------------------------------------------------
   int64_t seg, pID;

@@ -1,0 +1,760 @@
+// kernels_split.hip -- a9-a12 as two kernels (the default path of the chain):
+//
+//   weights_kernel<M>   one workgroup per (segment, pixel) pair: evaluates every charge sample once and emits the
+//                       pair's binned weights  A[cell][shift]  as compact "items" (cell id, first shift, #8-shift
+//                       blocks, offset into a global f64 arena) plus the window-edge corrections.  No response rows
+//                       are touched, so its LDS holds a larger weight arena and the erf/erfcx tables.
+//   mac_kernel<M>       one workgroup per block of 8 consecutive pairs of the pixel-sorted pair list (same pixel or
+//                       neighbours, i.e. mostly the same response cells): the pairs' item lists (sorted by cell) are
+//                       merged on the fly, every response row tile is staged ONCE per wave and reused by all pairs
+//                       that need it; per pair the register-tiled sliding-window correlation of kernels_current.hip.
+//
+// Pairs that exceed the fixed item / correction capacities are flagged and recomputed by the monolithic
+// current_kernel (kernels_current.hip), which has no such limits.
+#include "current_common.h"
+
+#define PB 8            // pairs per mac workgroup
+#define IMAX 512        // items per pair
+#define CMAX 192        // edge corrections per pair
+#define RUNS_MAX 8      // sorted runs (slice chunks) per pair
+#define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
+#define W_ARENA 5120
+#define W_CELLS 640
+#define MAC_SPAN 256    // max spread of first shifts staged together
+
+struct Item {
+  int32_t cell_nblk;   // cell | nblk << 16
+  int32_t sbase;       // response shift of weight[0]:  k = M*it + sbase + u
+  uint32_t woff_lo, woff_hi;
+};
+struct Corr {
+  int32_t tick, pad;
+  double val;
+};
+
+struct SplitArgs {
+  CurArgs c;
+  Item* items;            // [n_pairs][IMAX]
+  int32_t* hdr;           // [n_pairs][HDR_INTS]
+  Corr* corr;             // [n_pairs][CMAX]
+  double* wbuf;           // weight arena
+  unsigned long long wbuf_cap;   // doubles
+  unsigned long long* cursor;    // bump allocator (doubles)
+};
+
+__device__ __forceinline__ double tabL(const double* T, int n, double x) {   // table staged in LDS, [n][10]
+  int i = (int)(x * 8.0);
+  i = i < n - 1 ? i : n - 1;
+  const double s = (x - (i * 0.125 + 0.0625)) * 16.0;
+  const double* c = T + i * (ERFCX_DEG + 1);
+  double p = c[ERFCX_DEG];
+#pragma unroll
+  for (int d = ERFCX_DEG - 1; d >= 0; d--) p = fma(p, s, c[d]);
+  return p;
+}
+
+// =============================================================================================================
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
+  const CurArgs& A = S.c;
+  const LdsimConsts* c = A.c;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  int32_t* hdr = S.hdr + pair * HDR_INTS;
+
+  int64_t seg, pID;
+  {
+    int32_t v = A.pair_val[pair];
+    seg = A.seg_begin + v / A.P;
+    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
+  }
+  int T = A.T;
+  if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
+
+  PairGeo g;
+  pair_geometry(A, seg, pID, g);
+  auto write_empty = [&]() {
+    if (tid < HDR_INTS) hdr[tid] = 0;
+  };
+  if (!g.ok) { write_empty(); return; }
+  const int NS = c->sampled_points;
+  const double dt = c->time_sampling, dtr = c->response_sampling, TW = c->time_window;
+  const double bin = c->response_bin_size;
+
+  __shared__ double s_A[W_ARENA];
+  __shared__ double s_Redge[NEDGE][W_CELLS];
+  __shared__ double s_C[NEDGE][NU_MAX];
+  __shared__ double s_tx[ERFCX_N * (ERFCX_DEG + 1)], s_te[ERF_N * (ERFCX_DEG + 1)];
+  __shared__ double s_px[NS_MAX][2], s_py[NS_MAX][2], s_pz[ZC][2];
+  __shared__ int s_shift[ZC], s_inval[ZC];
+  __shared__ short s_icell[NS_MAX], s_jcell[NS_MAX], s_colof[NS_MAX], s_coli[NS_MAX], s_colstart[NS_MAX + 1];
+  __shared__ unsigned char s_ixord[NS_MAX];
+  __shared__ unsigned short s_list[W_CELLS];
+  __shared__ unsigned char s_culo[W_CELLS], s_cuhi[W_CELLS];
+  __shared__ unsigned short s_boff[W_CELLS];    // first 8-shift block of every listed cell inside the group's allocation
+  __shared__ unsigned int s_q[NWAVE][QLEN];
+  __shared__ int s_misc[24];
+  __shared__ unsigned long long s_base64;
+
+  for (int i = tid; i < ERFCX_N * (ERFCX_DEG + 1); i += CUR_THREADS) s_tx[i] = (&erfcx_tab[0][0])[i];
+  for (int i = tid; i < ERF_N * (ERFCX_DEG + 1); i += CUR_THREADS) s_te[i] = (&erf_tab[0][0])[i];
+
+  // ---- sample -> response cell maps; column slots ordered by response index i ---------------------------------
+  if (wv == 0) {
+    int i = -1, j = -1;
+    if (lane < NS) {
+      double x = g.x_start + g.sgnx * (lane * g.x_step - 4 * g.sT);
+      double xd = fabs(g.x_p - x);
+      if (!(xd > bin * A.ni)) {
+        i = (int)py_round(xd / bin - 0.5);
+        if (i < 0 || i >= A.ni) i = -1;
+      }
+      double y = g.y_start + g.sgny * (lane * g.y_step - 4 * g.sT);
+      double yd = fabs(g.y_p - y);
+      if (!(yd > bin * A.nj)) {
+        j = (int)py_round(yd / bin - 0.5);
+        if (j < 0 || j >= A.nj) j = -1;
+      }
+      s_icell[lane] = (short)i;
+      s_jcell[lane] = (short)j;
+      double ddx = x - g.sx, ddy = y - g.sy;
+      double iT2 = 1.0 / (g.sT * g.sT), i2T = 1.0 / (2 * g.sT * g.sT);
+      s_px[lane][0] = ddx * iT2 * (g.Dx / g.Dr);
+      s_px[lane][1] = ddx * ddx * i2T;
+      s_py[lane][0] = ddy * iT2 * (g.Dy / g.Dr);
+      s_py[lane][1] = ddy * ddy * i2T;
+    }
+    int leader = lane;
+    for (int q = 0; q < NS; q++) {
+      int iq = __shfl(i, q);
+      if (q < leader && iq == i) leader = q;
+    }
+    bool is_leader = (lane < NS) && (i >= 0) && (leader == lane);
+    // slot = rank of this column's i among the distinct i  -> cells come out sorted by (i, j)
+    int slot = 0;
+    for (int q = 0; q < NS; q++) {
+      int iq = __shfl(i, q);
+      bool lq = __shfl((int)is_leader, q);
+      if (lq && iq < i) slot++;
+    }
+    int myslot = (i < 0 || lane >= NS) ? -1 : slot;
+    int ncol = __popcll(__ballot(is_leader));
+    if (lane < NS) s_colof[lane] = (short)myslot;
+    if (is_leader) s_coli[slot] = (short)i;
+    int posn = 0;
+    for (int q = 0; q < NS; q++) {
+      int sq = __shfl(myslot, q);
+      if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
+    }
+    if (myslot >= 0) s_ixord[posn] = (unsigned char)lane;
+    if (is_leader) s_colstart[slot] = (short)posn;
+    int nvalid = __popcll(__ballot(myslot >= 0));
+    int jmin = (j >= 0) ? j : (1 << 20), jmax = j;
+    for (int off = 32; off > 0; off >>= 1) {
+      jmin = min(jmin, __shfl_down(jmin, off));
+      jmax = max(jmax, __shfl_down(jmax, off));
+    }
+    if (lane == 0) {
+      s_colstart[ncol] = (short)nvalid;
+      s_misc[0] = ncol;
+      s_misc[1] = jmin;
+      s_misc[2] = jmax;
+      s_misc[16] = 0;   // items emitted
+      s_misc[17] = 0;   // corrections emitted
+      s_misc[18] = 0;   // overflow
+      s_misc[19] = 0;   // runs
+    }
+  }
+  __syncthreads();
+  const int ncol = s_misc[0], jmin = s_misc[1], jmax = s_misc[2];
+  const int NJ = jmax - jmin + 1;
+  if (ncol == 0 || NJ <= 0) { write_empty(); return; }
+
+  const double V = TW / dtr;
+  int edge_k[NEDGE] = {0, -1, -1};
+  int k_top;
+  {
+    int ka = (int)floor(V - 0.5 - 1e-6);
+    if ((double)ka + 0.5 >= V - 1e-6) ka--;
+    int kn = (int)ceil(V + 0.5 + 1e-6);
+    k_top = kn - 1;
+    int ne = 1;
+    for (int k = ka + 1; k <= k_top && ne < NEDGE; k++) edge_k[ne++] = k;
+    if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;
+  }
+  const int k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
+  const int k_stage_lo = max(0, A.k_first);
+
+  int it0 = 0;
+  if (g.t_start < 0) {
+    int cand = (int)ceil(-g.t_start / dt) - 1;
+    if (cand < 0) cand = 0;
+    while (g.t_start + cand * dt < 0.) cand++;
+    it0 = cand;
+  }
+  int iz_lo = 0, iz_hi = g.z_steps - 1;
+  if (A.prune_log > 0 && g.z_step > 0) {
+    double cz = sqrt(2.0 * A.prune_log) * g.sL;
+    double zl = g.sz - cz, zh = g.sz + g.Dz + cz;
+    double fl = floor((zl - g.z_start_int) / g.z_step) - 1, fh = ceil((zh - g.z_start_int) / g.z_step) + 1;
+    if (fl > iz_lo) iz_lo = (int)fmin(fl, (double)g.z_steps);
+    if (fh < iz_hi) iz_hi = (int)fmax(fh, -1.0);
+  }
+  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
+  const double i2T = 1.0 / (2 * g.sT * g.sT), i2L = 1.0 / (2 * g.sL * g.sL);
+  const double iL2 = 1.0 / (g.sL * g.sL);
+  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
+  const double factor = g.q / g.Dr / (g.sT * g.sT * g.sL * sqrt(8 * M_PI * M_PI * M_PI));
+  const double sqrt_a_2 = 2 * sqrt(a);
+  const double inv_sa2 = 1.0 / sqrt_a_2, inv4a = 1.0 / (4 * a);
+  const double pref = factor * sqrt(M_PI) * inv_sa2 * g.dV;
+  const double hi_off = 2 * a * g.Dr * inv_sa2;
+  const bool do_prune = A.prune_log > 0;
+  const double cut = -A.prune_log;
+
+  auto slice_shift = [&](int iz, double& z, double& t0, bool count) -> int {
+    z = g.z_start_int + iz * g.z_step;
+    t0 = fabs(z - g.z_anode) / c->v_drift - TW;
+    int it_ref = (int)((t0 + 0.5 * TW - g.t_start) / dt);
+    if (it_ref < 0) it_ref = 0;
+    double tt = g.t_start + it_ref * dt;
+    double val = (tt - t0) / dtr;
+    double kr = py_round(val);
+    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
+    return (int)kr - M * it_ref;
+  };
+  {
+    int smin = 1 << 30, smax = -(1 << 30);
+    for (int iz = iz_lo + tid; iz <= iz_hi; iz += CUR_THREADS) {
+      double z, t0;
+      int sh = slice_shift(iz, z, t0, false);
+      smin = min(smin, sh);
+      smax = max(smax, sh);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      smin = min(smin, __shfl_down(smin, off));
+      smax = max(smax, __shfl_down(smax, off));
+    }
+    if (lane == 0) {
+      s_misc[8 + wv] = smin;
+      s_misc[12 + wv] = smax;
+    }
+  }
+  __syncthreads();
+  const int sh_min = min(min(s_misc[8], s_misc[9]), min(s_misc[10], s_misc[11]));
+  const int sh_max = max(max(s_misc[12], s_misc[13]), max(s_misc[14], s_misc[15]));
+  int it_w0 = it0, it_w1 = T;
+  if (sh_min <= sh_max) {
+    int lo = (k_stage_lo - sh_max) / M - 1, hi = (k_stage_hi - sh_min) / M + 2;
+    it_w0 = max(it_w0, lo);
+    it_w1 = min(it_w1, hi);
+  }
+  if (sh_min > sh_max || it_w1 <= it_w0 || k_stage_hi < k_stage_lo) { write_empty(); return; }
+
+  Item* items = S.items + pair * IMAX;
+  Corr* corr = S.corr + pair * CMAX;
+
+  auto wsample = [&](double E, double lo, double hi) -> double {   // exp(E) (erf(hi) - erf(lo)), tables in LDS
+    if (lo < 0 && hi > 0) {
+      double eh = hi >= 6.0 ? 1.0 : tabL(s_te, ERF_N, hi), el = -lo >= 6.0 ? 1.0 : tabL(s_te, ERF_N, -lo);
+      return exp(E) * (eh + el);
+    }
+    const double al = fabs(lo), ah = fabs(hi);
+    const double A1 = fmin(al, ah), A2 = fmax(al, ah);
+    if (A1 < 2.0) {
+      double e2 = A2 >= 6.0 ? 1.0 : tabL(s_te, ERF_N, A2);
+      return exp(E) * (e2 - tabL(s_te, ERF_N, A1));
+    }
+    const double e1 = exp(E - A1 * A1);
+    const double t = (A2 - A1) * (A2 + A1);
+    double tail = 0.0;
+    if (t < 45.0) tail = exp(-t) * (A2 < 16.0 ? tabL(s_tx, ERFCX_N, A2) : erfcx_pos(A2));
+    return e1 * ((A1 < 16.0 ? tabL(s_tx, ERFCX_N, A1) : erfcx_pos(A1)) - tail);
+  };
+
+  int iz_next = iz_lo;
+  while (iz_next <= iz_hi) {
+    __syncthreads();
+    if (wv == 0) {
+      int nmax = min(ZC, iz_hi - iz_next + 1);
+      int sh = 0, inval = 0;
+      if (lane < nmax) {
+        int iz = iz_next + lane;
+        double z, t0;
+        sh = slice_shift(iz, z, t0, true);
+        double ddz = z - g.sz;
+        s_pz[lane][0] = ddz * iL2 * uz;
+        s_pz[lane][1] = ddz * ddz * i2L;
+        s_shift[lane] = sh;
+#pragma unroll
+        for (int e = 0; e < NEDGE; e++) {
+          bool ok = false;
+          int num = edge_k[e] - sh;
+          if (edge_k[e] >= 0 && num >= 0 && (num % M) == 0) {
+            int64_t kk;
+            ok = slice_valid_at(c, g.t_start, t0, num / M, kk) && kk == edge_k[e];
+          }
+          if (!ok) inval |= 1 << e;
+        }
+        s_inval[lane] = inval;
+      }
+      int pmin = lane < nmax ? sh : (1 << 30), pmax = lane < nmax ? sh : -(1 << 30);
+      for (int off = 1; off < 64; off <<= 1) {
+        int a1 = __shfl_up(pmin, off), a2 = __shfl_up(pmax, off);
+        if (lane >= off) { pmin = min(pmin, a1); pmax = max(pmax, a2); }
+      }
+      bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
+      unsigned long long fm = __ballot(fits);
+      int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
+      int lo = __shfl(pmin, n - 1), hi = __shfl(pmax, n - 1);
+      if (lane == 0) {
+        s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
+        int r = s_misc[19];
+        if (r < RUNS_MAX) hdr[8 + r] = s_misc[16]; else s_misc[18] = 1;
+        s_misc[19] = r + 1;
+      }
+    }
+    __syncthreads();
+    const int n_sl = s_misc[3], u_min = s_misc[4];
+    const int NU = s_misc[5] - u_min + 1;
+    const int NU8 = (NU + 7) & ~7;
+    for (int i = tid; i < NEDGE * NU_MAX; i += CUR_THREADS) (&s_C[0][0])[i] = 0;
+    const int cols_per_group = max(1, min(W_ARENA / (NJ * NU8), W_CELLS / NJ));
+
+    for (int col0 = 0; col0 < ncol; col0 += cols_per_group) {
+      const int gcols = min(cols_per_group, ncol - col0);
+      const int ncell = gcols * NJ;
+      const int g_ix0 = s_colstart[col0], g_nix = s_colstart[col0 + gcols] - g_ix0;
+      __syncthreads();
+      for (int i = tid; i < ncell * NU8; i += CUR_THREADS) s_A[i] = 0;
+      for (int i = tid; i < NEDGE * ncell; i += CUR_THREADS) {
+        int e = i / ncell, cell = i % ncell;
+        int k = edge_k[e];
+        double r = 0;
+        if (k >= k_stage_lo && k <= k_stage_hi)
+          r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + k];
+        s_Redge[e][cell] = r;
+      }
+      __syncthreads();
+      {
+        unsigned int* q = s_q[wv];
+        int qhead = 0, qn = 0;
+        auto process = [&](int n) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < n) {
+            unsigned int en = q[(qhead + lane) & (QLEN - 1)];
+            const int ix = en >> 12, iy = (en >> 6) & 63, sl = en & 63;
+            double b = -(s_px[ix][0] + s_py[iy][0] + s_pz[sl][0]);
+            double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
+            double E = b * b * inv4a - delta;
+            double lo = b * inv_sa2, hi = lo + hi_off;
+            double w = pref * wsample(E, lo, hi);
+            if (w != 0) {
+              const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
+              const int u = s_shift[sl] - u_min;
+              atomicAdd(&s_A[cell * NU8 + u], w);
+              const int inval = s_inval[sl];
+              if (inval) {
+#pragma unroll
+                for (int e = 0; e < NEDGE; e++)
+                  if (inval & (1 << e)) {
+                    double r = s_Redge[e][cell];
+                    if (r != 0) atomicAdd(&s_C[e][u], w * r);
+                  }
+              }
+            }
+          }
+          qhead = (qhead + n) & (QLEN - 1);
+          qn -= n;
+        };
+        const int npz = NS * n_sl;
+        const int npz_pad = (npz + 63) & ~63;
+        for (int p0 = wv * 64; p0 < npz_pad; p0 += CUR_THREADS) {
+          const int p = p0 + lane;
+          bool pv = p < npz;
+          const int iy = pv ? p / n_sl : 0, sl = pv ? p - iy * n_sl : 0;
+          pv = pv && (s_jcell[iy] >= 0);
+          const double byz = s_py[iy][0] + s_pz[sl][0], dyz = s_py[iy][1] + s_pz[sl][1];
+          const unsigned int tag = ((unsigned)iy << 6) | (unsigned)sl;
+          for (int gi = 0; gi < g_nix; gi++) {
+            const int ix = s_ixord[g_ix0 + gi];
+            bool keep = pv;
+            if (do_prune && keep) {
+              double b = -(s_px[ix][0] + byz);
+              double E2 = b * b * inv4a - (s_px[ix][1] + dyz);
+              double lo = b * inv_sa2, hi = lo + hi_off;
+              if (lo > 0) E2 -= lo * lo;
+              else if (hi < 0) E2 -= hi * hi;
+              keep = !(E2 < cut);
+            }
+            unsigned long long m = __ballot(keep);
+            if (m) {
+              if (keep) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
+              qn += __popcll(m);
+              if (qn >= 64) process(64);
+            }
+          }
+        }
+        if (qn > 0) process(qn);
+      }
+      __syncthreads();
+      // ---- active cells, their shift range, and the compact emit -------------------------------------------------
+      for (int cell = wv; cell < ncell; cell += NWAVE) {
+        double v = (lane < NU8) ? s_A[cell * NU8 + lane] : 0.0;
+        unsigned long long nz = __ballot(v != 0.0);
+        if (lane == 0) {
+          s_culo[cell] = nz ? (unsigned char)(__ffsll((long long)nz) - 1) : (unsigned char)255;
+          s_cuhi[cell] = nz ? (unsigned char)(63 - __clzll((long long)nz)) : (unsigned char)0;
+        }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        int nact = 0, nblk_tot = 0;
+        for (int base = 0; base < ncell; base += 64) {
+          int cell = base + lane;
+          bool act = (cell < ncell) && (s_culo[cell] != 255);
+          unsigned long long am = __ballot(act);
+          int nb = act ? ((s_cuhi[cell] - (s_culo[cell] & ~7)) / 8 + 1) : 0;
+          // inclusive scan of block counts within the 64 lanes
+          int sc = nb;
+          for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(sc, off);
+            if (lane >= off) sc += o;
+          }
+          if (act) {
+            int pos = nact + __popcll(am & ((1ull << lane) - 1ull));
+            s_list[pos] = (unsigned short)cell;
+            s_boff[pos] = (unsigned short)(nblk_tot + sc - nb);
+          }
+          nact += __popcll(am);
+          nblk_tot += __shfl(sc, 63);
+        }
+        if (lane == 0) {
+          s_misc[6] = nact;
+          s_misc[7] = nblk_tot;
+          int have = s_misc[16];
+          unsigned long long need = (unsigned long long)nblk_tot * 8ull;
+          unsigned long long base = 0;
+          bool ok = (have + nact <= IMAX) && !s_misc[18];
+          if (ok && need) {
+            base = atomicAdd(S.cursor, need);
+            if (base + need > S.wbuf_cap) ok = false;
+          }
+          if (!ok) s_misc[18] = 1;
+          s_base64 = base;
+        }
+      }
+      __syncthreads();
+      {
+        const int nact = s_misc[6];
+        if (!s_misc[18] && nact > 0) {
+          const int have = s_misc[16];
+          const unsigned long long base = s_base64;
+          const unsigned short* boff = s_boff;
+          for (int li = wv; li < nact; li += NWAVE) {
+            const int cell = s_list[li];
+            const int ulo8 = s_culo[cell] & ~7;
+            const int nblk = (s_cuhi[cell] - ulo8) / 8 + 1;
+            const unsigned long long wo = base + (unsigned long long)boff[li] * 8ull;
+            if (lane == 0) {
+              Item itx;
+              itx.cell_nblk = (s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) | (nblk << 16);
+              itx.sbase = u_min + ulo8;
+              itx.woff_lo = (uint32_t)(wo & 0xFFFFFFFFull);
+              itx.woff_hi = (uint32_t)(wo >> 32);
+              items[have + li] = itx;
+            }
+            if (lane < nblk * 8) S.wbuf[wo + lane] = s_A[cell * NU8 + ulo8 + lane];
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0 && !s_misc[18]) s_misc[16] += s_misc[6];
+    }
+    // ---- window-edge corrections of this chunk -> (tick, value) list ------------------------------------------------
+    __syncthreads();
+    if (wv == 0) {
+      for (int e = 0; e < NEDGE; e++) {
+        double cv = (lane < NU) ? s_C[e][lane] : 0.0;
+        int num = edge_k[e] - (u_min + lane);
+        bool ok = (edge_k[e] >= 0) && (lane < NU) && cv != 0.0 && num >= 0 && (num % M) == 0;
+        unsigned long long om = __ballot(ok);
+        int have = s_misc[17];
+        int cnt = __popcll(om);
+        if (have + cnt > CMAX) {
+          if (lane == 0) s_misc[18] = 1;
+        } else if (ok) {
+          Corr cr;
+          cr.tick = num / M;
+          cr.pad = 0;
+          cr.val = cv;
+          corr[have + __popcll(om & ((1ull << lane) - 1ull))] = cr;
+        }
+        if (lane == 0 && have + cnt <= CMAX) s_misc[17] = have + cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+    iz_next += n_sl;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    hdr[0] = s_misc[18] ? 0 : s_misc[16];
+    hdr[1] = s_misc[18] ? 0 : s_misc[17];
+    hdr[2] = it0;
+    hdr[3] = T;
+    hdr[4] = it_w0;
+    hdr[5] = it_w1;
+    hdr[6] = s_misc[18] ? 0 : min(s_misc[19], RUNS_MAX);   // an overflowed pair exposes no runs to mac_kernel
+    hdr[7] = s_misc[18];            // 1 = capacity overflow: the monolithic kernel recomputes this pair
+    int r = min(s_misc[19], RUNS_MAX);
+    hdr[8 + r] = s_misc[16];
+    if (s_misc[18]) atomicAdd(&A.counters[6], 1ull);
+  }
+}
+
+// =============================================================================================================
+template <int M>
+__device__ __forceinline__ void mac_item(double (&acc)[TPL], const double* rowp, int roff, const double* wp, int nblk,
+                                         int lane) {
+  const int rl = M * TPL * lane + roff;
+  double w[M * (TPL - 1) + 8 + 1];
+#pragma unroll
+  for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rowp[rpos<M>(rl + q)];
+  for (int b8 = 0; b8 < nblk; b8++) {
+    const int u0 = b8 * 8;
+    double av[8];
+#pragma unroll
+    for (int du = 0; du < 8; du++) av[du] = wp[u0 + du];
+#pragma unroll
+    for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rowp[rpos<M>(rl + u0 + M * (TPL - 1) + 1 + q)];
+#pragma unroll
+    for (int du = 0; du < 8; du++) {
+#pragma unroll
+      for (int j = 0; j < TPL; j++) acc[j] = fma(av[du], w[M * j + du], acc[j]);
+    }
+#pragma unroll
+    for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
+  }
+}
+
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS) mac_kernel(SplitArgs S) {
+  const CurArgs& A = S.c;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * PB;
+  if (p0 >= A.n_pairs) return;
+  const int np = (int)min((int64_t)PB, A.n_pairs - p0);
+
+  constexpr int ROWLEN = M * WTILE + MAC_SPAN + 80;
+  constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
+  __shared__ double s_row[NWAVE][ROWBUF];
+  __shared__ unsigned short s_cells[PB][IMAX];
+  __shared__ int s_hdr[PB][HDR_INTS];
+  __shared__ double s_out[PB][WTILE];     // combine buffer of one tile (waves sharing a tile add in rank order)
+
+  for (int i = tid; i < np * HDR_INTS; i += CUR_THREADS) s_hdr[i / HDR_INTS][i % HDR_INTS] = S.hdr[(p0 + i / HDR_INTS) * HDR_INTS + i % HDR_INTS];
+  __syncthreads();
+  for (int i = tid; i < np * IMAX; i += CUR_THREADS) {
+    int p = i / IMAX, k = i % IMAX;
+    if (k < s_hdr[p][0]) s_cells[p][k] = (unsigned short)(S.items[(p0 + p) * IMAX + k].cell_nblk & 0xFFFF);
+  }
+  // block window = union of the pairs' response-visible windows
+  int w0 = 1 << 30, w1 = 0;
+  for (int p = 0; p < np; p++)
+    if (s_hdr[p][0] > 0) {
+      w0 = min(w0, s_hdr[p][4]);
+      w1 = max(w1, s_hdr[p][5]);
+    }
+  __syncthreads();
+  // every pair's output row is written by this kernel unless it is flagged for the monolithic kernel
+  if (w1 <= w0) {
+    for (int p = 0; p < np; p++)
+      if (!s_hdr[p][7])
+        for (int it = tid; it < A.T; it += CUR_THREADS) A.out[(p0 + p) * (int64_t)A.T + it] = 0.f;
+    return;
+  }
+  const int k_stage_lo = max(0, A.k_first);
+  int k_stage_hi;
+  {
+    const double V = A.c->time_window / A.c->response_sampling;
+    int kn = (int)ceil(V + 0.5 + 1e-6);
+    int ka = (int)floor(V - 0.5 - 1e-6);
+    if ((double)ka + 0.5 >= V - 1e-6) ka--;
+    int k_top = kn - 1;
+    if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;
+    k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
+  }
+  // head of every (pair, run): lane = pair*8 + run
+  const int hp = lane >> 3, hr = lane & 7;
+  unsigned long long n_blocks = 0;
+
+  for (int sup0 = w0; sup0 < w1; sup0 += TILE_TICKS) {
+    const int wlen = min(w1 - sup0, TILE_TICKS);
+    const int ntt = (wlen + WTILE - 1) / WTILE;
+    int my_tile, share_rank, nshare;
+    if (ntt >= 3) { my_tile = wv; share_rank = 0; nshare = 1; }
+    else if (ntt == 2) { my_tile = wv >> 1; share_rank = wv & 1; nshare = 2; }
+    else { my_tile = 0; share_rank = wv; nshare = 4; }
+    const bool tile_live = my_tile < ntt;
+    const int tb = sup0 + my_tile * WTILE;
+    double acc0[TPL], acc1[TPL], acc2[TPL], acc3[TPL], acc4[TPL], acc5[TPL], acc6[TPL], acc7[TPL];
+#pragma unroll
+    for (int j = 0; j < TPL; j++) acc0[j] = acc1[j] = acc2[j] = acc3[j] = acc4[j] = acc5[j] = acc6[j] = acc7[j] = 0;
+
+    if (tile_live) {
+      int idx = 0, end = 0;
+      if (hp < np && hr < s_hdr[hp][6]) {
+        idx = s_hdr[hp][8 + hr];
+        end = s_hdr[hp][8 + hr + 1];
+      }
+      double* rowp = s_row[wv];
+      int cellno = 0;
+      while (true) {
+        int mycell = (idx < end) ? (int)s_cells[hp][idx] : (1 << 30);
+        int cmin = mycell;
+        for (int off = 32; off > 0; off >>= 1) cmin = min(cmin, __shfl_xor(cmin, off));
+        if (cmin >= (1 << 30)) break;
+        const bool mine = (mycell == cmin);
+        unsigned long long am = __ballot(mine);
+        const bool do_cell = (cellno % nshare) == share_rank;
+        cellno++;
+        if (do_cell) {
+          // the items of the heads that sit on this cell
+          Item itx;
+          itx.cell_nblk = 0; itx.sbase = 0; itx.woff_lo = itx.woff_hi = 0;
+          if (mine) itx = S.items[(p0 + hp) * IMAX + idx];
+          const int nblk = (itx.cell_nblk >> 16) & 0xFF;
+          const double* rrow = A.resp + (int64_t)cmin * A.nk;
+          unsigned long long todo = am;
+          while (todo) {
+            // stage a row segment that covers every remaining item whose first shift is within MAC_SPAN of the smallest
+            int sb = (todo >> lane) & 1ull ? itx.sbase : (1 << 30);
+            int sbmin = sb;
+            for (int off = 32; off > 0; off >>= 1) sbmin = min(sbmin, __shfl_xor(sbmin, off));
+            bool take = ((todo >> lane) & 1ull) && (itx.sbase + nblk * 8 - sbmin <= MAC_SPAN + 64);
+            unsigned long long tm = __ballot(take);
+            int send = take ? itx.sbase + nblk * 8 : -(1 << 30);
+            for (int off = 32; off > 0; off >>= 1) send = max(send, __shfl_xor(send, off));
+            const int kb = M * tb + sbmin;
+            const int nrow = M * WTILE + (send - sbmin) + 8;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int r = lane; r < nrow; r += 64) {
+              int k = kb + r;
+              rowp[rpos<M>(r)] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            unsigned long long run = tm;
+            while (run) {
+              const int src = __ffsll((long long)run) - 1;
+              run &= run - 1;
+              const int p = src >> 3;
+              const int i_nblk = __shfl(nblk, src);
+              const int i_sb = __shfl(itx.sbase, src);
+              const unsigned long long wo = ((unsigned long long)__shfl((int)itx.woff_hi, src) << 32) |
+                                            (unsigned long long)(unsigned int)__shfl((int)itx.woff_lo, src);
+              const double* wp = S.wbuf + wo;
+              const int roff = i_sb - sbmin;
+              switch (p) {
+                case 0: mac_item<M>(acc0, rowp, roff, wp, i_nblk, lane); break;
+                case 1: mac_item<M>(acc1, rowp, roff, wp, i_nblk, lane); break;
+                case 2: mac_item<M>(acc2, rowp, roff, wp, i_nblk, lane); break;
+                case 3: mac_item<M>(acc3, rowp, roff, wp, i_nblk, lane); break;
+                case 4: mac_item<M>(acc4, rowp, roff, wp, i_nblk, lane); break;
+                case 5: mac_item<M>(acc5, rowp, roff, wp, i_nblk, lane); break;
+                case 6: mac_item<M>(acc6, rowp, roff, wp, i_nblk, lane); break;
+                default: mac_item<M>(acc7, rowp, roff, wp, i_nblk, lane); break;
+              }
+              n_blocks += i_nblk;
+            }
+            todo &= ~tm;
+          }
+        }
+        if (mine) idx++;
+      }
+    }
+    // ---- combine the waves that share a tile, apply edge corrections, mask, f32 store -------------------------------
+    for (int t = 0; t < ntt; t++) {
+      for (int rnk = 0; rnk < nshare; rnk++) {
+        __syncthreads();
+        if (tile_live && my_tile == t && share_rank == rnk) {
+#pragma unroll
+          for (int j = 0; j < TPL; j++) {
+            const int i = TPL * lane + j;
+            const double v[PB] = {acc0[j], acc1[j], acc2[j], acc3[j], acc4[j], acc5[j], acc6[j], acc7[j]};
+#pragma unroll
+            for (int p = 0; p < PB; p++) s_out[p][i] = (rnk == 0) ? v[p] : s_out[p][i] + v[p];
+          }
+        }
+      }
+      __syncthreads();
+      const int tbase = sup0 + t * WTILE;
+      if (tid < np) {          // one thread per pair walks its (short) correction list
+        const int p = tid;
+        const Corr* cr = S.corr + (p0 + p) * CMAX;
+        for (int k = 0; k < s_hdr[p][1]; k++) {
+          int i = cr[k].tick - tbase;
+          if (i >= 0 && i < WTILE) s_out[p][i] -= cr[k].val;
+        }
+      }
+      __syncthreads();
+      for (int p = 0; p < np; p++) {
+        if (s_hdr[p][7]) continue;
+        const int it0 = s_hdr[p][2], Tp = s_hdr[p][3], pw0 = s_hdr[p][4], pw1 = s_hdr[p][5];
+        const bool has = s_hdr[p][0] > 0;
+        float* out = A.out + (p0 + p) * (int64_t)A.T;
+        for (int i = tid; i < WTILE; i += CUR_THREADS) {
+          int it = tbase + i;
+          if (it < A.T && it < sup0 + wlen)
+            out[it] = (has && it >= it0 && it < Tp && it >= pw0 && it < pw1) ? (float)s_out[p][i] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ticks outside the block window
+  for (int p = 0; p < np; p++) {
+    if (s_hdr[p][7]) continue;
+    float* out = A.out + (p0 + p) * (int64_t)A.T;
+    for (int it = tid; it < A.T; it += CUR_THREADS)
+      if (it < w0 || it >= w1) out[it] = 0.f;
+  }
+  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+}
+
+// =============================================================================================================
+extern "C++" int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
+                              unsigned long long wbuf_cap, unsigned long long* cursor) {
+  if (args.n_pairs == 0) return 0;
+  const LdsimConsts& h = ctx->h_consts;
+  double ratio = h.time_sampling / h.response_sampling;
+  int M = (int)llround(ratio);
+  if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX ||
+      args.ni * args.nj > 65535 || args.n_pairs > 0x7fffffffLL)
+    return 1;   // not supported by the split path: caller uses the monolithic kernel
+  SplitArgs S;
+  S.c = args;
+  S.items = (Item*)items;
+  S.hdr = (int32_t*)hdr;
+  S.corr = (Corr*)corr;
+  S.wbuf = wbuf;
+  S.wbuf_cap = wbuf_cap;
+  S.cursor = cursor;
+  dim3 block(CUR_THREADS);
+  dim3 gw((unsigned)args.n_pairs), gm((unsigned)((args.n_pairs + PB - 1) / PB));
+  if (M == 1) {
+    hipLaunchKernelGGL(weights_kernel<1>, gw, block, 0, ctx->stream, S);
+    hipLaunchKernelGGL(mac_kernel<1>, gm, block, 0, ctx->stream, S);
+  } else {
+    hipLaunchKernelGGL(weights_kernel<2>, gw, block, 0, ctx->stream, S);
+    hipLaunchKernelGGL(mac_kernel<2>, gm, block, 0, ctx->stream, S);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C++" void split_sizes(size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes) {
+  *item_bytes = sizeof(Item) * IMAX;
+  *hdr_bytes = sizeof(int32_t) * HDR_INTS;
+  *corr_bytes = sizeof(Corr) * CMAX;
+}

@@ -20,7 +20,9 @@ struct CurArgs {
   int32_t batch0;
   double prune_log;
   int32_t debug_phases;
-  unsigned long long* counters;  // [0] ambiguous-rounding slices, [1] degenerate pairs
+  unsigned long long* counters;  // [0] ambiguous-rounding slices, [5] DFMA lanes, [6] pairs sent to the fallback
+  const int32_t* only_flagged;   // if set: run only pairs whose only_flagged[pair*flag_stride + 7] != 0
+  int32_t flag_stride;
 };
 
 struct FeeArgs {
@@ -53,3 +55,6 @@ struct FeeArgs {
 
 int current_launch(ldsim_ctx* ctx, const CurArgs& args);
 int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F);
+int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
+                 unsigned long long wbuf_cap, unsigned long long* cursor);
+void split_sizes(size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes);

@@ -98,13 +98,16 @@ struct ldsim_ctx {
   // options
   double prune_log = 30.0;
   int trim_response = 1;
-  int debug_phases = 15;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
+  int debug_phases = 15;
+  int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
+  int wbuf_doubles_per_pair = 6144; // capacity of the weight arena per pair (overflow -> monolithic fallback)
+  int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments
   SegStore seg{};
   DevBuf seg_block;
   DevBuf raw;          // AoS staging (H2D/D2H)
   LdsimTrackLayout seg_layout{};
-  DevBuf scratch[24];  // named scratch buffers, grown on demand
+  DevBuf scratch[32];  // named scratch buffers, grown on demand
   // chain results
   LdsimChainStats stats{};
   int64_t chain_U = 0, chain_hits = 0;
@@ -117,7 +120,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF
 };
 
 void ldsim_set_error(const char* fmt, ...);

@@ -365,3 +365,41 @@ def test_chain_properties_full_event():
     for k in second:
         assert np.array_equal(second[k], again[k]), k
     assert st.n_overflow == 0 and st.n_batches == 2
+
+
+@pytest.mark.parametrize("cfg,kind", [("module0", "dense"), ("ndlar", "golden")])
+def test_split_kernels_equal_monolithic(cfg, kind):
+    """weights_kernel + mac_kernel (default) vs the monolithic current_kernel on 2 x 600 segments: same hits,
+    charges equal to rounding (summation order differs), incl. a tiny arena that forces the overflow fallback."""
+    H.load_cfg(cfg)
+    seg = synth.make_segments(1200, seed=33, segs_per_event=600, spill=bool(consts.sim.IS_SPILL_SIM))
+    if consts.sim.IS_SPILL_SIM:
+        loc = seg["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
+        for f in ("t0", "t0_start", "t0_end"):
+            seg[f] = seg[f] - loc * consts.sim.SPILL_PERIOD
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    ch = ChargeChain(H.response_for(kind))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    res = {}
+    try:
+        for name, split, cap in (("mono", 0, 6144), ("split", 1, 6144), ("tiny", 1, 700)):
+            lib.set_option("split_kernels", split)
+            lib.set_option("wbuf_doubles_per_pair", cap)
+            st = ch.run(0, len(seg), want_fractions=True)
+            res[name] = ch.download()
+    finally:
+        lib.set_option("split_kernels", 1)
+        lib.set_option("wbuf_doubles_per_pair", 6144)
+    a = res["mono"]
+    assert (a["adc_list"] != 0).sum() > 100
+    for name in ("split", "tiny"):
+        b = res[name]
+        assert np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"])
+        assert np.array_equal(a["adc_list"] != 0, b["adc_list"] != 0)
+        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=1e-9)
+        assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
+        assert np.array_equal(a["adc_digit"], b["adc_digit"])
+        np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
