@@ -401,20 +401,34 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
         const int nact = s_misc[6];
         if (tile_live && (A.debug_phases & 2)) {
           double* rowp = s_row[wv];
-          for (int li = share_rank; li < nact; li += nshare) {
+          // software pipeline: the NEXT cell's row segment is fetched into registers while the current cell is
+          // correlated out of LDS (one wave-private row buffer; LDS ops of a wave execute in order)
+          constexpr int NLOAD = (M * WTILE + NU_MAX + 8 + 63) / 64;
+          double pre[NLOAD];
+          auto fetch = [&](int li) {
             const int cell = s_list[li];
             const int ulo8 = s_culo[cell] & ~7;
             const int nblk = (s_cuhi[cell] - ulo8) / 8 + 1;
             const double* rrow = A.resp + ((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk;
-            // row element r  <->  response index k = kb + r
-            const int kb = M * tb + u_min + ulo8;
+            const int kb = M * tb + u_min + ulo8;         // row element r  <->  response index k = kb + r
             const int nrow = M * WTILE + nblk * 8 + 8;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (int r = lane; r < nrow; r += 64) {
-              int k = kb + r;
-              rowp[rpos<M>(r)] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
+#pragma unroll
+            for (int n = 0; n < NLOAD; n++) {
+              const int r = lane + 64 * n, k = kb + r;
+              pre[n] = (r < nrow && k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
             }
+          };
+          if (share_rank < nact) fetch(share_rank);
+          for (int li = share_rank; li < nact; li += nshare) {
+            const int cell = s_list[li];
+            const int ulo8 = s_culo[cell] & ~7;
+            const int nblk = (s_cuhi[cell] - ulo8) / 8 + 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int n = 0; n < NLOAD; n++)
+              if (lane + 64 * n < ROWLEN) rowp[rpos<M>(lane + 64 * n)] = pre[n];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (li + nshare < nact) fetch(li + nshare);
             const double* Aj = &s_A[cell * NU8 + ulo8];
             const int rl = M * TPL * lane;
             double w[M * (TPL - 1) + 8 + 1];

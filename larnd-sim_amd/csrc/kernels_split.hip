@@ -13,13 +13,13 @@
 // current_kernel (kernels_current.hip), which has no such limits.
 #include "current_common.h"
 
-#define PB 8            // pairs per mac workgroup
+#define PB 4            // pairs per mac workgroup
 #define IMAX 512        // items per pair
 #define CMAX 192        // edge corrections per pair
 #define RUNS_MAX 8      // sorted runs (slice chunks) per pair
 #define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
-#define W_ARENA 5120
-#define W_CELLS 640
+#define W_ARENA 4608
+#define W_CELLS 576
 #define MAC_SPAN 256    // max spread of first shifts staged together
 
 struct Item {
@@ -515,23 +515,22 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
 
 // =============================================================================================================
 template <int M>
-__device__ __forceinline__ void mac_item(double (&acc)[TPL], const double* rowp, int roff, const double* wp, int nblk,
+__device__ __forceinline__ void mac_item(double (&acc)[TPL], const double* rowp, int roff, double wreg, int nblk,
                                          int lane) {
+  // wreg: lane u holds weight[u] of this item (one coalesced 8 B/lane load); broadcast per shift with readlane
   const int rl = M * TPL * lane + roff;
   double w[M * (TPL - 1) + 8 + 1];
 #pragma unroll
   for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rowp[rpos<M>(rl + q)];
   for (int b8 = 0; b8 < nblk; b8++) {
     const int u0 = b8 * 8;
-    double av[8];
-#pragma unroll
-    for (int du = 0; du < 8; du++) av[du] = wp[u0 + du];
 #pragma unroll
     for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rowp[rpos<M>(rl + u0 + M * (TPL - 1) + 1 + q)];
 #pragma unroll
     for (int du = 0; du < 8; du++) {
+      const double av = __shfl(wreg, u0 + du);
 #pragma unroll
-      for (int j = 0; j < TPL; j++) acc[j] = fma(av[du], w[M * j + du], acc[j]);
+      for (int j = 0; j < TPL; j++) acc[j] = fma(av, w[M * j + du], acc[j]);
     }
 #pragma unroll
     for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
@@ -539,7 +538,7 @@ __device__ __forceinline__ void mac_item(double (&acc)[TPL], const double* rowp,
 }
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS) mac_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 2) mac_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * PB;
@@ -598,9 +597,9 @@ __global__ void __launch_bounds__(CUR_THREADS) mac_kernel(SplitArgs S) {
     else { my_tile = 0; share_rank = wv; nshare = 4; }
     const bool tile_live = my_tile < ntt;
     const int tb = sup0 + my_tile * WTILE;
-    double acc0[TPL], acc1[TPL], acc2[TPL], acc3[TPL], acc4[TPL], acc5[TPL], acc6[TPL], acc7[TPL];
+    double acc0[TPL], acc1[TPL], acc2[TPL], acc3[TPL];
 #pragma unroll
-    for (int j = 0; j < TPL; j++) acc0[j] = acc1[j] = acc2[j] = acc3[j] = acc4[j] = acc5[j] = acc6[j] = acc7[j] = 0;
+    for (int j = 0; j < TPL; j++) acc0[j] = acc1[j] = acc2[j] = acc3[j] = 0;
 
     if (tile_live) {
       int idx = 0, end = 0;
@@ -653,17 +652,13 @@ __global__ void __launch_bounds__(CUR_THREADS) mac_kernel(SplitArgs S) {
               const int i_sb = __shfl(itx.sbase, src);
               const unsigned long long wo = ((unsigned long long)__shfl((int)itx.woff_hi, src) << 32) |
                                             (unsigned long long)(unsigned int)__shfl((int)itx.woff_lo, src);
-              const double* wp = S.wbuf + wo;
+              const double wreg = (lane < i_nblk * 8) ? S.wbuf[wo + lane] : 0.0;
               const int roff = i_sb - sbmin;
               switch (p) {
-                case 0: mac_item<M>(acc0, rowp, roff, wp, i_nblk, lane); break;
-                case 1: mac_item<M>(acc1, rowp, roff, wp, i_nblk, lane); break;
-                case 2: mac_item<M>(acc2, rowp, roff, wp, i_nblk, lane); break;
-                case 3: mac_item<M>(acc3, rowp, roff, wp, i_nblk, lane); break;
-                case 4: mac_item<M>(acc4, rowp, roff, wp, i_nblk, lane); break;
-                case 5: mac_item<M>(acc5, rowp, roff, wp, i_nblk, lane); break;
-                case 6: mac_item<M>(acc6, rowp, roff, wp, i_nblk, lane); break;
-                default: mac_item<M>(acc7, rowp, roff, wp, i_nblk, lane); break;
+                case 0: mac_item<M>(acc0, rowp, roff, wreg, i_nblk, lane); break;
+                case 1: mac_item<M>(acc1, rowp, roff, wreg, i_nblk, lane); break;
+                case 2: mac_item<M>(acc2, rowp, roff, wreg, i_nblk, lane); break;
+                default: mac_item<M>(acc3, rowp, roff, wreg, i_nblk, lane); break;
               }
               n_blocks += i_nblk;
             }
@@ -681,7 +676,7 @@ __global__ void __launch_bounds__(CUR_THREADS) mac_kernel(SplitArgs S) {
 #pragma unroll
           for (int j = 0; j < TPL; j++) {
             const int i = TPL * lane + j;
-            const double v[PB] = {acc0[j], acc1[j], acc2[j], acc3[j], acc4[j], acc5[j], acc6[j], acc7[j]};
+            const double v[PB] = {acc0[j], acc1[j], acc2[j], acc3[j]};
 #pragma unroll
             for (int p = 0; p < PB; p++) s_out[p][i] = (rnk == 0) ? v[p] : s_out[p][i] + v[p];
           }

@@ -11,13 +11,13 @@ bid, order, table = batching.assign_batches(seg); seg, bid = seg[order], bid[ord
 for kind in (sys.argv[2:] or ["survey", "dense"]):
     ch = ChargeChain(synth.make_response(kind))
     ch.upload(seg, bid)
-    for phases in (3, 1, 2, 0):
+    for phases in (15, 13, 14, 12):
         lib.set_option("debug_phases", phases)
-        for prune in ((30.0,) if phases != 3 else (30.0, 20.0, 0.0)):
+        for prune in ((30.0,) if phases != 15 else (30.0, 20.0, 0.0)):
             lib.set_option("prune_log", prune)
             ch.reset(); ch.quench_drift(); st = ch.run(0, n)
             ch.reset(); ch.quench_drift(); st = ch.run(0, n)
             ms = ch.kernel_ms()
             print(f"{kind:7s} phases={phases} prune={prune:4.0f} current {ms['current_ms']:8.2f} ms adc {ms['adc_ms']:6.2f} total {ms['total_ms']:8.2f} "
                   f"dfma/seg {st.n_dfma/n:.3g} TF {2*st.n_dfma/ms['current_ms']/1e9:.2f} pairs/seg {st.n_pairs/n:.2f}", flush=True)
-    lib.set_option("debug_phases", 3); lib.set_option("prune_log", 30.0)
+    lib.set_option("debug_phases", 15); lib.set_option("prune_log", 30.0)
