@@ -16,7 +16,7 @@
 #include "current_common.h"
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
+__global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t pair = blockIdx.x;
@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
     return;
   }
   unsigned long long n_blocks = 0;   // 8-shift MAC blocks executed by this lane's wave (each = 64 DFMA per lane)
+  unsigned long long n_surv = 0;     // samples that reached the transcendental pass (this wave)
 
   for (int sup0 = it_w0; sup0 < it_w1; sup0 += TILE_TICKS) {
     const int wlen = min(it_w1 - sup0, TILE_TICKS);
@@ -289,6 +290,8 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
       }
       __syncthreads();
       const int n_sl = s_misc[3], u_min = s_misc[4];
+      const double cz_ = iL2 * uz;
+      const double ddz0 = (g.z_start_int + iz_next * g.z_step) - g.sz;   // ddz of the chunk's first slice
       const int NU = s_misc[5] - u_min + 1;
       const int NU8 = (NU + 7) & ~7;
       for (int i = tid; i < NEDGE * NU_MAX; i += CUR_THREADS) (&s_C[0][0])[i] = 0;
@@ -323,7 +326,8 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
               double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
               double E = b * b * inv4a - delta;
               double lo = b * inv_sa2, hi = lo + hi_off;
-              double w = (A.debug_phases & 4) ? pref * exp_erf_diff(E, lo, hi) : 1e-300 * E;
+              double integral = erf(hi) - erf(lo);          // detsim.py:150-152 (literal form)
+              double w = (A.debug_phases & 4) ? pref * integral * exp(E) : 1e-300 * E;
               if (w != 0 && (A.debug_phases & 8)) {
                 const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
                 const int u = s_shift[sl] - u_min;
@@ -341,22 +345,56 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
             }
             qhead = (qhead + n) & (QLEN - 1);
             qn -= n;
+            n_surv += n;
           };
-          const int npz = NS * n_sl;
-          const int npz_pad = (npz + 63) & ~63;
-          for (int p0 = wv * 64; p0 < npz_pad; p0 += CUR_THREADS) {
-            const int p = p0 + lane;
-            bool pv = p < npz;
-            const int iy = pv ? p / n_sl : 0, sl = pv ? p - iy * n_sl : 0;
-            pv = pv && (s_jcell[iy] >= 0);
-            const double byz = s_py[iy][0] + s_pz[sl][0], dyz = s_py[iy][1] + s_pz[sl][1];
-            const unsigned int tag = ((unsigned)iy << 6) | (unsigned)sl;
-            for (int gi = 0; gi < g_nix; gi++) {
-              const int ix = s_ixord[g_ix0 + gi];
-              bool keep = pv;
+          // Pass A.  For a fixed (ix, iy) the exponent E is a concave quadratic in z, so the slices with E >= cut
+          // form one interval: solve it once per (ix, iy) and enqueue only that interval (minus the samples the
+          // erf bound removes beyond the segment ends).
+          const double qa2 = cz_ * cz_ * inv4a - i2L;                 // <= 0
+          const int nxy = g_nix * NS;
+          const int nxy_pad = (nxy + 63) & ~63;
+          for (int q0 = wv * 64; q0 < nxy_pad; q0 += CUR_THREADS) {
+            const int qq = q0 + lane;
+            int s_lo = 0, s_hi = -1;
+            int ix = 0, iy = 0;
+            double Bxy = 0, Dxy = 0;
+            if (qq < nxy) {
+              const int gi = qq / NS;
+              iy = qq - gi * NS;
+              ix = s_ixord[g_ix0 + gi];
+              if (s_jcell[iy] >= 0) {
+                Bxy = s_px[ix][0] + s_py[iy][0];
+                Dxy = s_px[ix][1] + s_py[iy][1];
+                s_lo = 0;
+                s_hi = n_sl - 1;
+                if (do_prune && qa2 < -1e-300 && g.z_step > 0) {
+                  // E(ddz) = qa2 ddz^2 + qa1 ddz + qa0 >= cut
+                  const double qa1 = 2 * Bxy * cz_ * inv4a, qa0 = Bxy * Bxy * inv4a - Dxy - cut;
+                  const double disc = qa1 * qa1 - 4 * qa2 * qa0;
+                  if (disc < 0) {
+                    s_hi = -1;
+                  } else {
+                    const double sq = sqrt(disc);
+                    const double r1 = (-qa1 + sq) / (2 * qa2), r2 = (-qa1 - sq) / (2 * qa2);   // r1 <= r2 (qa2 < 0)
+                    // slice sl has ddz = ddz0 + sl*z_step
+                    const double f_lo = floor((r1 - ddz0) / g.z_step) - 1, f_hi = ceil((r2 - ddz0) / g.z_step) + 1;
+                    if (f_lo > s_lo) s_lo = (int)fmin(f_lo, (double)n_sl);
+                    if (f_hi < s_hi) s_hi = (int)fmax(f_hi, -1.0);
+                  }
+                }
+              }
+            }
+            int len = s_hi - s_lo + 1;
+            if (len < 0) len = 0;
+            int maxlen = len;
+            for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+            const unsigned int tagxy = ((unsigned)ix << 12) | ((unsigned)iy << 6);
+            for (int t = 0; t < maxlen; t++) {
+              bool keep = t < len;
+              const int sl = s_lo + t;
               if (do_prune && keep) {
-                double b = -(s_px[ix][0] + byz);
-                double E2 = b * b * inv4a - (s_px[ix][1] + dyz);
+                double b = -(Bxy + s_pz[sl][0]);
+                double E2 = b * b * inv4a - (Dxy + s_pz[sl][1]);
                 double lo = b * inv_sa2, hi = lo + hi_off;
                 if (lo > 0) E2 -= lo * lo;
                 else if (hi < 0) E2 -= hi * hi;
@@ -364,7 +402,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
               }
               unsigned long long m = __ballot(keep);
               if (m) {
-                if (keep) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
+                if (keep) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = tagxy | (unsigned)sl;
                 qn += __popcll(m);
                 if (qn >= 64) process(64);
               }
@@ -490,6 +528,7 @@ __global__ void __launch_bounds__(CUR_THREADS) current_kernel(CurArgs A) {
   for (int it = tid; it < A.T; it += CUR_THREADS)
     if (it < it_w0 || it >= it_w1) out[it] = 0.f;
   if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+  if (lane == 0 && n_surv) atomicAdd(&A.counters[1], n_surv);
 }
 
 extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {

@@ -12,4 +12,4 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "survey"
 ch = ChargeChain(synth.make_response(kind)); ch.upload(seg, bid)
 for _ in range(2):
     ch.reset(); ch.quench_drift(); st = ch.run(0, n)
-print(kind, ch.kernel_ms(), "fallback pairs", st.n_fallback, "of", st.n_pairs, "dfma/seg", st.n_dfma / n)
+print(kind, ch.kernel_ms(), "fallback pairs", st.n_fallback, "of", st.n_pairs, "dfma/seg", st.n_dfma / n, "samples/pair", st.n_samples / max(st.n_pairs,1))
