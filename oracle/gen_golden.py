@@ -37,6 +37,7 @@ REF = "/root/reference"
 GOLD = os.path.join(REPO, "tests", "golden")
 SNAP = os.path.join(REPO, "larnd-sim_amd", "larndsim_amd", "snapshots")
 sys.path.insert(0, os.path.join(REPO, "larnd-sim_amd"))
+sys.path.insert(0, REPO)
 
 CONFIGS = {
     "module0": ("detector_properties/module0.yaml", "pixel_layouts/multi_tile_layout-2.3.16.yaml",
@@ -377,11 +378,25 @@ def gen_chain(jobs):
         pix = _pixel_stage(ref, r)
         neigh, nrad, T = pix["neigh"], pix["nrad"], pix["max_length"]
         n = r.shape[0]
+        # tracks_current over ALL ticks costs ~20 min per (segment, pixel) in pure Python (64000 rho calls per tick),
+        # so the full-tick `signals` of this set come from the oracle (oracle/ldsim_oracle.c), which the `sampled_*`
+        # sets pin to the reference's tracks_current; every stage downstream runs the reference's own source.
+        try:
+            from oracle import oracle as ORC
+        except ImportError:      # run as a script: the script directory shadows the package name
+            import oracle as ORC
+        from larndsim_amd import consts as my_consts
+        my_consts.load_snapshot({"module0": "module0"}[cfg])
+        for kk in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOISE"):
+            setattr(my_consts.detector, kk, 0)
+        signals = ORC.tracks_current(r, neigh, T, synth.make_response("golden"))
+        # spot-check against the reference itself on a few ticks of every segment
+        peak_tick = int(np.argmax(np.abs(signals).sum(axis=(0, 1))))
+        spot = sorted({3, peak_tick - 7, peak_tick, peak_tick + 5, T - 2})
         with Pool(jobs) as pool:
-            res = pool.map(_current_job, [(cfg, r, neigh, T, i, None, "golden") for i in range(n)])
-        signals = np.zeros((n, neigh.shape[1], T), dtype=np.float32)
-        for itrk, s in res:
-            signals[itrk] = s
+            res = pool.map(_current_job, [(cfg, r, neigh, T, i, spot, "golden") for i in range(n)])
+        for itrk, sref in res:
+            np.testing.assert_allclose(signals[itrk][:, spot], sref[:, spot], rtol=3e-7, atol=0)
         unique_pix = np.unique(neigh.ravel())
         unique_pix = unique_pix[unique_pix != -1]
         pixel_index_map = np.full(neigh.shape, -1, dtype=np.int64)
@@ -405,7 +420,7 @@ def gen_chain(jobs):
         A = ref.sim.MAX_ADC_VALUES
         out = dict(segments_in=seg, signals=signals, unique_pix=unique_pix, pixel_index_map=pixel_index_map,
                    track_pixel_map=track_pixel_map, pixels_signals=pixels_signals, overflow=overflow,
-                   response_kind="golden", **pix)
+                   response_kind="golden", signals_source="oracle (spot-checked against the reference at 5 ticks per segment)", **pix)
         for thr_name, thr in (("default", det.DISCRIMINATION_THRESHOLD * ref.consts.units.e), ("low", 600.0)):
             time_ticks = np.linspace(0, 1 * det.TIME_INTERVAL[1], NT + 1)
             integral = np.zeros((U, A)); ticks = np.zeros((U, A)); frac = np.zeros((U, A, M))
@@ -499,13 +514,13 @@ def gen_light():
         inc['n_photons_det'] = inc8['n_photons_det']; inc['t0_det'] = inc8['t0_det']
         inc8['n_photons_det'] = inc['n_photons_det']; inc8['t0_det'] = inc['t0_det']     # narrowed values
         n_ticks, t_start = ref.light_sim.get_nticks(inc)
-        n_ticks = min(n_ticks, 3000)
+        n_ticks = min(n_ticks, 1200)
         op_channel = light.TPC_TO_OP_CHANNEL[:].ravel()
         n_det = op_channel.shape[0]
         sorted_indices = np.zeros((n_det, n), dtype=np.int32)
         for idet in range(n_det):
             sorted_indices[idet] = np.argsort(inc[:, idet]['n_photons_det'])[::-1]
-        out_inc = np.zeros((n_det, n_ticks))           # f64 accumulate; narrowed to f4 by the test
+        out_inc = np.zeros((n_det, n_ticks), dtype='f4')   # like the reference driver: f64 add, f4 store per update
         M = 4
         true_id = np.full((n_det, n_ticks, M), -1, dtype='i8')
         true_ph = np.zeros((n_det, n_ticks, M))
@@ -514,8 +529,8 @@ def gen_light():
             sorted_indices, n_prof)
         np.savez_compressed(os.path.join(GOLD, f"light_{cfg}.npz"), segments_in=seg, lut_seed=seed, n_prof=n_prof,
                             n_photons_det=inc['n_photons_det'], t0_det=inc['t0_det'], voxel=voxel,
-                            n_ticks=n_ticks, t_start=t_start, light_sample_inc=out_inc, true_id=true_id,
-                            true_photons=true_ph, sorted_indices=sorted_indices, op_channel=op_channel)
+                            n_ticks=n_ticks, t_start=t_start, light_sample_inc=out_inc, true_id=true_id.astype(np.int32),
+                            true_photons=true_ph.astype(np.float32), sorted_indices=sorted_indices, op_channel=op_channel)
         print("light", cfg, "n_op", n_op, "ticks", n_ticks, "smearing", light.ENABLE_LUT_SMEARING,
               "sum", float(out_inc.sum()))
 

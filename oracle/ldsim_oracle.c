@@ -28,6 +28,15 @@ typedef struct {
   int32_t pad_;
 } OTrack;
 
+/* Numba types f32 (op) f32 as f32.  With the 152-byte HDF5 schema (f4 coordinates and sigmas) this makes a few
+ * sub-expressions of tracks_current single precision (detsim.py:387, :74-79, :116-118, :141).  g_numba_f32 = 1
+ * restates exactly those spots in float; 0 = all-f64 (what the reference computes for f8 records). */
+static int g_numba_f32 = 0;
+void o_set_numba_f32(int on) { g_numba_f32 = on; }
+#define F32SUB(a, b) (g_numba_f32 ? (double)((float)(a) - (float)(b)) : ((a) - (b)))
+#define F32MUL(a, b) (g_numba_f32 ? (double)((float)(a) * (float)(b)) : ((a) * (b)))
+#define F32DIV(a, b) (g_numba_f32 ? (double)((float)(a) / (float)(b)) : ((a) / (b)))
+
 /* ---- Python / Numba scalar semantics -------------------------------------------------------- */
 static double py_round(double x) { return nearbyint(x); } /* round-half-even, FE_TONEAREST */
 
@@ -258,11 +267,11 @@ static void z_interval(const double sp[3], const double ep[3], double x_p, doubl
   else if (sp[0] < ep[0]) { start = sp; end = ep; }
   else return;
   double xs = start[0], ys = start[1], xe = end[0], ye = end[1];
-  double m = (ye - ys) / (xe - xs);
-  double q = (xe * ys - xs * ye) / (xe - xs);
+  double m = F32DIV(F32SUB(ye, ys), F32SUB(xe, xs));
+  double q = F32DIV(F32SUB(F32MUL(xe, ys), F32MUL(xs, ye)), F32SUB(xe, xs));
   double a = m, b = -1, cc = q;
-  double x_poca = (b * (b * x_p - a * y_p) - a * cc) / (a * a + b * b);
-  double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
+  double x_poca = (b * (b * x_p - a * y_p) - F32MUL(a, cc)) / (F32MUL(a, a) + b * b);
+  double dx = F32SUB(end[0], start[0]), dy = F32SUB(end[1], start[1]), dz = F32SUB(end[2], start[2]);
   double length = sqrt(dx * dx + dy * dy + dz * dz);
   double dir3[3] = {dx / length, dy / length, dz / length};
   double doca;
@@ -273,12 +282,13 @@ static void z_interval(const double sp[3], const double ep[3], double x_p, doubl
     doca = sqrt((x_p - end[0]) * (x_p - end[0]) + (y_p - end[1]) * (y_p - end[1]));
     x_poca = end[0];
   } else {
-    doca = fabs(a * x_p + b * y_p + cc) / sqrt(a * a + b * b);
+    doca = fabs(a * x_p + b * y_p + cc) / sqrt(F32MUL(a, a) + b * b);
   }
   double zp = start[2] + (x_poca - start[0]) / dir3[0] * dir3[2];
   if (tol > doca) {
-    double length2D = sqrt((xe - xs) * (xe - xs) + (ye - ys) * (ye - ys));
-    double dir2x = (end[0] - start[0]) / length2D;
+    double dxs = F32SUB(xe, xs), dys = F32SUB(ye, ys);
+    double length2D = sqrt(dxs * dxs + dys * dys);
+    double dir2x = F32SUB(end[0], start[0]) / length2D;
     double deltaL2D = sqrt(tol * tol - doca * doca);
     double x_plus = x_poca + deltaL2D * dir2x;
     double x_minus = x_poca - deltaL2D * dir2x;
@@ -299,10 +309,10 @@ static double rho(double x, double y, double z, double q, const double start[3],
   double Dr = sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
   double a = ((Dx / Dr) * (Dx / Dr) / (2 * sg[0] * sg[0]) + (Dy / Dr) * (Dy / Dr) / (2 * sg[1] * sg[1]) +
               (Dz / Dr) * (Dz / Dr) / (2 * sg[2] * sg[2]));
-  double factor = q / Dr / (sg[0] * sg[1] * sg[2] * sqrt(8 * M_PI * M_PI * M_PI));
+  double factor = q / Dr / (F32MUL(F32MUL(sg[0], sg[1]), sg[2]) * sqrt(8 * M_PI * M_PI * M_PI));
   double sqrt_a_2 = 2 * sqrt(a);
-  double b = -((x - start[0]) / (sg[0] * sg[0]) * (seg[0] / Dr) + (y - start[1]) / (sg[1] * sg[1]) * (seg[1] / Dr) +
-               (z - start[2]) / (sg[2] * sg[2]) * (seg[2] / Dr));
+  double b = -((x - start[0]) / F32MUL(sg[0], sg[0]) * (seg[0] / Dr) + (y - start[1]) / F32MUL(sg[1], sg[1]) * (seg[1] / Dr) +
+               (z - start[2]) / F32MUL(sg[2], sg[2]) * (seg[2] / Dr));
   double delta = (x - start[0]) * (x - start[0]) / (2 * sg[0] * sg[0]) +
                  (y - start[1]) * (y - start[1]) / (2 * sg[1] * sg[1]) +
                  (z - start[2]) * (z - start[2]) / (2 * sg[2] * sg[2]);
@@ -349,7 +359,7 @@ int o_tracks_current(float* signals, const int32_t* pixels, const OTrack* tr, in
         end[0] = t->x_start; end[1] = t->y_start; end[2] = t->z_start;
         start[0] = t->x_end; start[1] = t->y_end; start[2] = t->z_end;
       }
-      double seg[3] = {end[0] - start[0], end[1] - start[1], end[2] - start[2]};
+      double seg[3] = {F32SUB(end[0], start[0]), F32SUB(end[1], start[1]), F32SUB(end[2], start[2])};
       double length = sqrt(seg[0] * seg[0] + seg[1] * seg[1] + seg[2] * seg[2]);
       double dir[3] = {seg[0] / length, seg[1] / length, seg[2] / length};
       double sg[3] = {t->tran_diff, t->tran_diff, t->long_diff};

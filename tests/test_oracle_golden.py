@@ -68,3 +68,84 @@ def test_tracks_current_sampled(cfg):
     np.testing.assert_allclose(got, ref, rtol=3e-7, atol=0)
     nz = ref != 0
     assert np.array_equal(got != 0, nz)
+
+
+def test_chain_downstream_stages():
+    """a13-a16 of the oracle vs the reference's own get_track_pixel_map2 / sum_pixel_signals / get_adc_values /
+    digitize run on the golden chain (whose full-tick `signals` are oracle-made, spot-checked against the reference)."""
+    H.load_cfg("module0")
+    g = H.gold("chain_module0.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    neigh, nrad = g["neigh"], g["nrad"]
+    T = int(g["max_length"])
+    sig = O.tracks_current(r, neigh, T, H.response_for(g["response_kind"]))
+    assert np.array_equal(sig, g["signals"])
+    upix = O.unique_pixels(neigh)
+    assert np.array_equal(upix, g["unique_pix"])
+    pim = O.pixel_index_map(neigh, upix)
+    assert np.array_equal(pim, g["pixel_index_map"])
+    M = consts.sim.MAX_TRACKS_PER_PIXEL
+    tpm = O.track_pixel_map(upix, neigh, nrad, int(nrad.max()) + 1, M)
+    assert np.array_equal(tpm, g["track_pixel_map"])
+    ps, pts, ovf = O.sum_pixel_signals(g["signals"], g["track_starts"], pim, tpm, len(upix))
+    np.testing.assert_allclose(ps, g["pixels_signals"], rtol=1e-13, atol=1e-13 * np.abs(g["pixels_signals"]).max())
+    assert np.array_equal(ovf, g["overflow"])
+    tt = np.linspace(0, consts.detector.TIME_INTERVAL[1], ps.shape[1] + 1)
+    for name in ("default", "low"):
+        thr = np.full(len(upix), float(g[f"threshold_{name}"]))
+        adc, ticks, frac = O.get_adc_values(ps, pts, tt, thr)
+        ref = g[f"adc_integral_{name}"]
+        assert np.array_equal(adc != 0, ref != 0)
+        np.testing.assert_allclose(adc, ref, rtol=1e-12)
+        assert np.array_equal(ticks, g[f"adc_ticks_{name}"])
+        hit = ref != 0
+        np.testing.assert_allclose(frac[hit], g[f"adc_fractions_{name}"][hit], rtol=1e-10, atol=1e-14)
+        assert np.array_equal(O.digitize(adc), g[f"adc_digit_{name}"])
+    assert (g["adc_integral_low"] != 0).sum() >= 10
+
+
+def test_numba_f32_typing_effect_is_recorded():
+    """DESIGN.md §2 typing caveat: Numba keeps f32 (op) f32 in single precision for f4 record fields.  The oracle can
+    emulate those spots; the induced current then moves by ~2e-7 of the waveform peak (median), <1e-3 worst case."""
+    H.load_cfg("module0")
+    from larndsim_amd import batching, synth
+    seg = synth.make_segments(6, seed=77, segs_per_event=6)
+    batching.swap_coordinates(seg)
+    O.quench(seg, 2)
+    O.drift(seg)
+    nmax = O.max_pixels(seg)
+    _, neigh, _, _ = O.get_pixels(seg, nmax, 3 * nmax + 6, 1)
+    _, T = O.time_intervals(seg)
+    resp = synth.make_response("dense")
+    a = O.tracks_current(seg, neigh, T, resp).astype(np.float64)
+    O.lib().o_set_numba_f32(1)
+    try:
+        b = O.tracks_current(seg, neigh, T, resp).astype(np.float64)
+    finally:
+        O.lib().o_set_numba_f32(0)
+    pk = np.abs(a).max(-1)
+    ok = (neigh >= 0) & (pk > 0)
+    rel = np.abs(a - b).max(-1)[ok] / pk[ok]
+    assert 0 < np.median(rel) < 5e-6 and rel.max() < 1e-3
+
+
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_light_golden(cfg):
+    """a17/a18: light incidence (voxel lookup) and photon sum vs the reference on a synthetic LUT."""
+    from larndsim_amd import synth
+    H.load_cfg(cfg)
+    g = H.gold(f"light_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    lut = synth.make_lut((14, 26, 8), 48, int(g["n_prof"]), int(g["lut_seed"]))
+    nph, t0d, vox = O.light_incidence(r, lut)
+    assert np.array_equal(vox, g["voxel"])
+    assert np.array_equal(nph, g["n_photons_det"])
+    assert np.array_equal(t0d, g["t0_det"])
+    n_ticks = int(g["n_ticks"])
+    Mt = g["true_id"].shape[-1]
+    out, tid, tph = O.sum_light_signals(r, vox, np.arange(len(r)), g["n_photons_det"], g["op_channel"], lut,
+                                        float(g["t_start"]), n_ticks, g["sorted_indices"], max_truth=Mt)
+    # the generator ran with f8 LUT mirrors (f64 product); the real f4 fields make Numba's product f32: <=1 ulp of f32
+    np.testing.assert_allclose(out, g["light_sample_inc"], rtol=3e-7, atol=0)
+    assert np.array_equal(tid, g["true_id"])
+    assert g["light_sample_inc"].sum() > 0
