@@ -14,9 +14,9 @@
 #define NJ_MAX 48                // max distinct j cells (response table <= 48 wide in j)
 #define NS_MAX 64                // max SAMPLED_POINTS
 #define NEDGE 3                  // partially valid edge k's: k=0 and up to 2 at the top of the window
-#define ARENA 4352               // f64 weight entries held in LDS per column group
+#define ARENA 5888               // f64 weight entries held in LDS per column group
 #define QLEN 128                 // survivor queue entries per wave
-#define CELLS_MAX 512            // response cells per column group
+#define CELLS_MAX 736            // response cells per column group
 
 
 struct PairGeo {

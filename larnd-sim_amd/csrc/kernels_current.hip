@@ -52,7 +52,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
   constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
   __shared__ double s_row[NWAVE][ROWBUF];       // wave-private staged response rows
   __shared__ double s_A[ARENA];                 // weights A[cell][u] of the current column group
-  __shared__ double s_Redge[NEDGE][CELLS_MAX];  // response at the partially valid edge k's, per cell
   __shared__ double s_C[NEDGE][NU_MAX];         // weight*response of slices that are NOT valid at an edge
   __shared__ double s_px[NS_MAX][2], s_py[NS_MAX][2], s_pz[ZC][2];   // separable parts of b and delta
   __shared__ int s_shift[ZC], s_inval[ZC];
@@ -303,14 +302,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
         const int g_ix0 = s_colstart[col0], g_nix = s_colstart[col0 + gcols] - g_ix0;
         __syncthreads();
         for (int i = tid; i < ncell * NU8; i += CUR_THREADS) s_A[i] = 0;
-        for (int i = tid; i < NEDGE * ncell; i += CUR_THREADS) {
-          int e = i / ncell, cell = i % ncell;
-          int k = edge_k[e];
-          double r = 0;
-          if (k >= k_stage_lo && k <= k_stage_hi)
-            r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + k];
-          s_Redge[e][cell] = r;
-        }
         __syncthreads();
         // ---- (1) weights.  Pass A (all lanes busy): the cheap bound on every sample, survivors pushed to a
         //      wave-private queue.  Pass B (dense lanes): 2 erf + exp per survivor, f64 ds_add into A[cell][u]. ------
@@ -336,8 +327,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
                 if (inval) {
 #pragma unroll
                   for (int e = 0; e < NEDGE; e++)
-                    if (inval & (1 << e)) {
-                      double r = s_Redge[e][cell];
+                    if ((inval & (1 << e)) && edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi) {
+                      // response at the edge index, straight from L2 (a few hundred distinct addresses per pair)
+                      double r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + edge_k[e]];
                       if (r != 0) atomicAdd(&s_C[e][u], w * r);
                     }
                 }
