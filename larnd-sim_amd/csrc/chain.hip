@@ -9,7 +9,8 @@
 #include "ldsim_args.h"
 
 int seg_launch_max_pixels(ldsim_ctx*, int64_t, int64_t, int32_t*, unsigned long long*);
-int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*);
+int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*, const int32_t*,
+                          int32_t);
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
@@ -18,7 +19,7 @@ int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
 int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
                      int32_t*, int64_t*, int64_t);
 int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
-int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*);
+int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*, unsigned long long*);
 int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
                       const double*, int, int64_t, int32_t*);
 
@@ -106,16 +107,34 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
     return LDSIM_EINVAL;
   }
 
-  // ---- a5 max_pixels + max tran_diff (max_radius, cli/simulate_pixels.py:918-928) ------------------------------------
+  // ---- a8 time_intervals per batch, and the per-batch max tran_diff that sets max_radius -------------------------------
+  CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8));
+  CK(ldsim_ensure(ctx, SB_NLIST, (size_t)n_batches * 24 + 64));   // [nb] tmax i32 | [nb] first i32 | [nb] tran u64 | [nb] radius i32
+  int32_t* d_tmax_b = (int32_t*)ctx->scratch[SB_NLIST].p;
+  int32_t* d_first_b = d_tmax_b + n_batches;
+  unsigned long long* d_tran_b = (unsigned long long*)((char*)ctx->scratch[SB_NLIST].p + ((n_batches * 8 + 15) / 16) * 16);
+  int32_t* d_radius_b = (int32_t*)(d_tran_b + n_batches);
+  HIPCHK(hipMemsetAsync(ctx->scratch[SB_NLIST].p, 0, (size_t)n_batches * 24 + 64, st));
+  double* d_starts = (double*)ctx->scratch[SB_STARTS].p;
+  CK(sort_tmax_batch(ctx, seg_begin, n, batch0, d_starts, d_tmax_b, d_tran_b));
+  CK(sort_batch_first(ctx, seg_begin, n, batch0, d_first_b));
+
+  // ---- a5 max_pixels (cli/simulate_pixels.py:918-928) ---------------------------------------------------------------------
   CK(seg_launch_max_pixels(ctx, seg_begin, seg_end, (int32_t*)(misc + 8), (unsigned long long*)(misc + 16)));
   int32_t nmax = 0;
-  unsigned long long tbits = 0;
+  std::vector<unsigned long long> h_tran(n_batches);
+  std::vector<int32_t> h_radius(n_batches);
   HIPCHK(hipMemcpyAsync(&nmax, misc + 8, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&tbits, misc + 16, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(h_tran.data(), d_tran_b, n_batches * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  double max_tran;
-  memcpy(&max_tran, &tbits, 8);
-  const int radius = (int)ceil(max_tran * 5 / h.pixel_pitch);
+  int radius = 0;
+  for (int64_t b = 0; b < n_batches; b++) {
+    double mt;
+    memcpy(&mt, &h_tran[b], 8);
+    h_radius[b] = (int32_t)ceil(mt * 5 / h.pixel_pitch);      // max_radius of the batch
+    radius = h_radius[b] > radius ? h_radius[b] : radius;
+  }
+  HIPCHK(hipMemcpyAsync(d_radius_b, h_radius.data(), n_batches * 4, hipMemcpyHostToDevice, st));
   const int P = (2 * radius + 1) * nmax + (1 + 2 * radius) * radius * 2;
   ctx->stats.max_active = nmax;
   ctx->stats.max_neigh = P;
@@ -136,17 +155,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   int32_t* d_neigh = (int32_t*)ctx->scratch[SB_NEIGH].p;
   int32_t* d_nrad = (int32_t*)ctx->scratch[SB_NRAD].p;
   CK(seg_launch_get_pixels(ctx, seg_begin, seg_end, radius, (int32_t*)ctx->scratch[SB_ACTIVE].p, nmax, d_neigh, d_nrad,
-                           P, nullptr));
-
-  // ---- a8 time_intervals per batch -------------------------------------------------------------------------------------------
-  CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8));
-  CK(ldsim_ensure(ctx, SB_NLIST, (size_t)n_batches * 8 + 64));   // [n_batches] tmax i32, [n_batches] first i32
-  int32_t* d_tmax_b = (int32_t*)ctx->scratch[SB_NLIST].p;
-  int32_t* d_first_b = d_tmax_b + n_batches;
-  HIPCHK(hipMemsetAsync(d_tmax_b, 0, (size_t)n_batches * 8, st));
-  double* d_starts = (double*)ctx->scratch[SB_STARTS].p;
-  CK(sort_tmax_batch(ctx, seg_begin, n, batch0, d_starts, d_tmax_b));
-  CK(sort_batch_first(ctx, seg_begin, n, batch0, d_first_b));
+                           P, nullptr, d_radius_b, batch0));
 
   // ---- a7 unique pixels: stable radix sort of (batch, pixel, ring code) --------------------------------------------------------
   CK(ldsim_ensure(ctx, SB_KEYS, (size_t)n_entries * 8));

@@ -201,10 +201,16 @@ __global__ void __launch_bounds__(128) get_pixels_kernel(SegStore s, const Ldsim
                                                          int64_t end, int radius, int32_t* __restrict__ active,
                                                          int max_active, int32_t* __restrict__ neigh,
                                                          int32_t* __restrict__ nrad, int P,
-                                                         double* __restrict__ n_list) {
+                                                         double* __restrict__ n_list,
+                                                         const int32_t* __restrict__ radius_b, int32_t batch0) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t i = begin + r;
   if (i >= end) return;
+  // the reference derives max_radius per batch from max(tran_diff) (cli/simulate_pixels.py:918)
+  if (radius_b) {
+    int32_t b = s.batch[i];
+    radius = b >= 0 ? radius_b[b - batch0] : 0;
+  }
   int32_t* act = active + r * max_active;
   int32_t* ng = neigh + r * P;
   int32_t* nr = nrad + r * P;
@@ -292,10 +298,11 @@ int seg_launch_max_pixels(ldsim_ctx* ctx, int64_t b, int64_t e, int32_t* d_nmax,
   return 0;
 }
 int seg_launch_get_pixels(ldsim_ctx* ctx, int64_t b, int64_t e, int radius, int32_t* active, int max_active,
-                          int32_t* neigh, int32_t* nrad, int P, double* n_list) {
+                          int32_t* neigh, int32_t* nrad, int P, double* n_list, const int32_t* radius_b,
+                          int32_t batch0) {
   if (e <= b) return 0;
   hipLaunchKernelGGL(get_pixels_kernel, dim3(nblk(e - b, 128)), dim3(128), 0, ctx->stream, ctx->seg, ctx->d_consts, b,
-                     e, radius, active, max_active, neigh, nrad, P, n_list);
+                     e, radius, active, max_active, neigh, nrad, P, n_list, radius_b, batch0);
   HIPCHK(hipGetLastError());
   return 0;
 }

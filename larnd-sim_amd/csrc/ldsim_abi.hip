@@ -17,7 +17,8 @@ int seg_launch_unpack(ldsim_ctx*, const LdsimTrackLayout*, int64_t);
 int seg_launch_repack(ldsim_ctx*, const LdsimTrackLayout*, int64_t);
 int seg_launch_quench_drift(ldsim_ctx*, int, int, int, int*);
 int seg_launch_max_pixels(ldsim_ctx*, int64_t, int64_t, int32_t*, unsigned long long*);
-int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*);
+int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*, const int32_t*,
+                          int32_t);
 int seg_launch_time_intervals(ldsim_ctx*, int64_t, int64_t, double*, int32_t*);
 int fee_launch_track_pixel_map(ldsim_ctx*, int64_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t,
                                int, int, int);
@@ -364,7 +365,7 @@ extern "C" int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, c
   HIPCHK(hipMemsetAsync(ctx->scratch[SB_NRAD].p, 0xFF, bn, ctx->stream));
   CK(seg_launch_get_pixels(ctx, 0, n, radius, (int32_t*)ctx->scratch[SB_ACTIVE].p, max_active,
                            (int32_t*)ctx->scratch[SB_NEIGH].p, (int32_t*)ctx->scratch[SB_NRAD].p, P,
-                           (double*)ctx->scratch[SB_NLIST].p));
+                           (double*)ctx->scratch[SB_NLIST].p, nullptr, 0));
   if (ba) HIPCHK(hipMemcpyAsync(active, ctx->scratch[SB_ACTIVE].p, ba, hipMemcpyDeviceToHost, ctx->stream));
   if (bn) HIPCHK(hipMemcpyAsync(neigh, ctx->scratch[SB_NEIGH].p, bn, hipMemcpyDeviceToHost, ctx->stream));
   if (bn) HIPCHK(hipMemcpyAsync(nrad, ctx->scratch[SB_NRAD].p, bn, hipMemcpyDeviceToHost, ctx->stream));

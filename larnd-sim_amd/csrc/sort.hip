@@ -63,7 +63,8 @@ __global__ void batch_first_kernel(const int32_t* __restrict__ batch, int64_t se
 }
 
 __global__ void tmax_batch_kernel(SegStore s, const LdsimConsts* __restrict__ c, int64_t begin, int64_t n, int32_t batch0,
-                                  double* __restrict__ starts, int32_t* __restrict__ tmax_b) {
+                                  double* __restrict__ starts, int32_t* __restrict__ tmax_b,
+                                  unsigned long long* __restrict__ tran_b) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   int64_t i = begin + r;
@@ -74,6 +75,8 @@ __global__ void tmax_batch_kernel(SegStore s, const LdsimConsts* __restrict__ c,
   if (b < 0) return;
   double len = ceil((t_end - t_start) / c->time_sampling);
   if (len > 0 && len < 2.0e9) atomicMax(&tmax_b[b - batch0], (int32_t)len);
+  double td = s.f[LDSIM_TRAN_DIFF][i];
+  if (tran_b && td > 0) atomicMax(&tran_b[b - batch0], (unsigned long long)__double_as_longlong(td));
 }
 
 // compact hit rows for the multi-GPU all-gather: {batch i32, pixel i32, adc i32, tick f64-bits hi/lo}
@@ -154,10 +157,11 @@ int sort_batch_first(ldsim_ctx* ctx, int64_t seg_begin, int64_t n, int32_t batch
   return 0;
 }
 
-int sort_tmax_batch(ldsim_ctx* ctx, int64_t seg_begin, int64_t n, int32_t batch0, double* starts, int32_t* tmax_b) {
+int sort_tmax_batch(ldsim_ctx* ctx, int64_t seg_begin, int64_t n, int32_t batch0, double* starts, int32_t* tmax_b,
+                    unsigned long long* tran_b) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(tmax_batch_kernel, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->seg, ctx->d_consts,
-                     seg_begin, n, batch0, starts, tmax_b);
+                     seg_begin, n, batch0, starts, tmax_b, tran_b);
   HIPCHK(hipGetLastError());
   return 0;
 }
