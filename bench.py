@@ -31,6 +31,9 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = 50_000
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
+# current_kernel, one launch = 50k segments: FETCH_SIZE 213 MB (x2 on gfx950 = 427 MB) + WRITE_SIZE 4.56 GB; the writes are
+# the compact per-pair f32 waveforms (548k pairs x 1927 ticks x 4 B), an intermediate the algorithmic count excludes
+PROFILED_TRAFFIC_BYTES = 4.99e9
 
 
 def chunk_ranges(bid, max_segments):
@@ -199,7 +202,11 @@ def main():
                        "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "current_kernel<1>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_*: FETCH_SIZE x2 per the
+                         # gfx950 correction + WRITE_SIZE) -- only valid for the default workload/chunking
+                         "traffic": PROFILED_TRAFFIC_BYTES if (a.segments == SEGS_PER_GPU and a.response == "survey"
+                                                               and a.fractions) else None,
                          "launch_ms_avg": acc["cur_ms"] / max(acc["launches"], 1),
                          "launches": acc["launches"],
                          "algorithmic_bytes_per_launch": acc["bytes"] / max(acc["launches"], 1),

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
             double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
             double E = b * b * inv4a - delta;
             double lo = b * inv_sa2, hi = lo + hi_off;
-            double w = pref * wsample(E, lo, hi);
+            double w = (A.debug_phases & 16) ? pref * (erf(hi) - erf(lo)) * exp(E) : pref * wsample(E, lo, hi);
             if (w != 0) {
               const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
               const int u = s_shift[sl] - u_min;
