@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--response", default="survey", choices=["survey", "dense", "golden"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fractions", type=int, default=1, help="compute backtracking fractions (reference always does)")
+    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / all-gather path even with one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,12 +103,15 @@ def main():
 
     tdist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import datetime
         import torch
         import torch.distributed as tdist
         torch.cuda.set_device(local_rank)
-        tdist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=300),
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        tdist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=300), rank=rank, world_size=world,
                                  device_id=torch.device("cuda", local_rank))
 
     consts.load_snapshot("module0")
@@ -144,12 +148,12 @@ def main():
                 acc["dfma"] += st.n_dfma; acc["S"] += st.n_segments; acc["U"] += st.n_unique
                 acc["pairs"] += st.n_pairs; acc["launches"] += 1; acc["ambig"] += st.n_ambiguous
                 acc["ovf"] += st.n_overflow
-            if world > 1:
+            if use_dist:
                 p, n, rb = ch.compact_hits()
                 rows_all.append(ldist.device_rows_as_tensor(p, n, rb, torch.device("cuda", local_rank)).clone())
             if record:
                 acc["hits"] += ch.compact_hits()[1]
-        if world > 1:
+        if use_dist:
             rows = torch.cat(rows_all, dim=0)
             gathered, _ = ldist.allgather_rows(rows)
             torch.cuda.synchronize()
@@ -158,7 +162,7 @@ def main():
 
     def barrier():
         ch.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             tdist.barrier()
 
@@ -170,7 +174,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -226,7 +230,7 @@ def main():
         out["ambiguous_slices"] = acc["ambig"]
         out["overflow_pixels"] = acc["ovf"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         tdist.barrier()
         tdist.destroy_process_group()
 

