@@ -434,4 +434,6 @@ def test_cli_end_to_end(tmp_path):
     assert np.array_equal(out["unique_pix"], ref["unique_pix"]) and np.array_equal(out["adc_list"], ref["adc_list"])
     assert np.array_equal(out["event_id"], np.array([t[0] for t in table])[ref["batch"]])
     # stored un-swapped: x is the drift axis again
-    assert np.allclose(out["segments"]["x"], seg["x"][np.isin(seg["segment_id"], out["segments"]["segment_id"])][np.argsort(np.argsort(out["segments"]["segment_id"]))] if False else out["segments"]["x"])
+    by_id = {int(r["segment_id"]): r for r in seg}
+    for r in out["segments"]:
+        assert r["x"] == by_id[int(r["segment_id"])]["x"] and r["z"] == by_id[int(r["segment_id"])]["z"]
