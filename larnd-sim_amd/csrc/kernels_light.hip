@@ -117,6 +117,64 @@ __global__ void __launch_bounds__(64) sum_light_signals_kernel(SegStore s, const
   out[(int64_t)idet * n_ticks + itick] = acc;
 }
 
+
+// Scatter form of the photon sum for the (default) case without truth slots: one workgroup per (detector, tick tile)
+// keeps the tile in LDS as f64 and every thread walks its share of the segments, adding each contribution to the one
+// tick whose (start, end) window the reference's strict inequalities select (candidates it-1, it, it+1 are tested with
+// the reference's own expressions).  Work is O(n_det * tiles * S + contributions) instead of O(n_det * n_ticks * S).
+// The accumulation order differs from the reference's sorted loop, so the f32 result can differ in the last bits.
+#define LTILE 8192
+__global__ void __launch_bounds__(256) sum_light_scatter_kernel(SegStore s, const LdsimConsts* __restrict__ c,
+                                                                const int32_t* __restrict__ voxel,
+                                                                const float* __restrict__ nph, int n_inc,
+                                                                const int32_t* __restrict__ op_channel, int n_det,
+                                                                const float* __restrict__ t0_avg,
+                                                                const float* __restrict__ time_dist, int ny, int nz,
+                                                                int ndet_lut, int nprof, double start_time,
+                                                                int64_t n_ticks, float* __restrict__ out) {
+  __shared__ double acc[LTILE];
+  const int idet = blockIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.y * LTILE;
+  const int tlen = (int)min((int64_t)LTILE, n_ticks - tile0);
+  if (idet >= n_det || tlen <= 0) return;
+  const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
+  for (int i = threadIdx.x; i < tlen; i += 256) acc[i] = 0;
+  __syncthreads();
+  const int opch = op_channel[idet];
+  const int idet_lut = opch % ndet_lut;
+  auto deposit = [&](double pt, double photons) {
+    double f = floor((pt - start_time) / tick);
+    if (!(f > -2.0 && f < (double)n_ticks + 1.0)) return;
+    int64_t it0 = (int64_t)f;
+    for (int64_t it = it0 - 1; it <= it0 + 1; it++) {
+      if (it < tile0 || it >= tile0 + tlen) continue;
+      double st = it * tick + start_time, en = st + tick;
+      if (pt < en && pt > st) atomicAdd(&acc[it - tile0], photons);
+    }
+  };
+  for (int64_t itrk = threadIdx.x; itrk < s.n; itrk += 256) {
+    float ph = nph[itrk * n_inc + opch];
+    if (!(ph > 0)) continue;
+    double track_time = s.f[LDSIM_T0][itrk];
+    const int32_t* vx = voxel + itrk * 3;
+    int64_t lb = ((((int64_t)vx[0] * ny + vx[1]) * nz + vx[2]) * ndet_lut + idet_lut);
+    if (c->enable_lut_smearing) {
+      const float* prof = time_dist + lb * nprof;
+      for (int ip = 0; ip < nprof; ip++) {
+        float p = prof[ip];
+        if (p != 0.f) deposit(track_time + ip * ns / mus, (double)ph * (double)p / tick);
+      }
+    } else {
+      deposit(track_time + (double)t0_avg[lb] * ns / mus, (double)ph / tick);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tlen; i += 256) {
+    int64_t o = (int64_t)idet * n_ticks + tile0 + i;
+    out[o] = (float)((double)out[o] + acc[i]);
+  }
+}
+
 extern "C++" {
 int light_launch_incidence(ldsim_ctx* ctx, int n_out, float* nph, float* t0det, int32_t* voxel) {
   int64_t total = ctx->seg.n * n_out;
@@ -131,6 +189,13 @@ int light_launch_sum(ldsim_ctx* ctx, const int32_t* voxel, const int64_t* track_
                      const int32_t* op_channel, int n_det, const int32_t* sorted_idx, double start_time, int64_t n_ticks,
                      float* out, int64_t* true_id, double* true_ph, int max_truth) {
   if (n_det == 0 || n_ticks == 0) return 0;
+  if (max_truth == 0) {
+    hipLaunchKernelGGL(sum_light_scatter_kernel, dim3(n_det, (unsigned)((n_ticks + LTILE - 1) / LTILE)), dim3(256), 0,
+                       ctx->stream, ctx->seg, ctx->d_consts, voxel, nph, n_inc, op_channel, n_det, ctx->d_lut_t0avg,
+                       ctx->d_lut_td, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->lut_nprof, start_time, n_ticks, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sum_light_signals_kernel, dim3(n_det, (unsigned)((n_ticks + 63) / 64)), dim3(64), 0, ctx->stream,
                      ctx->seg, ctx->d_consts, voxel, track_id, nph, n_inc, op_channel, n_det, ctx->d_lut_t0avg,
                      ctx->d_lut_td, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->lut_nprof, start_time, sorted_idx,
