@@ -444,3 +444,39 @@ def test_cli_end_to_end(tmp_path):
     by_id = {int(r["segment_id"]): r for r in seg}
     for r in out["segments"]:
         assert r["x"] == by_id[int(r["segment_id"])]["x"] and r["z"] == by_id[int(r["segment_id"])]["z"]
+
+
+def test_tracks_current_edge_cases_vs_oracle():
+    """Degenerate and extreme segments: x_start == x_end (reference returns 0, detsim.py:62-69), z_start == z_end,
+    a 6 cm steep segment (many slice chunks, waveform longer than one 2048-tick tile), a segment leaving the pixel
+    plane (-1 gaps), and one outside every TPC."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(6, seed=5, segs_per_event=6)
+    batching.swap_coordinates(seg)
+    B = consts.detector.TPC_BORDERS[0]
+    zmid = 0.5 * (B[2][0] + B[2][1])
+    def put(i, a, b):
+        for k, ax in enumerate("xyz"):
+            seg[ax + "_start"][i] = a[k]; seg[ax + "_end"][i] = b[k]
+            seg[ax][i] = 0.5 * (np.float32(a[k]).astype(np.float64) + np.float32(b[k]))
+        seg["dx"][i] = np.linalg.norm(np.array(b) - np.array(a)); seg["dE"][i] = 2.1 * seg["dx"][i]
+    x0, y0 = B[0][0] + 20.0, B[1][0] + 50.0
+    put(0, (x0, y0, zmid), (x0, y0 + 0.3, zmid + 0.2))                 # x_start == x_end
+    put(1, (x0, y0, zmid), (x0 + 0.3, y0 + 0.1, zmid))                 # z_start == z_end
+    put(2, (x0, y0, B[2][0] + np.sign(B[2][1] - B[2][0]) * 2.0), (x0 + 0.4, y0 + 0.3, B[2][0] + np.sign(B[2][1] - B[2][0]) * 8.0))   # 6 cm, steep
+    put(3, (B[0][0] + 0.5, y0, zmid), (B[0][0] - 0.3, y0 + 0.2, zmid + 0.1))     # leaves the pixel plane
+    put(4, (x0 + 500, y0, zmid), (x0 + 500.2, y0, zmid + 0.1))         # outside every TPC
+    r = H.quench_drift(O, seg)
+    assert r["pixel_plane"][4] == consts.detector.DEFAULT_PLANE_INDEX
+    nmax = O.max_pixels(r)
+    P = 3 * nmax + 6
+    _, neigh, nrad, _ = O.get_pixels(r, nmax, P, 1)
+    _, T = O.time_intervals(r)
+    assert T > 2048                                                      # second tick tile exercised
+    resp = synth.make_response("golden")
+    ref = O.tracks_current(r, neigh, T, resp)
+    sig = np.zeros_like(ref)
+    detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
+    assert not ref[0].any() and not sig[0].any() and not sig[4].any()
+    H.assert_wave_close(sig, ref, rtol=1e-5, atol_peak=1e-7, what="edge cases")
+    assert np.abs(ref[2]).max() > 0 and np.abs(ref[3]).max() > 0
