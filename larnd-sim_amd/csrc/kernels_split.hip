@@ -1,26 +1,23 @@
-// kernels_split.hip -- a9-a12 as two kernels (the default path of the chain):
+// kernels_split.hip -- a9-a12 as two kernels (option "split_kernels"):
 //
 //   weights_kernel<M>   one workgroup per (segment, pixel) pair: evaluates every charge sample once and emits the
 //                       pair's binned weights  A[cell][shift]  as compact "items" (cell id, first shift, #8-shift
-//                       blocks, offset into a global f64 arena) plus the window-edge corrections.  No response rows
-//                       are touched, so its LDS holds a larger weight arena and the erf/erfcx tables.
-//   mac_kernel<M>       one workgroup per block of 8 consecutive pairs of the pixel-sorted pair list (same pixel or
-//                       neighbours, i.e. mostly the same response cells): the pairs' item lists (sorted by cell) are
-//                       merged on the fly, every response row tile is staged ONCE per wave and reused by all pairs
-//                       that need it; per pair the register-tiled sliding-window correlation of kernels_current.hip.
+//                       blocks, offset into a global f64 arena) plus the window-edge corrections.  It touches no
+//                       response rows, needs ~45 KB of LDS and ~135 VGPRs -> 3 workgroups per CU.
+//   mac_kernel<M>       one workgroup per pair: streams the pair's items; per item the response row segment and the
+//                       item's weights are prefetched into registers one item ahead, staged in wave-private LDS and
+//                       correlated with the register-tiled sliding window of kernels_current.hip.  ~30 KB LDS.
 //
 // Pairs that exceed the fixed item / correction capacities are flagged and recomputed by the monolithic
 // current_kernel (kernels_current.hip), which has no such limits.
 #include "current_common.h"
 
-#define PB 4            // pairs per mac workgroup
 #define IMAX 512        // items per pair
 #define CMAX 192        // edge corrections per pair
 #define RUNS_MAX 8      // sorted runs (slice chunks) per pair
 #define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
-#define W_ARENA 4608
-#define W_CELLS 576
-#define MAC_SPAN 256    // max spread of first shifts staged together
+#define W_ARENA 3072
+#define W_CELLS 512
 
 struct Item {
   int32_t cell_nblk;   // cell | nblk << 16
@@ -42,20 +39,9 @@ struct SplitArgs {
   unsigned long long* cursor;    // bump allocator (doubles)
 };
 
-__device__ __forceinline__ double tabL(const double* T, int n, double x) {   // table staged in LDS, [n][10]
-  int i = (int)(x * 8.0);
-  i = i < n - 1 ? i : n - 1;
-  const double s = (x - (i * 0.125 + 0.0625)) * 16.0;
-  const double* c = T + i * (ERFCX_DEG + 1);
-  double p = c[ERFCX_DEG];
-#pragma unroll
-  for (int d = ERFCX_DEG - 1; d >= 0; d--) p = fma(p, s, c[d]);
-  return p;
-}
-
 // =============================================================================================================
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -85,7 +71,6 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
   __shared__ double s_A[W_ARENA];
   __shared__ double s_Redge[NEDGE][W_CELLS];
   __shared__ double s_C[NEDGE][NU_MAX];
-  __shared__ double s_tx[ERFCX_N * (ERFCX_DEG + 1)], s_te[ERF_N * (ERFCX_DEG + 1)];
   __shared__ double s_px[NS_MAX][2], s_py[NS_MAX][2], s_pz[ZC][2];
   __shared__ int s_shift[ZC], s_inval[ZC];
   __shared__ short s_icell[NS_MAX], s_jcell[NS_MAX], s_colof[NS_MAX], s_coli[NS_MAX], s_colstart[NS_MAX + 1];
@@ -97,8 +82,6 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
   __shared__ int s_misc[24];
   __shared__ unsigned long long s_base64;
 
-  for (int i = tid; i < ERFCX_N * (ERFCX_DEG + 1); i += CUR_THREADS) s_tx[i] = (&erfcx_tab[0][0])[i];
-  for (int i = tid; i < ERF_N * (ERFCX_DEG + 1); i += CUR_THREADS) s_te[i] = (&erf_tab[0][0])[i];
 
   // ---- sample -> response cell maps; column slots ordered by response index i ---------------------------------
   if (wv == 0) {
@@ -255,24 +238,6 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
   Item* items = S.items + pair * IMAX;
   Corr* corr = S.corr + pair * CMAX;
 
-  auto wsample = [&](double E, double lo, double hi) -> double {   // exp(E) (erf(hi) - erf(lo)), tables in LDS
-    if (lo < 0 && hi > 0) {
-      double eh = hi >= 6.0 ? 1.0 : tabL(s_te, ERF_N, hi), el = -lo >= 6.0 ? 1.0 : tabL(s_te, ERF_N, -lo);
-      return exp(E) * (eh + el);
-    }
-    const double al = fabs(lo), ah = fabs(hi);
-    const double A1 = fmin(al, ah), A2 = fmax(al, ah);
-    if (A1 < 2.0) {
-      double e2 = A2 >= 6.0 ? 1.0 : tabL(s_te, ERF_N, A2);
-      return exp(E) * (e2 - tabL(s_te, ERF_N, A1));
-    }
-    const double e1 = exp(E - A1 * A1);
-    const double t = (A2 - A1) * (A2 + A1);
-    double tail = 0.0;
-    if (t < 45.0) tail = exp(-t) * (A2 < 16.0 ? tabL(s_tx, ERFCX_N, A2) : erfcx_pos(A2));
-    return e1 * ((A1 < 16.0 ? tabL(s_tx, ERFCX_N, A1) : erfcx_pos(A1)) - tail);
-  };
-
   int iz_next = iz_lo;
   while (iz_next <= iz_hi) {
     __syncthreads();
@@ -349,7 +314,7 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
             double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
             double E = b * b * inv4a - delta;
             double lo = b * inv_sa2, hi = lo + hi_off;
-            double w = (A.debug_phases & 16) ? pref * (erf(hi) - erf(lo)) * exp(E) : pref * wsample(E, lo, hi);
+            double w = pref * (erf(hi) - erf(lo)) * exp(E);          // detsim.py:150-157 (literal form)
             if (w != 0) {
               const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
               const int u = s_shift[sl] - u_min;
@@ -515,64 +480,29 @@ __global__ void __launch_bounds__(CUR_THREADS) weights_kernel(SplitArgs S) {
 
 // =============================================================================================================
 template <int M>
-__device__ __forceinline__ void mac_item(double (&acc)[TPL], const double* rowp, int roff, double wreg, int nblk,
-                                         int lane) {
-  // wreg: lane u holds weight[u] of this item (one coalesced 8 B/lane load); broadcast per shift with readlane
-  const int rl = M * TPL * lane + roff;
-  double w[M * (TPL - 1) + 8 + 1];
-#pragma unroll
-  for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rowp[rpos<M>(rl + q)];
-  for (int b8 = 0; b8 < nblk; b8++) {
-    const int u0 = b8 * 8;
-#pragma unroll
-    for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rowp[rpos<M>(rl + u0 + M * (TPL - 1) + 1 + q)];
-#pragma unroll
-    for (int du = 0; du < 8; du++) {
-      const double av = __shfl(wreg, u0 + du);
-#pragma unroll
-      for (int j = 0; j < TPL; j++) acc[j] = fma(av, w[M * j + du], acc[j]);
-    }
-#pragma unroll
-    for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
-  }
-}
-
-template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 2) mac_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t p0 = (int64_t)blockIdx.x * PB;
-  if (p0 >= A.n_pairs) return;
-  const int np = (int)min((int64_t)PB, A.n_pairs - p0);
-
-  constexpr int ROWLEN = M * WTILE + MAC_SPAN + 80;
-  constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
-  __shared__ double s_row[NWAVE][ROWBUF];
-  __shared__ unsigned short s_cells[PB][IMAX];
-  __shared__ int s_hdr[PB][HDR_INTS];
-  __shared__ double s_out[PB][WTILE];     // combine buffer of one tile (waves sharing a tile add in rank order)
-
-  for (int i = tid; i < np * HDR_INTS; i += CUR_THREADS) s_hdr[i / HDR_INTS][i % HDR_INTS] = S.hdr[(p0 + i / HDR_INTS) * HDR_INTS + i % HDR_INTS];
-  __syncthreads();
-  for (int i = tid; i < np * IMAX; i += CUR_THREADS) {
-    int p = i / IMAX, k = i % IMAX;
-    if (k < s_hdr[p][0]) s_cells[p][k] = (unsigned short)(S.items[(p0 + p) * IMAX + k].cell_nblk & 0xFFFF);
-  }
-  // block window = union of the pairs' response-visible windows
-  int w0 = 1 << 30, w1 = 0;
-  for (int p = 0; p < np; p++)
-    if (s_hdr[p][0] > 0) {
-      w0 = min(w0, s_hdr[p][4]);
-      w1 = max(w1, s_hdr[p][5]);
-    }
-  __syncthreads();
-  // every pair's output row is written by this kernel unless it is flagged for the monolithic kernel
-  if (w1 <= w0) {
-    for (int p = 0; p < np; p++)
-      if (!s_hdr[p][7])
-        for (int it = tid; it < A.T; it += CUR_THREADS) A.out[(p0 + p) * (int64_t)A.T + it] = 0.f;
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  const int32_t* hdr = S.hdr + pair * HDR_INTS;
+  if (hdr[7]) return;                               // overflowed: the monolithic kernel writes this pair
+  float* out = A.out + pair * (int64_t)A.T;
+  const int n_items = hdr[0], n_corr = hdr[1], it0 = hdr[2], T = hdr[3], it_w0 = hdr[4], it_w1 = hdr[5];
+  if (n_items <= 0 || it_w1 <= it_w0) {
+    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
     return;
   }
+  constexpr int ROWLEN = M * WTILE + NU_MAX + 16;
+  constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
+  __shared__ double s_row[NWAVE][ROWBUF];           // wave-private staged response row
+  __shared__ double s_w[NWAVE][64];                 // wave-private weights of the current item
+  __shared__ Item s_items[IMAX];
+  __shared__ double s_out[TILE_TICKS];
+
+  const Item* gitems = S.items + pair * IMAX;
+  for (int i = tid; i < n_items; i += CUR_THREADS) s_items[i] = gitems[i];
+  __syncthreads();
   const int k_stage_lo = max(0, A.k_first);
   int k_stage_hi;
   {
@@ -584,12 +514,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) mac_kernel(SplitArgs S) {
     if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;
     k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
   }
-  // head of every (pair, run): lane = pair*8 + run
-  const int hp = lane >> 3, hr = lane & 7;
   unsigned long long n_blocks = 0;
 
-  for (int sup0 = w0; sup0 < w1; sup0 += TILE_TICKS) {
-    const int wlen = min(w1 - sup0, TILE_TICKS);
+  for (int sup0 = it_w0; sup0 < it_w1; sup0 += TILE_TICKS) {
+    const int wlen = min(it_w1 - sup0, TILE_TICKS);
     const int ntt = (wlen + WTILE - 1) / WTILE;
     int my_tile, share_rank, nshare;
     if (ntt >= 3) { my_tile = wv; share_rank = 0; nshare = 1; }
@@ -597,123 +525,87 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) mac_kernel(SplitArgs S) {
     else { my_tile = 0; share_rank = wv; nshare = 4; }
     const bool tile_live = my_tile < ntt;
     const int tb = sup0 + my_tile * WTILE;
-    double acc0[TPL], acc1[TPL], acc2[TPL], acc3[TPL];
+    double acc[TPL];
 #pragma unroll
-    for (int j = 0; j < TPL; j++) acc0[j] = acc1[j] = acc2[j] = acc3[j] = 0;
+    for (int j = 0; j < TPL; j++) acc[j] = 0;
 
     if (tile_live) {
-      int idx = 0, end = 0;
-      if (hp < np && hr < s_hdr[hp][6]) {
-        idx = s_hdr[hp][8 + hr];
-        end = s_hdr[hp][8 + hr + 1];
-      }
       double* rowp = s_row[wv];
-      int cellno = 0;
-      while (true) {
-        int mycell = (idx < end) ? (int)s_cells[hp][idx] : (1 << 30);
-        int cmin = mycell;
-        for (int off = 32; off > 0; off >>= 1) cmin = min(cmin, __shfl_xor(cmin, off));
-        if (cmin >= (1 << 30)) break;
-        const bool mine = (mycell == cmin);
-        unsigned long long am = __ballot(mine);
-        const bool do_cell = (cellno % nshare) == share_rank;
-        cellno++;
-        if (do_cell) {
-          // the items of the heads that sit on this cell
-          Item itx;
-          itx.cell_nblk = 0; itx.sbase = 0; itx.woff_lo = itx.woff_hi = 0;
-          if (mine) itx = S.items[(p0 + hp) * IMAX + idx];
-          const int nblk = (itx.cell_nblk >> 16) & 0xFF;
-          const double* rrow = A.resp + (int64_t)cmin * A.nk;
-          unsigned long long todo = am;
-          while (todo) {
-            // stage a row segment that covers every remaining item whose first shift is within MAC_SPAN of the smallest
-            int sb = (todo >> lane) & 1ull ? itx.sbase : (1 << 30);
-            int sbmin = sb;
-            for (int off = 32; off > 0; off >>= 1) sbmin = min(sbmin, __shfl_xor(sbmin, off));
-            bool take = ((todo >> lane) & 1ull) && (itx.sbase + nblk * 8 - sbmin <= MAC_SPAN + 64);
-            unsigned long long tm = __ballot(take);
-            int send = take ? itx.sbase + nblk * 8 : -(1 << 30);
-            for (int off = 32; off > 0; off >>= 1) send = max(send, __shfl_xor(send, off));
-            const int kb = M * tb + sbmin;
-            const int nrow = M * WTILE + (send - sbmin) + 8;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (int r = lane; r < nrow; r += 64) {
-              int k = kb + r;
-              rowp[rpos<M>(r)] = (k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            unsigned long long run = tm;
-            while (run) {
-              const int src = __ffsll((long long)run) - 1;
-              run &= run - 1;
-              const int p = src >> 3;
-              const int i_nblk = __shfl(nblk, src);
-              const int i_sb = __shfl(itx.sbase, src);
-              const unsigned long long wo = ((unsigned long long)__shfl((int)itx.woff_hi, src) << 32) |
-                                            (unsigned long long)(unsigned int)__shfl((int)itx.woff_lo, src);
-              const double wreg = (lane < i_nblk * 8) ? S.wbuf[wo + lane] : 0.0;
-              const int roff = i_sb - sbmin;
-              switch (p) {
-                case 0: mac_item<M>(acc0, rowp, roff, wreg, i_nblk, lane); break;
-                case 1: mac_item<M>(acc1, rowp, roff, wreg, i_nblk, lane); break;
-                case 2: mac_item<M>(acc2, rowp, roff, wreg, i_nblk, lane); break;
-                default: mac_item<M>(acc3, rowp, roff, wreg, i_nblk, lane); break;
-              }
-              n_blocks += i_nblk;
-            }
-            todo &= ~tm;
-          }
+      double* wl = s_w[wv];
+      constexpr int NLOAD = (M * WTILE + NU_MAX + 8 + 63) / 64;
+      double pre[NLOAD], prew = 0;
+      auto fetch = [&](int li) {
+        const Item itx = s_items[li];
+        const int nblk = (itx.cell_nblk >> 16) & 0xFF;
+        const double* rrow = A.resp + (int64_t)(itx.cell_nblk & 0xFFFF) * A.nk;
+        const int kb = M * tb + itx.sbase;           // row element r  <->  response index k = kb + r
+        const int nrow = M * WTILE + nblk * 8 + 8;
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) {
+          const int r = lane + 64 * n, k = kb + r;
+          pre[n] = (r < nrow && k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
         }
-        if (mine) idx++;
+        const unsigned long long wo = ((unsigned long long)itx.woff_hi << 32) | (unsigned long long)itx.woff_lo;
+        prew = (lane < nblk * 8) ? S.wbuf[wo + lane] : 0.0;
+      };
+      if (share_rank < n_items) fetch(share_rank);
+      for (int li = share_rank; li < n_items; li += nshare) {
+        const int nblk = (s_items[li].cell_nblk >> 16) & 0xFF;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++)
+          if (lane + 64 * n < ROWLEN) rowp[rpos<M>(lane + 64 * n)] = pre[n];
+        wl[lane] = prew;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (li + nshare < n_items) fetch(li + nshare);
+        const int rl = M * TPL * lane;
+        double w[M * (TPL - 1) + 8 + 1];
+#pragma unroll
+        for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = rowp[rpos<M>(rl + q)];
+        for (int b8 = 0; b8 < nblk; b8++) {
+          const int u0 = b8 * 8;
+#pragma unroll
+          for (int q = 0; q < 8; q++) w[M * (TPL - 1) + 1 + q] = rowp[rpos<M>(rl + u0 + M * (TPL - 1) + 1 + q)];
+#pragma unroll
+          for (int du = 0; du < 8; du++) {
+            const double av = wl[u0 + du];
+#pragma unroll
+            for (int j = 0; j < TPL; j++) acc[j] = fma(av, w[M * j + du], acc[j]);
+          }
+#pragma unroll
+          for (int q = 0; q < M * (TPL - 1) + 1; q++) w[q] = w[q + 8];
+        }
+        n_blocks += nblk;
       }
     }
-    // ---- combine the waves that share a tile, apply edge corrections, mask, f32 store -------------------------------
-    for (int t = 0; t < ntt; t++) {
-      for (int rnk = 0; rnk < nshare; rnk++) {
-        __syncthreads();
-        if (tile_live && my_tile == t && share_rank == rnk) {
-#pragma unroll
-          for (int j = 0; j < TPL; j++) {
-            const int i = TPL * lane + j;
-            const double v[PB] = {acc0[j], acc1[j], acc2[j], acc3[j]};
-#pragma unroll
-            for (int p = 0; p < PB; p++) s_out[p][i] = (rnk == 0) ? v[p] : s_out[p][i] + v[p];
-          }
-        }
-      }
+    // ---- combine waves sharing a tile, window-edge corrections, mask, f32 store -------------------------------------
+    for (int rnk = 0; rnk < nshare; rnk++) {
       __syncthreads();
-      const int tbase = sup0 + t * WTILE;
-      if (tid < np) {          // one thread per pair walks its (short) correction list
-        const int p = tid;
-        const Corr* cr = S.corr + (p0 + p) * CMAX;
-        for (int k = 0; k < s_hdr[p][1]; k++) {
-          int i = cr[k].tick - tbase;
-          if (i >= 0 && i < WTILE) s_out[p][i] -= cr[k].val;
-        }
-      }
-      __syncthreads();
-      for (int p = 0; p < np; p++) {
-        if (s_hdr[p][7]) continue;
-        const int it0 = s_hdr[p][2], Tp = s_hdr[p][3], pw0 = s_hdr[p][4], pw1 = s_hdr[p][5];
-        const bool has = s_hdr[p][0] > 0;
-        float* out = A.out + (p0 + p) * (int64_t)A.T;
-        for (int i = tid; i < WTILE; i += CUR_THREADS) {
-          int it = tbase + i;
-          if (it < A.T && it < sup0 + wlen)
-            out[it] = (has && it >= it0 && it < Tp && it >= pw0 && it < pw1) ? (float)s_out[p][i] : 0.f;
+      if (tile_live && share_rank == rnk) {
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+          const int idx = my_tile * WTILE + TPL * lane + j;
+          s_out[idx] = (rnk == 0) ? acc[j] : s_out[idx] + acc[j];
         }
       }
     }
     __syncthreads();
+    {
+      const Corr* cr = S.corr + pair * CMAX;
+      for (int k = tid; k < n_corr; k += CUR_THREADS) {
+        int i = cr[k].tick - sup0;
+        if (i >= 0 && i < wlen) atomicAdd(&s_out[i], -cr[k].val);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < wlen; i += CUR_THREADS) {
+      int it = sup0 + i;
+      if (it < A.T) out[it] = (it >= it0 && it < T) ? (float)s_out[i] : 0.f;
+    }
+    __syncthreads();
   }
-  // ticks outside the block window
-  for (int p = 0; p < np; p++) {
-    if (s_hdr[p][7]) continue;
-    float* out = A.out + (p0 + p) * (int64_t)A.T;
-    for (int it = tid; it < A.T; it += CUR_THREADS)
-      if (it < w0 || it >= w1) out[it] = 0.f;
-  }
+  for (int it = tid; it < A.T; it += CUR_THREADS)
+    if (it < it_w0 || it >= it_w1) out[it] = 0.f;
   if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
 }
 
@@ -736,7 +628,7 @@ extern "C++" int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, 
   S.wbuf_cap = wbuf_cap;
   S.cursor = cursor;
   dim3 block(CUR_THREADS);
-  dim3 gw((unsigned)args.n_pairs), gm((unsigned)((args.n_pairs + PB - 1) / PB));
+  dim3 gw((unsigned)args.n_pairs), gm((unsigned)args.n_pairs);
   if (M == 1) {
     hipLaunchKernelGGL(weights_kernel<1>, gw, block, 0, ctx->stream, S);
     hipLaunchKernelGGL(mac_kernel<1>, gm, block, 0, ctx->stream, S);

@@ -99,7 +99,7 @@ struct ldsim_ctx {
   double prune_log = 30.0;
   int trim_response = 1;
   int debug_phases = 15;
-  int split_kernels = 0;            // 0: monolithic current_kernel (default), 1: weights_kernel + mac_kernel
+  int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
   int wbuf_doubles_per_pair = 6144; // capacity of the weight arena per pair (overflow -> monolithic fallback)
   int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments

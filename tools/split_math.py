@@ -8,9 +8,10 @@ for k in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOIS
 n = 20000
 seg = synth.make_segments(n, seed=synth.SEED_BASE + 2); batching.swap_coordinates(seg)
 bid, order, table = batching.assign_batches(seg); seg, bid = seg[order], bid[order]
-ch = ChargeChain(synth.make_response("survey")); ch.upload(seg, bid)
+kind = sys.argv[1] if len(sys.argv) > 1 else "survey"
+ch = ChargeChain(synth.make_response(kind)); ch.upload(seg, bid)
 lib.set_option("split_kernels", 1)
-for ph in (15, 31):
+for ph in (15,):
     lib.set_option("debug_phases", ph)
     for _ in range(2):
         ch.reset(); ch.quench_drift(); st = ch.run(0, n)
