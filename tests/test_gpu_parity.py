@@ -478,5 +478,9 @@ def test_tracks_current_edge_cases_vs_oracle():
     sig = np.zeros_like(ref)
     detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
     assert not ref[0].any() and not sig[0].any() and not sig[4].any()
-    H.assert_wave_close(sig, ref, rtol=1e-5, atol_peak=1e-7, what="edge cases")
+    # z_start == z_end: direction[2] == 0 makes the reference's track_point divide 0/0; its waveform is NaN
+    # (0 * NaN accumulates).  Recorded divergence: this build emits zeros for such a pair.
+    assert np.isnan(ref[1]).any() and not sig[1].any()
+    ok = [0, 2, 3, 4, 5]
+    H.assert_wave_close(sig[ok], ref[ok], rtol=1e-5, atol_peak=1e-7, what="edge cases")
     assert np.abs(ref[2]).max() > 0 and np.abs(ref[3]).max() > 0
