@@ -194,6 +194,7 @@ typedef struct {
   int64_t n_dfma;          /* f64 FMAs issued by the induced-current correlation loop (lanes x instructions) */
   int64_t n_fallback;      /* pairs recomputed by the monolithic kernel (split-path capacity overflow) */
   int64_t n_samples;       /* charge samples that passed the bound and were evaluated (2 erf + exp each) */
+  int64_t n_wbuf;          /* f64 entries of the weight arena used by the split path in this call */
 } LdsimChainStats;
 
 /* Fused a5-a16 (max_pixels .. digitize) on resident segments [seg_begin, seg_end):

@@ -288,6 +288,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   ctx->n_fallback = (int64_t)h_cnt[6];
   ctx->stats.n_fallback = (int64_t)h_cnt[6];
   ctx->stats.n_samples = (int64_t)h_cnt[1];
+  ctx->stats.n_wbuf = (int64_t)h_cnt[7];
   CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
   CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
                        (int32_t*)ctx->scratch[SB_HITS].p));

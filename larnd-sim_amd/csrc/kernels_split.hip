@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   Item* items = S.items + pair * IMAX;
   Corr* corr = S.corr + pair * CMAX;
 
+  unsigned long long n_surv = 0;
   int iz_next = iz_lo;
   while (iz_next <= iz_hi) {
     __syncthreads();
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
           }
           qhead = (qhead + n) & (QLEN - 1);
           qn -= n;
+          n_surv += n;
         };
         const int npz = NS * n_sl;
         const int npz_pad = (npz + 63) & ~63;
@@ -462,6 +464,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
     }
     iz_next += n_sl;
   }
+  if (lane == 0 && n_surv) atomicAdd(&A.counters[1], n_surv);
   __syncthreads();
   if (tid == 0) {
     hdr[0] = s_misc[18] ? 0 : s_misc[16];
@@ -534,16 +537,27 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
       double* wl = s_w[wv];
       constexpr int NLOAD = (M * WTILE + NU_MAX + 8 + 63) / 64;
       double pre[NLOAD], prew = 0;
+      int spos[NLOAD];                               // padded LDS position of this lane's n-th staged element
+#pragma unroll
+      for (int n = 0; n < NLOAD; n++) spos[n] = rpos<M>(lane + 64 * n);
       auto fetch = [&](int li) {
         const Item itx = s_items[li];
         const int nblk = (itx.cell_nblk >> 16) & 0xFF;
         const double* rrow = A.resp + (int64_t)(itx.cell_nblk & 0xFFFF) * A.nk;
         const int kb = M * tb + itx.sbase;           // row element r  <->  response index k = kb + r
         const int nrow = M * WTILE + nblk * 8 + 8;
+        const double* src = rrow + kb + lane;
+        if (kb >= k_stage_lo && kb + 64 * NLOAD - 1 <= k_stage_hi) {
+          // the whole staged window lies inside the live response range: plain coalesced loads
 #pragma unroll
-        for (int n = 0; n < NLOAD; n++) {
-          const int r = lane + 64 * n, k = kb + r;
-          pre[n] = (r < nrow && k >= k_stage_lo && k <= k_stage_hi) ? rrow[k] : 0.0;
+          for (int n = 0; n < NLOAD; n++) pre[n] = src[64 * n];
+        } else {
+          const int r_lo = k_stage_lo - kb, r_hi = min(nrow, k_stage_hi - kb + 1);
+#pragma unroll
+          for (int n = 0; n < NLOAD; n++) {
+            const int r = lane + 64 * n;
+            pre[n] = (r >= r_lo && r < r_hi) ? src[64 * n] : 0.0;
+          }
         }
         const unsigned long long wo = ((unsigned long long)itx.woff_hi << 32) | (unsigned long long)itx.woff_lo;
         prew = (lane < nblk * 8) ? S.wbuf[wo + lane] : 0.0;
@@ -554,7 +568,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
         for (int n = 0; n < NLOAD; n++)
-          if (lane + 64 * n < ROWLEN) rowp[rpos<M>(lane + 64 * n)] = pre[n];
+          if (n < NLOAD - 1 || lane + 64 * n < ROWLEN) rowp[spos[n]] = pre[n];
         wl[lane] = prew;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (li + nshare < n_items) fetch(li + nshare);

@@ -69,8 +69,7 @@ def context(device=None, refresh_consts=True, noise_zero=False):
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) if _ctx is None else _ctx_device
     if _ctx is not None and device != _ctx_device:
-        lib.ldsim_ctx_destroy(_ctx)
-        _ctx = None
+        destroy_context()
     c = pack_consts(noise_zero=noise_zero)
     if _ctx is None:
         h = C.c_void_p()
@@ -82,18 +81,35 @@ def context(device=None, refresh_consts=True, noise_zero=False):
 
 
 def destroy_context():
-    global _ctx
+    global _ctx, _resp_token, _lut_token
     if _ctx is not None:
         load().ldsim_ctx_destroy(_ctx)
         _ctx = None
+    _resp_token = _lut_token = None
 
 
-def set_response(response, ctx=None):
+_resp_token = None
+_lut_token = None
+
+
+def _token(arr, sample):
+    # identity + a strided content checksum: a freed table's address can be reused by a different table
+    return (arr.__array_interface__['data'][0], arr.shape, str(arr.dtype), float(sample))
+
+
+def set_response(response, ctx=None, force=False):
+    """Upload the induction response table unless this exact table is already resident (one token for every
+    caller, so the stage API and ChargeChain can never see each other's stale table)."""
+    global _resp_token
     ctx = ctx or context()
     r = np.ascontiguousarray(response, dtype=np.float64)
     if r.ndim != 3:
         raise ValueError("response must be [ni][nj][nk]")
+    tok = _token(r, r.ravel()[::997].sum())
+    if not force and tok == _resp_token:
+        return
     check(load().ldsim_set_response(ctx, ptr(r), C.c_int32(r.shape[0]), C.c_int32(r.shape[1]), C.c_int32(r.shape[2])))
+    _resp_token = tok
 
 
 def set_option(name, value, ctx=None):
@@ -102,13 +118,18 @@ def set_option(name, value, ctx=None):
 
 
 def set_light(lut=None, ctx=None):
-    """Upload light channel tables (from ``consts.light``) and, if given, the LUT (structured array)."""
+    """Upload light channel tables (from ``consts.light``) and, if given and not already resident, the LUT."""
+    global _lut_token
     ctx = ctx or context()
     lib = load()
     eff = np.ascontiguousarray(consts.light.OP_CHANNEL_EFFICIENCY, dtype=np.float64)
     c2t = np.ascontiguousarray(consts.light.OP_CHANNEL_TO_TPC, dtype=np.int32)
     check(lib.ldsim_set_light_channels(ctx, ptr(eff), ptr(c2t), C.c_int32(len(eff))))
     if lut is not None:
+        tok = _token(lut, lut['vis'].ravel()[::97].sum())
+        if tok == _lut_token:
+            return
+        _lut_token = tok
         vis = np.ascontiguousarray(lut['vis'], dtype=np.float32)
         t0 = np.ascontiguousarray(lut['t0'], dtype=np.float32)
         t0a = np.ascontiguousarray(lut['t0_avg'], dtype=np.float32)

@@ -7,14 +7,8 @@ from . import lib
 from ._kernel import kernel
 from .layout import make_layout
 
-_lut_token = [None]
-
-
 def _ensure_lut(lut):
-    key = (lut.__array_interface__['data'][0], lut.shape, float(lut['vis'].ravel()[::97].sum()))
-    if _lut_token[0] != key:
-        lib.set_light(lut)
-        _lut_token[0] = key
+    lib.set_light(lut)                # channel tables always, the LUT only when it is not already resident
 
 
 @kernel

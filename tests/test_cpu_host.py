@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert c.tpc_borders.offset == 13 * 8 + 8
     assert c.n_pixels.offset == c.tpc_borders.offset + 128 * 6 * 8
     assert C.sizeof(abi.LdsimTrackLayout) == 4 + 2 * 4 * layout.NFIELDS
-    assert C.sizeof(abi.LdsimChainStats) == 5 * 8 + 4 * 4 + 3 * 8
+    assert C.sizeof(abi.LdsimChainStats) == 5 * 8 + 4 * 4 + 4 * 8
 
 
 def test_segments_dtype_is_the_edep_sim_schema():

@@ -15,4 +15,4 @@ for ph in (15,):
     lib.set_option("debug_phases", ph)
     for _ in range(2):
         ch.reset(); ch.quench_drift(); st = ch.run(0, n)
-    print("phases", ph, ch.kernel_ms())
+    print("phases", ph, ch.kernel_ms(), "wbuf per pair", st.n_wbuf / st.n_pairs, "samples per pair", st.n_samples / st.n_pairs, "fallback", st.n_fallback)
