@@ -31,9 +31,10 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = 50_000
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
-# current_kernel, one launch = 50k segments: FETCH_SIZE 213 MB (x2 on gfx950 = 427 MB) + WRITE_SIZE 4.56 GB; the writes are
-# the compact per-pair f32 waveforms (548k pairs x 1927 ticks x 4 B), an intermediate the algorithmic count excludes
-PROFILED_TRAFFIC_BYTES = 4.99e9
+# weights_kernel<1>, one launch = 50k segments (profiles/r01_split_pmc_*.csv): FETCH_SIZE 107.6 MB (x2 on gfx950 = 215 MB)
+# + WRITE_SIZE 16.83 GB; the writes are the per-pair weight blocks handed to mac_kernel (an intermediate the algorithmic
+# count excludes; mac_kernel reads them back: FETCH 8.91 GB x2, and writes 4.23 GB of compact f32 waveforms)
+PROFILED_TRAFFIC_BYTES = 17.05e9
 
 
 def chunk_ranges(bid, max_segments):
@@ -132,7 +133,7 @@ def main():
     ch.upload(seg, bid)                      # H2D happens here, outside the timed region
     ranges = chunk_ranges(bid, CHUNK_SEGMENTS)
 
-    acc = {"cur_ms": 0.0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0, "S": 0, "U": 0, "pairs": 0, "launches": 0,
+    acc = {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0, "S": 0, "U": 0, "pairs": 0, "launches": 0,
            "hits": 0, "ambig": 0, "ovf": 0}
 
     def step(record):
@@ -144,6 +145,8 @@ def main():
             if record:
                 ms = ch.kernel_ms()
                 acc["cur_ms"] += ms["current_ms"]; acc["adc_ms"] += ms["adc_ms"]
+                acc["w_ms"] += ms["weights_ms"]; acc["m_ms"] += ms["mac_ms"]; acc["f_ms"] += ms["fallback_ms"]
+                acc["samples"] += st.n_samples
                 acc["bytes"] += 184.0 * st.n_segments + 484.0 * st.n_unique     # SURVEY §8d B_alg
                 acc["dfma"] += st.n_dfma; acc["S"] += st.n_segments; acc["U"] += st.n_unique
                 acc["pairs"] += st.n_pairs; acc["launches"] += 1; acc["ambig"] += st.n_ambiguous
@@ -187,9 +190,14 @@ def main():
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         value = n_job * a.steps / elapsed
-        cur_s = acc["cur_ms"] * 1e-3
-        achieved = acc["bytes"] / cur_s / 1e9 if cur_s > 0 else 0.0
-        tflops = 2.0 * acc["dfma"] / cur_s / 1e12 if cur_s > 0 else 0.0
+        split = acc["w_ms"] > 0
+        # dominant kernel of the path: weights_kernel (split path, default) or the monolithic current_kernel
+        dom_ms = acc["w_ms"] if split else acc["cur_ms"]
+        dom_s = dom_ms * 1e-3
+        achieved = acc["bytes"] / dom_s / 1e9 if dom_s > 0 else 0.0
+        mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
+        tflops = 2.0 * acc["dfma"] / mac_s / 1e12 if mac_s > 0 else 0.0
+        nl = max(acc["launches"], 1)
         out = {
             "metric": "edep segments/s end-to-end (quench->ADC), module0 config",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -204,22 +212,26 @@ def main():
                        "unique_pixels_per_segment": acc["U"] / max(acc["S"], 1),
                        "hits_per_step": acc["hits"] // max(a.steps, 1),
                        "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "current_kernel<1>",
+            "roofline": {"bound": "hbm", "kernel": "weights_kernel<1>" if split else "current_kernel<1>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_*: FETCH_SIZE x2 per the
                          # gfx950 correction + WRITE_SIZE) -- only valid for the default workload/chunking
                          "traffic": PROFILED_TRAFFIC_BYTES if (a.segments == SEGS_PER_GPU and a.response == "survey"
-                                                               and a.fractions) else None,
-                         "launch_ms_avg": acc["cur_ms"] / max(acc["launches"], 1),
+                                                               and a.fractions and split) else None,
+                         "launch_ms_avg": dom_ms / nl,
                          "launches": acc["launches"],
-                         "algorithmic_bytes_per_launch": acc["bytes"] / max(acc["launches"], 1),
-                         "note": "compute-bound kernel: see valu_f64; HBM fraction is tiny by construction "
-                                 "(SURVEY §8d: ~2 KB of compulsory traffic per segment)",
-                         "valu_f64": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "algorithmic_bytes_per_launch": acc["bytes"] / nl,
+                         "note": "f64-VALU-bound path: HBM fraction is tiny by construction (SURVEY 8d: ~2 KB of "
+                                 "compulsory traffic per segment); see valu_f64 and stage_kernels",
+                         "stage_kernels": {"weights_kernel_ms_avg": acc["w_ms"] / nl, "mac_kernel_ms_avg": acc["m_ms"] / nl,
+                                           "current_kernel_ms_avg": acc["f_ms"] / nl,
+                                           "pixel_adc_kernel_ms_avg": acc["adc_ms"] / nl,
+                                           "charge_samples_per_launch": acc["samples"] / nl},
+                         "valu_f64": {"kernel": "mac_kernel<1>" if split else "current_kernel<1>",
+                                      "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
-                                      "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)},
-                         "adc_kernel_ms_avg": acc["adc_ms"] / max(acc["launches"], 1)},
+                                      "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},
         }
         if not a.no_cpu_baseline:
             try:

@@ -215,6 +215,9 @@ int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, i
 
 /* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
 int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);
+/* split of current_ms over the tracks_current kernels of the last chain call: weights_kernel, mac_kernel and the
+ * monolithic current_kernel (overflow fallback, or the whole stage when the split path is off: then the first two are 0) */
+int ldsim_chain_kernel_ms_detail(ldsim_ctx* ctx, double* weights_ms, double* mac_ms, double* fallback_ms);
 
 #ifdef __cplusplus
 }

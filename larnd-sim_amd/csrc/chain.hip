@@ -221,7 +221,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   a.only_flagged = nullptr;
   a.flag_stride = 0;
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  bool split_done = false;
+  bool split_done = false, split_timed = false;
   if (ctx->split_kernels) {
     size_t ib, hb, cb;
     split_sizes(&ib, &hb, &cb);
@@ -234,6 +234,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
                           (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
     if (rc < 0) return rc;
     if (rc == 0) {
+      split_timed = true;
       // pairs that overflowed the split path's fixed capacities: recompute with the monolithic kernel
       a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
       a.flag_stride = (int32_t)(hb / 4);
@@ -297,6 +298,13 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->ms_current = ms;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->ms_adc = ms;
+  ctx->ms_weights = ctx->ms_mac = 0;
+  ctx->ms_fallback = ctx->ms_current;
+  if (split_timed) {
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5])); ctx->ms_weights = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->ms_mac = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[2])); ctx->ms_fallback = ms;
+  }
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4])); ctx->ms_total = ms;
   return 0;
 }

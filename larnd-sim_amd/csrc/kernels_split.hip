@@ -645,11 +645,14 @@ extern "C++" int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, 
   dim3 gw((unsigned)args.n_pairs), gm((unsigned)args.n_pairs);
   if (M == 1) {
     hipLaunchKernelGGL(weights_kernel<1>, gw, block, 0, ctx->stream, S);
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(mac_kernel<1>, gm, block, 0, ctx->stream, S);
   } else {
     hipLaunchKernelGGL(weights_kernel<2>, gw, block, 0, ctx->stream, S);
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(mac_kernel<2>, gm, block, 0, ctx->stream, S);
   }
+  HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
   HIPCHK(hipGetLastError());
   return 0;
 }

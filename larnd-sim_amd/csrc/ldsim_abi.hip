@@ -115,7 +115,7 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
   ctx->device = device;
   HIPCHK(hipStreamCreate(&ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
-  for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
   *out = ctx;
   return ldsim_set_consts(ctx, consts);
 }
@@ -139,7 +139,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
     if (p) (void)hipFree(p);
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 8; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -620,5 +620,13 @@ extern "C" int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double*
   if (current_ms) *current_ms = ctx->ms_current;
   if (adc_ms) *adc_ms = ctx->ms_adc;
   if (total_ms) *total_ms = ctx->ms_total;
+  return 0;
+}
+
+extern "C" int ldsim_chain_kernel_ms_detail(ldsim_ctx* ctx, double* weights_ms, double* mac_ms, double* fallback_ms) {
+  NEED(ctx, "null ctx");
+  if (weights_ms) *weights_ms = ctx->ms_weights;
+  if (mac_ms) *mac_ms = ctx->ms_mac;
+  if (fallback_ms) *fallback_ms = ctx->ms_fallback;
   return 0;
 }

@@ -112,8 +112,9 @@ struct ldsim_ctx {
   LdsimChainStats stats{};
   int64_t chain_U = 0, chain_hits = 0;
   int want_fractions = 0;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double ms_current = 0, ms_adc = 0, ms_total = 0;
+  double ms_weights = 0, ms_mac = 0, ms_fallback = 0;   // split path: per-kernel share of ms_current
 };
 
 // scratch slots

@@ -60,7 +60,10 @@ class ChargeChain:
     def kernel_ms(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         lib.check(lib.load().ldsim_chain_kernel_ms(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(current_ms=a.value, adc_ms=b.value, total_ms=c.value)
+        w, m, f = C.c_double(), C.c_double(), C.c_double()
+        lib.check(lib.load().ldsim_chain_kernel_ms_detail(self.ctx, C.byref(w), C.byref(m), C.byref(f)))
+        return dict(current_ms=a.value, adc_ms=b.value, total_ms=c.value, weights_ms=w.value, mac_ms=m.value,
+                    fallback_ms=f.value)
 
     def download(self, fractions=None):
         """Per-unique-(batch, pixel) results of the last run(), reference dtypes."""
