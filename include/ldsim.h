@@ -107,7 +107,11 @@ int ldsim_set_light_channels(ldsim_ctx* ctx, const double* efficiency, const int
 int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const float* t0_avg,
                         const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet, int32_t nprof);
 /* tuning / validation knobs: "prune_log" (weights below exp(-v) of the local peak are skipped, 0 = keep all),
- * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell) */
+ * "tail_log" (split path: charge samples bounded by exp(-v) of the segment's peak density are evaluated in f32,
+ * relative error ~3e-7 of a term that small; 0 = every sample in f64),
+ * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell),
+ * "split_kernels" (1 = weights_kernel + mac_kernel, 0 = monolithic current_kernel),
+ * "wbuf_doubles_per_pair" (capacity of the split path's weight stream) */
 int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
 int ldsim_synchronize(ldsim_ctx* ctx);
 

@@ -42,6 +42,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
     a.k_last = ctx->nk - 1;
   }
   a.prune_log = ctx->prune_log;
+  a.tail_log = ctx->tail_log;
   a.debug_phases = ctx->debug_phases;
 }
 

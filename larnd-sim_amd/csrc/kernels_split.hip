@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   __shared__ unsigned char s_culo[W_CELLS], s_cuhi[W_CELLS];
   __shared__ unsigned short s_boff[W_CELLS];    // first 8-shift block of every listed cell inside the group's allocation
   __shared__ unsigned int s_q[NWAVE][QLEN];
+  __shared__ unsigned int s_qt[NWAVE][QLEN];    // tail class (f32 evaluation)
   __shared__ int s_misc[24];
   __shared__ unsigned long long s_base64;
 
@@ -195,6 +196,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   const double hi_off = 2 * a * g.Dr * inv_sa2;
   const bool do_prune = A.prune_log > 0;
   const double cut = -A.prune_log;
+  // samples bounded by exp(-tail_log) of the segment's peak density are evaluated in f32 (relative error ~3e-7 of
+  // a term that is itself < exp(-tail_log) of the peak); 0 = every sample in f64
+  const bool do_tail = A.tail_log > 0;
+  const double tcut = -A.tail_log;
 
   auto slice_shift = [&](int iz, double& z, double& t0, bool count) -> int {
     z = g.z_start_int + iz * g.z_step;
@@ -305,39 +310,86 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
       __syncthreads();
       {
         unsigned int* q = s_q[wv];
-        int qhead = 0, qn = 0;
+        unsigned int* qt = s_qt[wv];
+        int qhead = 0, qn = 0, qthead = 0, qtn = 0;
+        auto deposit = [&](int ix, int iy, int sl, double w) {
+          const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
+          const int u = s_shift[sl] - u_min;
+          atomicAdd(&s_A[cell * NU8 + u], w);
+          const int inval = s_inval[sl];
+          if (inval) {
+#pragma unroll
+            for (int e = 0; e < NEDGE; e++)
+              if (inval & (1 << e)) {
+                double r = s_Redge[e][cell];
+                if (r != 0) atomicAdd(&s_C[e][u], w * r);
+              }
+          }
+        };
         auto process = [&](int n) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane < n) {
+          if (lane < n && (A.debug_phases & 1)) {
             unsigned int en = q[(qhead + lane) & (QLEN - 1)];
             const int ix = en >> 12, iy = (en >> 6) & 63, sl = en & 63;
             double b = -(s_px[ix][0] + s_py[iy][0] + s_pz[sl][0]);
             double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
             double E = b * b * inv4a - delta;
             double lo = b * inv_sa2, hi = lo + hi_off;
-            double w = pref * (erf(hi) - erf(lo)) * exp(E);          // detsim.py:150-157 (literal form)
-            if (w != 0) {
-              const int cell = (s_colof[ix] - col0) * NJ + (s_jcell[iy] - jmin);
-              const int u = s_shift[sl] - u_min;
-              atomicAdd(&s_A[cell * NU8 + u], w);
-              const int inval = s_inval[sl];
-              if (inval) {
-#pragma unroll
-                for (int e = 0; e < NEDGE; e++)
-                  if (inval & (1 << e)) {
-                    double r = s_Redge[e][cell];
-                    if (r != 0) atomicAdd(&s_C[e][u], w * r);
-                  }
-              }
-            }
+            double w = (A.debug_phases & 4) ? pref * (erf(hi) - erf(lo)) * exp(E)          // detsim.py:150-157 (literal form)
+                                            : 1e-300 * (E + lo);
+            if (w != 0 && (A.debug_phases & 8)) deposit(ix, iy, sl, w);
           }
           qhead = (qhead + n) & (QLEN - 1);
           qn -= n;
           n_surv += n;
         };
+        // tail class: erf(hi) - erf(lo) = (sgn hi - sgn lo) - sgn(hi) erfc|hi| + sgn(lo) erfc|lo| with
+        // exp(E) erfc(z) = t exp(E - z^2 + P(2t-1)), t = 1/(1+z/2) (tools/gen_erfc32.py); the exponent is reduced in f64
+        // (k = rint(arg*log2e)) so the f32 part only sees |r| <= 0.5 + |P| log2e
+        auto processT = [&](int n) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < n && (A.debug_phases & 1)) {
+            unsigned int en = qt[(qthead + lane) & (QLEN - 1)];
+            const int ix = en >> 12, iy = (en >> 6) & 63, sl = en & 63;
+            double b = -(s_px[ix][0] + s_py[iy][0] + s_pz[sl][0]);
+            double delta = s_px[ix][1] + s_py[iy][1] + s_pz[sl][1];
+            double E = b * b * inv4a - delta;
+            double lo = b * inv_sa2, hi = lo + hi_off;
+            const float L2E = 1.44269504088896341f;
+            auto scaled_exp = [&](double arg, float extra) -> float {   // exp(arg + extra), arg <= 0
+              double a2 = arg * 1.4426950408889634074;
+              double kk = rint(a2);
+              float r = (float)(a2 - kk) + extra * L2E;
+              return ldexpf(__builtin_amdgcn_exp2f(r), (int)fmax(kk, -1000.0));
+            };
+            auto Tf = [&](double z) -> float {                          // exp(E) erfc(z), z >= 0
+              float t = __builtin_amdgcn_rcpf(1.0f + 0.5f * (float)z);
+              float u = 2.0f * t - 1.0f;
+              float P = 3.337358939e-04f;
+              P = fmaf(P, u, -2.079091206e-04f);
+              P = fmaf(P, u, -2.048734760e-03f);
+              P = fmaf(P, u, 1.776564635e-03f);
+              P = fmaf(P, u, 8.703812035e-03f);
+              P = fmaf(P, u, -9.873768747e-03f);
+              P = fmaf(P, u, -4.687488818e-02f);
+              P = fmaf(P, u, 4.734310629e-02f);
+              P = fmaf(P, u, 6.726422172e-01f);
+              P = fmaf(P, u, -6.717940761e-01f);
+              return t * scaled_exp(E - z * z, P);
+            };
+            const float th = Tf(fabs(hi)), tl = Tf(fabs(lo));
+            float wf = (hi < 0 ? th : -th) + (lo < 0 ? -tl : tl);
+            if (lo < 0 && !(hi < 0)) wf += 2.0f * scaled_exp(E, 0.0f);
+            double w = (A.debug_phases & 4) ? pref * (double)wf : 1e-300 * (E + lo);
+            if (w != 0 && (A.debug_phases & 8)) deposit(ix, iy, sl, w);
+          }
+          qthead = (qthead + n) & (QLEN - 1);
+          qtn -= n;
+          n_surv += n;
+        };
         const int npz = NS * n_sl;
         const int npz_pad = (npz + 63) & ~63;
-        for (int p0 = wv * 64; p0 < npz_pad; p0 += CUR_THREADS) {
+        for (int p0 = wv * 64; p0 < npz_pad && (A.debug_phases & 2); p0 += CUR_THREADS) {
           const int p = p0 + lane;
           bool pv = p < npz;
           const int iy = pv ? p / n_sl : 0, sl = pv ? p - iy * n_sl : 0;
@@ -346,24 +398,33 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
           const unsigned int tag = ((unsigned)iy << 6) | (unsigned)sl;
           for (int gi = 0; gi < g_nix; gi++) {
             const int ix = s_ixord[g_ix0 + gi];
-            bool keep = pv;
-            if (do_prune && keep) {
+            bool keep = pv, tail = false;
+            if ((do_prune || do_tail) && keep) {
               double b = -(s_px[ix][0] + byz);
               double E2 = b * b * inv4a - (s_px[ix][1] + dyz);
               double lo = b * inv_sa2, hi = lo + hi_off;
               if (lo > 0) E2 -= lo * lo;
               else if (hi < 0) E2 -= hi * hi;
-              keep = !(E2 < cut);
+              keep = !(do_prune && E2 < cut);
+              tail = do_tail && E2 < tcut;
             }
-            unsigned long long m = __ballot(keep);
+            const unsigned long long m = __ballot(keep && !tail), mt = __ballot(keep && tail);
             if (m) {
-              if (keep) q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
+              if (keep && !tail)
+                q[(qhead + qn + __popcll(m & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
               qn += __popcll(m);
               if (qn >= 64) process(64);
+            }
+            if (mt) {
+              if (keep && tail)
+                qt[(qthead + qtn + __popcll(mt & ((1ull << lane) - 1ull))) & (QLEN - 1)] = ((unsigned)ix << 12) | tag;
+              qtn += __popcll(mt);
+              if (qtn >= 64) processT(64);
             }
           }
         }
         if (qn > 0) process(qn);
+        if (qtn > 0) processT(qtn);
       }
       __syncthreads();
       // ---- active cells, their shift range, and the compact emit -------------------------------------------------

@@ -155,6 +155,7 @@ extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
 extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) {
   NEED(ctx && name, "null argument");
   if (!strcmp(name, "prune_log")) ctx->prune_log = value;
+  else if (!strcmp(name, "tail_log")) ctx->tail_log = value;
   else if (!strcmp(name, "trim_response")) ctx->trim_response = value != 0;
   else if (!strcmp(name, "debug_phases")) ctx->debug_phases = (int)value;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;

@@ -19,6 +19,7 @@ struct CurArgs {
   const int32_t* tmax_batch;     // per-batch max_length (chain) or NULL -> T
   int32_t batch0;
   double prune_log;
+  double tail_log;        // split path: samples below exp(-tail_log) of the peak density are evaluated in f32 (0 = off)
   int32_t debug_phases;
   unsigned long long* counters;  // [0] ambiguous-rounding slices, [5] DFMA lanes, [6] pairs sent to the fallback
   const int32_t* only_flagged;   // if set: run only pairs whose only_flagged[pair*flag_stride + 7] != 0

@@ -97,6 +97,7 @@ struct ldsim_ctx {
   int32_t lut_nx = 0, lut_ny = 0, lut_nz = 0, lut_ndet = 0, lut_nprof = 0;
   // options
   double prune_log = 30.0;
+  double tail_log = 14.0;
   int trim_response = 1;
   int debug_phases = 15;
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
