@@ -37,19 +37,6 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI35
 PROFILED_TRAFFIC_BYTES = 17.05e9
 
 
-def chunk_ranges(bid, max_segments):
-    """[begin, end) ranges aligned to batch boundaries, at most ~max_segments each."""
-    n = len(bid)
-    edges = np.flatnonzero(np.r_[True, bid[1:] != bid[:-1], True])
-    out, b = [], 0
-    for e in edges[1:]:
-        if e - b >= max_segments or e == n:
-            if e > b:
-                out.append((int(b), int(e)))
-            b = e
-    return out
-
-
 def cpu_baseline(response, n_seg=48):
     """The oracle (C port of the reference algorithm) on a bounded sample of the same workload."""
     from larndsim_amd import batching, consts, synth
@@ -131,7 +118,7 @@ def main():
 
     ch = ChargeChain(response, device=local_rank)
     ch.upload(seg, bid)                      # H2D happens here, outside the timed region
-    ranges = chunk_ranges(bid, CHUNK_SEGMENTS)
+    ranges = batching.chunk_ranges(bid, CHUNK_SEGMENTS)
 
     acc = {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0, "S": 0, "U": 0, "pairs": 0, "launches": 0,
            "hits": 0, "ambig": 0, "ovf": 0}

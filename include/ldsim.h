@@ -111,7 +111,10 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * relative error ~3e-7 of a term that small; 0 = every sample in f64),
  * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell),
  * "split_kernels" (1 = weights_kernel + mac_kernel, 0 = monolithic current_kernel),
- * "wbuf_doubles_per_pair" (capacity of the split path's weight stream) */
+ * "wbuf_doubles_per_pair" (initial average budget of the split path's weight pool; the pool grows to the measured
+ * demand and the launch is repeated when it was exhausted, so this only affects the first launches; setting it forgets
+ * the size learned so far), "split_max_items" (validation: pairs with more weight items than this are recomputed by
+ * the monolithic kernel; 0 = the built-in capacity 512 * TIME_SAMPLING/RESPONSE_SAMPLING) */
 int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
 int ldsim_synchronize(ldsim_ctx* ctx);
 

@@ -44,6 +44,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
   a.prune_log = ctx->prune_log;
   a.tail_log = ctx->tail_log;
   a.debug_phases = ctx->debug_phases;
+  a.split_max_items = ctx->split_max_items;
 }
 
 // materialising tracks_current: dense [S][P] pixel array, signals [S][P][T]
@@ -223,25 +224,49 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   a.flag_stride = 0;
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   bool split_done = false, split_timed = false;
-  if (ctx->split_kernels) {
-    size_t ib, hb, cb;
-    split_sizes(&ib, &hb, &cb);
-    const unsigned long long wcap = (unsigned long long)n_valid * (unsigned long long)ctx->wbuf_doubles_per_pair;
+  size_t ib = 0, hb = 0, cb = 0;
+  if (ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0) {
     CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
     CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));
     CK(ldsim_ensure(ctx, SB_CORR, (size_t)n_valid * cb));
-    CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
-    int rc = split_launch(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
-                          (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
-    if (rc < 0) return rc;
-    if (rc == 0) {
-      split_timed = true;
-      // pairs that overflowed the split path's fixed capacities: recompute with the monolithic kernel
-      a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
-      a.flag_stride = (int32_t)(hb / 4);
-      CK(current_launch(ctx, a));
-      split_done = true;
+    // The weights go to one pool shared by all pairs of the launch (bump allocator, counters[7] = doubles requested).
+    // Which pairs lose when it runs dry depends on scheduling order, and a pair recomputed by the monolithic kernel
+    // agrees only to rounding -- so a launch that exhausted the pool is never used: the pool is grown to the demand
+    // (a lower bound then: an exhausted pair stops requesting) and weights_kernel runs again.  The size per pair is
+    // remembered, so this happens on the first launches of a new detector configuration only.
+    double per_pair = fmax((double)ctx->wbuf_doubles_per_pair, ctx->wbuf_learned);
+    unsigned long long wcap = 0, demand = 0;
+    bool fits = false;
+    for (int attempt = 0; attempt < 6 && !fits; attempt++) {
+      wcap = (unsigned long long)ceil(per_pair * (double)n_valid);
+      CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
+      if (attempt > 0) {
+        HIPCHK(hipMemsetAsync(&counters[0], 0, 16, st));   // ambiguous shifts, samples
+        HIPCHK(hipMemsetAsync(&counters[5], 0, 24, st));   // dfma, overflowed pairs, pool cursor
+      }
+      int rc = split_launch_weights(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
+                                    (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
+      if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
+      if (rc < 0) return rc;
+      HIPCHK(hipMemcpyAsync(&demand, &counters[7], 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      fits = demand <= wcap;
+      if (!fits) per_pair = 1.5 * (double)(demand > wcap ? demand : wcap) / (double)n_valid;
     }
+    ctx->wbuf_learned = fmax(ctx->wbuf_learned, 1.25 * (double)demand / (double)n_valid);
+    HIPCHK(hipEventRecord(ctx->ev[5], st));
+    int rc = split_launch_mac(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
+                              (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
+    if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
+    if (rc < 0) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    split_timed = true;
+    // pairs beyond the per-pair item / correction / run capacities (and, after 6 attempts, a pool that still does not
+    // fit): recomputed by the monolithic kernel
+    a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
+    a.flag_stride = (int32_t)(hb / 4);
+    CK(current_launch(ctx, a));
+    split_done = true;
   }
   if (!split_done) CK(current_launch(ctx, a));
   HIPCHK(hipEventRecord(ctx->ev[2], st));

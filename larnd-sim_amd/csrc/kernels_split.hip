@@ -12,7 +12,9 @@
 // current_kernel (kernels_current.hip), which has no such limits.
 #include "current_common.h"
 
-#define IMAX 512        // items per pair
+// items per pair: 512 at M = 1; at M = 2 a 64-shift chunk covers half as many slices (twice the runs, twice the
+// items), and 1408 is what mac_kernel<2>'s LDS allows at its 2 workgroups per CU (16 B per item)
+template <int M> struct ItemCap { static constexpr int value = M == 1 ? 512 : 1408; };
 #define CMAX 192        // edge corrections per pair
 #define RUNS_MAX 8      // sorted runs (slice chunks) per pair
 #define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
@@ -31,7 +33,7 @@ struct Corr {
 
 struct SplitArgs {
   CurArgs c;
-  Item* items;            // [n_pairs][IMAX]
+  Item* items;            // [n_pairs][ItemCap<M>::value]
   int32_t* hdr;           // [n_pairs][HDR_INTS]
   Corr* corr;             // [n_pairs][CMAX]
   double* wbuf;           // weight arena
@@ -240,6 +242,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   }
   if (sh_min > sh_max || it_w1 <= it_w0 || k_stage_hi < k_stage_lo) { write_empty(); return; }
 
+  constexpr int IMAX = ItemCap<M>::value;
   Item* items = S.items + pair * IMAX;
   Corr* corr = S.corr + pair * CMAX;
 
@@ -464,7 +467,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
           int have = s_misc[16];
           unsigned long long need = (unsigned long long)nblk_tot * 8ull;
           unsigned long long base = 0;
-          bool ok = (have + nact <= IMAX) && !s_misc[18];
+          const int item_cap = (A.split_max_items > 0 && A.split_max_items < IMAX) ? A.split_max_items : IMAX;
+          bool ok = (have + nact <= item_cap) && !s_misc[18];
           if (ok && need) {
             base = atomicAdd(S.cursor, need);
             if (base + need > S.wbuf_cap) ok = false;
@@ -561,6 +565,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
   constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
   __shared__ double s_row[NWAVE][ROWBUF];           // wave-private staged response row
   __shared__ double s_w[NWAVE][64];                 // wave-private weights of the current item
+  constexpr int IMAX = ItemCap<M>::value;
   __shared__ Item s_items[IMAX];
   __shared__ double s_out[TILE_TICKS];
 
@@ -685,15 +690,19 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
 }
 
 // =============================================================================================================
-extern "C++" int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
-                              unsigned long long wbuf_cap, unsigned long long* cursor) {
-  if (args.n_pairs == 0) return 0;
+// M of the split path for these constants, 0 = configuration not covered (caller uses the monolithic kernel)
+static int split_M(const ldsim_ctx* ctx, const CurArgs& args) {
   const LdsimConsts& h = ctx->h_consts;
   double ratio = h.time_sampling / h.response_sampling;
   int M = (int)llround(ratio);
   if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX ||
       args.ni * args.nj > 65535 || args.n_pairs > 0x7fffffffLL)
-    return 1;   // not supported by the split path: caller uses the monolithic kernel
+    return 0;
+  return M;
+}
+
+static SplitArgs split_args(const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
+                            unsigned long long wbuf_cap, unsigned long long* cursor) {
   SplitArgs S;
   S.c = args;
   S.items = (Item*)items;
@@ -702,24 +711,40 @@ extern "C++" int split_launch(ldsim_ctx* ctx, const CurArgs& args, void* items, 
   S.wbuf = wbuf;
   S.wbuf_cap = wbuf_cap;
   S.cursor = cursor;
-  dim3 block(CUR_THREADS);
-  dim3 gw((unsigned)args.n_pairs), gm((unsigned)args.n_pairs);
-  if (M == 1) {
-    hipLaunchKernelGGL(weights_kernel<1>, gw, block, 0, ctx->stream, S);
-    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(mac_kernel<1>, gm, block, 0, ctx->stream, S);
-  } else {
-    hipLaunchKernelGGL(weights_kernel<2>, gw, block, 0, ctx->stream, S);
-    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(mac_kernel<2>, gm, block, 0, ctx->stream, S);
-  }
-  HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+  return S;
+}
+
+// returns 0 = launched, 1 = not covered by the split path, < 0 = error
+extern "C++" int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
+                                      unsigned long long wbuf_cap, unsigned long long* cursor) {
+  if (args.n_pairs == 0) return 0;
+  const int M = split_M(ctx, args);
+  if (!M) return 1;
+  SplitArgs S = split_args(args, items, hdr, corr, wbuf, wbuf_cap, cursor);
+  if (M == 1) hipLaunchKernelGGL(weights_kernel<1>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
+  else hipLaunchKernelGGL(weights_kernel<2>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-extern "C++" void split_sizes(size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes) {
-  *item_bytes = sizeof(Item) * IMAX;
+extern "C++" int split_launch_mac(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
+                                  unsigned long long wbuf_cap, unsigned long long* cursor) {
+  if (args.n_pairs == 0) return 0;
+  const int M = split_M(ctx, args);
+  if (!M) return 1;
+  SplitArgs S = split_args(args, items, hdr, corr, wbuf, wbuf_cap, cursor);
+  if (M == 1) hipLaunchKernelGGL(mac_kernel<1>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
+  else hipLaunchKernelGGL(mac_kernel<2>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// per-pair record sizes of the split path's HBM lists for these constants; returns M (0 = not covered)
+extern "C++" int split_sizes(const ldsim_ctx* ctx, const CurArgs& args, size_t* item_bytes, size_t* hdr_bytes,
+                             size_t* corr_bytes) {
+  const int M = split_M(ctx, args);
+  *item_bytes = sizeof(Item) * (M == 2 ? ItemCap<2>::value : ItemCap<1>::value);
   *hdr_bytes = sizeof(int32_t) * HDR_INTS;
   *corr_bytes = sizeof(Corr) * CMAX;
+  return M;
 }

@@ -159,7 +159,8 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "trim_response")) ctx->trim_response = value != 0;
   else if (!strcmp(name, "debug_phases")) ctx->debug_phases = (int)value;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
-  else if (!strcmp(name, "wbuf_doubles_per_pair")) ctx->wbuf_doubles_per_pair = (int)value;
+  else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
+  else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
   else {
     ldsim_set_error("unknown option %s", name);
     return LDSIM_EINVAL;

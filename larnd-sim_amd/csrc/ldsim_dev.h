@@ -101,7 +101,9 @@ struct ldsim_ctx {
   int trim_response = 1;
   int debug_phases = 15;
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
-  int wbuf_doubles_per_pair = 6144; // capacity of the weight arena per pair (overflow -> monolithic fallback)
+  int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
+  int split_max_items = 0;          // validation knob, see CurArgs
+  double wbuf_learned = 0;          // high-water demand per pair seen so far (x1.25): later calls size the pool with it
   int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments
   SegStore seg{};

@@ -136,3 +136,19 @@ def shard_batches(table, world_size):
     cum = np.cumsum(sizes) - sizes / 2.0
     rank[:] = np.minimum((cum * world_size / max(total, 1)).astype(np.int64), world_size - 1)
     return rank
+
+
+def chunk_ranges(bid, max_segments):
+    """[begin, end) ranges over batch-sorted segments, cut only at batch boundaries, each the smallest run of whole
+    batches holding at least ``max_segments`` segments (the last one may be shorter).  One range = one chain launch: a
+    batch (event x TPC group, cli/simulate_pixels.py:864-905) is never split, so a launch sees every segment of the
+    pixels it sums."""
+    n = len(bid)
+    edges = np.flatnonzero(np.r_[True, bid[1:] != bid[:-1], True])
+    out, b = [], 0
+    for e in edges[1:]:
+        if e - b >= max_segments or e == n:
+            if e > b:
+                out.append((int(b), int(e)))
+            b = e
+    return out

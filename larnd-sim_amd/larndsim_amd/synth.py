@@ -78,6 +78,20 @@ def make_lut(vox_div=(14, 26, 8), n_det=48, n_prof=100, seed=SEED_BASE):
     return lut
 
 
+def set_synthetic_light(channels_per_tpc=48):
+    """a detector-properties file without light keys (ndlar) gets a synthetic light set-up --
+    ``channels_per_tpc`` optical channels per TPC in TPC order, efficiency 1.  Writes the same ``consts.light`` fields
+    ``consts.set_light_properties`` would have filled from ``n_op_channel`` / ``tpc_to_op_channel``."""
+    n_tpc = int(np.asarray(consts.detector.TPC_BORDERS).shape[0])
+    l = consts.light
+    l.LIGHT_SIMULATED = True
+    l.N_OP_CHANNEL = n_tpc * int(channels_per_tpc)
+    l.OP_CHANNEL_EFFICIENCY = np.ones(l.N_OP_CHANNEL)
+    l.TPC_TO_OP_CHANNEL = np.arange(l.N_OP_CHANNEL, dtype=int).reshape(n_tpc, int(channels_per_tpc))
+    l.OP_CHANNEL_TO_TPC = np.repeat(np.arange(n_tpc, dtype=int), int(channels_per_tpc))
+    return l.N_OP_CHANNEL
+
+
 # --------------------------------------------------------------------------
 # straight-track segment sets
 # --------------------------------------------------------------------------

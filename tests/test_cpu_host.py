@@ -117,6 +117,20 @@ def test_shard_batches_balanced_and_contiguous():
         assert loads.max() / loads.mean() < 1.05
 
 
+def test_chunk_ranges_cut_only_at_batch_boundaries():
+    """One chain launch = whole batches: ranges tile [0, n), never split a batch, and reach the requested size."""
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 40, size=60)
+    bid = np.repeat(np.arange(len(sizes)), sizes)
+    for want in (1, 25, 100, 10_000):
+        r = batching.chunk_ranges(bid, want)
+        assert r[0][0] == 0 and r[-1][1] == len(bid)
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(e == len(bid) or bid[e] != bid[e - 1] for _, e in r)
+        assert all(e - b >= want for b, e in r[:-1])
+    assert batching.chunk_ranges(bid[:0], 10) == []
+
+
 def test_synthetic_inputs_are_deterministic_and_in_schema():
     consts.load_snapshot("module0")
     a = synth.make_segments(3000, seed=20241016 + 2)
