@@ -263,13 +263,19 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
         s_shift[lane] = sh;
 #pragma unroll
         for (int e = 0; e < NEDGE; e++) {
-          bool ok = false;
-          int num = edge_k[e] - sh;
-          if (edge_k[e] >= 0 && num >= 0 && (num % M) == 0) {
-            int64_t kk;
-            ok = slice_valid_at(c, g.t_start, t0, num / M, kk) && kk == edge_k[e];
+          // a correction is needed only where the correlation would use this slice's weight at a tick the reference
+          // does not: the edge index must be inside the staged response range, reachable by this shift (an integer tick)
+          // and that tick inside the stored window; everything else is dropped at the end anyway
+          bool need = false;
+          const int num = edge_k[e] - sh;
+          if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+            const int it_e = num / M;
+            if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+              int64_t kk;
+              need = !(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e]);
+            }
           }
-          if (!ok) inval |= 1 << e;
+          if (need) inval |= 1 << e;
         }
         s_inval[lane] = inval;
       }
