@@ -43,7 +43,7 @@ struct SplitArgs {
 
 // =============================================================================================================
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -71,7 +71,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
   const double bin = c->response_bin_size;
 
   __shared__ double s_A[W_ARENA];
-  __shared__ double s_Redge[NEDGE][W_CELLS];
   __shared__ double s_C[NEDGE][NU_MAX];
   __shared__ double s_px[NS_MAX][2], s_py[NS_MAX][2], s_pz[ZC][2];
   __shared__ int s_shift[ZC], s_inval[ZC];
@@ -308,14 +307,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
       const int g_ix0 = s_colstart[col0], g_nix = s_colstart[col0 + gcols] - g_ix0;
       __syncthreads();
       for (int i = tid; i < ncell * NU8; i += CUR_THREADS) s_A[i] = 0;
-      for (int i = tid; i < NEDGE * ncell; i += CUR_THREADS) {
-        int e = i / ncell, cell = i % ncell;
-        int k = edge_k[e];
-        double r = 0;
-        if (k >= k_stage_lo && k <= k_stage_hi)
-          r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + k];
-        s_Redge[e][cell] = r;
-      }
       __syncthreads();
       {
         unsigned int* q = s_q[wv];
@@ -330,7 +321,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) weights_kernel(SplitArgs S) {
 #pragma unroll
             for (int e = 0; e < NEDGE; e++)
               if (inval & (1 << e)) {
-                double r = s_Redge[e][cell];
+                // only slices flagged by the predicate above get here: edge_k[e] is inside the staged range
+                double r = A.resp[((int64_t)s_coli[col0 + cell / NJ] * A.nj + (jmin + cell % NJ)) * A.nk + edge_k[e]];
                 if (r != 0) atomicAdd(&s_C[e][u], w * r);
               }
           }
