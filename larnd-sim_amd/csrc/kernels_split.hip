@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
 
 // =============================================================================================================
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 4 : 2)) mac_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t pair = blockIdx.x;
@@ -561,11 +561,14 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
   }
   constexpr int ROWLEN = M * WTILE + NU_MAX + 16;
   constexpr int ROWBUF = ROWLEN + ROWLEN / (8 * M) + 8;
-  __shared__ double s_row[NWAVE][ROWBUF];           // wave-private staged response row
+  // wave-private staged response rows; once every wave has left the correlation loop (the barrier that opens the
+  // combine step) the same memory is the tile buffer s_out, and the barrier closing a supertile hands it back
+  __shared__ double s_rowbuf[NWAVE * ROWBUF];
+  static_assert(NWAVE * ROWBUF >= TILE_TICKS, "s_out aliases the row buffers");
+  double* const s_out = s_rowbuf;
   __shared__ double s_w[NWAVE][64];                 // wave-private weights of the current item
   constexpr int IMAX = ItemCap<M>::value;
   __shared__ Item s_items[IMAX];
-  __shared__ double s_out[TILE_TICKS];
 
   const Item* gitems = S.items + pair * IMAX;
   for (int i = tid; i < n_items; i += CUR_THREADS) s_items[i] = gitems[i];
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_kernel(SplitArgs S) {
     for (int j = 0; j < TPL; j++) acc[j] = 0;
 
     if (tile_live) {
-      double* rowp = s_row[wv];
+      double* rowp = s_rowbuf + wv * ROWBUF;
       double* wl = s_w[wv];
       constexpr int NLOAD = (M * WTILE + NU_MAX + 8 + 63) / 64;
       double pre[NLOAD], prew = 0;
