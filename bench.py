@@ -31,10 +31,11 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = 50_000
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
-# weights_kernel<1>, one launch = 50k segments (profiles/r01_split_pmc_*.csv): FETCH_SIZE 107.6 MB (x2 on gfx950 = 215 MB)
-# + WRITE_SIZE 16.83 GB; the writes are the per-pair weight blocks handed to mac_kernel (an intermediate the algorithmic
-# count excludes; mac_kernel reads them back: FETCH 8.91 GB x2, and writes 4.23 GB of compact f32 waveforms)
-PROFILED_TRAFFIC_BYTES = 17.05e9
+# weights_kernel<1>, one launch = 50k segments (profiles/r01_split_pmc_*.csv): FETCH_SIZE 196.5 MB (x2 on gfx950 = 393 MB)
+# + WRITE_SIZE 21.80 GB; the writes are the per-pair weight blocks and item lists handed to mac_kernel (intermediates the
+# algorithmic count excludes) plus ~5 GB of register-spill scratch written back (the kernel is built for 4 workgroups
+# per CU: 128 VGPRs, 52 B/lane of scratch).  mac_kernel reads the blocks back: FETCH 8.99 GB x2, WRITE 5.06 GB.
+PROFILED_TRAFFIC_BYTES = 22.19e9
 
 
 def cpu_baseline(response, n_seg=48):
