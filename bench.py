@@ -93,7 +93,14 @@ def main():
     tdist = None
     torch = None
     use_dist = world > 1 or a.force_dist
+    result_fd = None
     if use_dist:
+        # RCCL prints a version banner to stdout when the communicator is created (and may print again on teardown).
+        # The result stream must carry exactly one JSON line, so for the whole process fd 1 points at stderr and the line
+        # is written to a saved duplicate of the original stdout.
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
         import datetime
         import torch
         import torch.distributed as tdist
@@ -229,7 +236,12 @@ def main():
                                        "sample": f"failed: {e}"}
         out["ambiguous_slices"] = acc["ambig"]
         out["overflow_pixels"] = acc["ovf"]
-        print(json.dumps(out))
+        line = json.dumps(out) + "\n"
+        if result_fd is None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            os.write(result_fd, line.encode())
     if use_dist:
         tdist.barrier()
         tdist.destroy_process_group()

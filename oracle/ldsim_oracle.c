@@ -7,7 +7,7 @@
  *
  * Each function cites the reference lines it follows (paths relative to /root/reference).
  * Pinned against golden vectors generated from the reference's own source
- * (oracle/gen_golden.py -> tests/golden/*.npz; checked by tests/test_oracle_golden.py).
+ * (oracle/gen_golden.py writes the .npz files under tests/golden; checked by tests/test_oracle_golden.py).
  *
  * The only structural liberty taken: in o_tracks_current the tick-independent charge
  * rho(x,y,z)*dV is evaluated once per sample point and reused for every tick (the reference
