@@ -118,6 +118,18 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * "debug_phases" (timing tools only, tools/phase_timing*.py: bit mask that drops phases of the tracks_current kernels;
  * results are wrong unless it is 15, the default).  An unknown name returns LDSIM_EINVAL. */
 int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
+/* Per-pixel discrimination thresholds and gains of the fused chain -- the reference driver's
+ * pixel_thresholds_lut[unique_pix] (cli/simulate_pixels.py:1079-1084) and pixel_gains_lut[unique_pix] (:1097-1100),
+ * CudaDict lookups of util/cuda_dict.py:49-53 loaded from an .npz with keys / values / default (:82-88).
+ * keys[n] are pixel ids (unique), values[n] their entries, every other pixel id gets default_value; keys outside the
+ * current pixel geometry can never be looked up and are skipped.  Held as a dense table over
+ * n_pixels[0]*n_pixels[1]*n_tpc ids: set the constants first, and set the tables again after a change of geometry
+ * (ldsim_charge_chain returns LDSIM_ESTATE otherwise).  Without a table the chain uses DISCRIMINATION_THRESHOLD*e and
+ * GAIN*mV/e.  The stage functions ldsim_get_adc_values / ldsim_digitize take their arrays from the caller as before. */
+int ldsim_set_pixel_thresholds(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n,
+                               double default_value);
+int ldsim_set_pixel_gains(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n, double default_value);
+int ldsim_clear_pixel_tables(ldsim_ctx* ctx);
 int ldsim_synchronize(ldsim_ctx* ctx);
 
 /* ---- (1) stage-by-stage, host buffers ---------------------------------------------------------- */

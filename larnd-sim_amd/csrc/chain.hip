@@ -76,6 +76,12 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   ctx->chain_hits = 0;
   ctx->want_fractions = want_fractions;
   ctx->ms_current = ctx->ms_adc = ctx->ms_total = 0;
+  // per-pixel threshold / gain tables are dense over one pixel geometry: refuse another one before any work is launched
+  const bool tables_fit = ctx->pix_table_n == (int64_t)h.n_pixels[0] * h.n_pixels[1] * h.n_tpc;
+  if (!tables_fit && (ctx->d_pix_thr || ctx->d_pix_gain)) {
+    ldsim_set_error("pixel threshold/gain tables were set for another pixel geometry: set them again after set_consts");
+    return LDSIM_ESTATE;
+  }
   if (n == 0) return 0;
   const int A = h.max_adc_values, M = h.max_tracks_per_pixel;
   hipStream_t st = ctx->stream;
@@ -292,6 +298,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   F.batch_first = d_first_b;
   F.batch0 = batch0;
   F.threshold = h.discrimination_threshold * 1.0;   // DISCRIMINATION_THRESHOLD * units.e
+  F.thr_table = tables_fit ? ctx->d_pix_thr : nullptr;
+  F.gain_table = tables_fit ? ctx->d_pix_gain : nullptr;
   F.time_padding = 0.0;                             // cli/simulate_pixels.py:1092
   F.adc_list = (double*)ctx->scratch[SB_ADC].p;
   F.adc_ticks = (double*)ctx->scratch[SB_TICKS].p;

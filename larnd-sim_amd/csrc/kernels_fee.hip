@@ -200,12 +200,13 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   __syncthreads();
   // ---- trigger scan on wave 0 ----------------------------------------------------------------------------------------
   if (wv == 0) {
-    int nh = adc_scan(c, S, NT, F.threshold, F.time_padding, lane, hits, wtap, ntap);
+    const double thr = F.thr_table ? F.thr_table[F.upix[u]] : F.threshold;
+    int nh = adc_scan(c, S, NT, thr, F.time_padding, lane, hits, wtap, ntap);
     if (lane == 0) s_nh = nh;
   }
   __syncthreads();
   const int nh = s_nh;
-  const double gain = c->gain * (1e-3 * (1e-6 * 1.0)) / 1.0;   // GAIN * mV / e
+  const double gain = F.gain_table ? F.gain_table[F.upix[u]] : c->gain * (1e-3 * (1e-6 * 1.0)) / 1.0;   // GAIN * mV / e
   for (int h = tid; h < A; h += FEE_THREADS) {
     double q = h < nh ? hits[h].q : 0.0;
     F.adc_list[u * A + h] = q;

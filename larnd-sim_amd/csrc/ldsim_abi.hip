@@ -134,7 +134,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
-                  ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p};
+                  ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p,  ctx->d_pix_thr, ctx->d_pix_gain};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : ctx->scratch)
@@ -165,6 +165,52 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     ldsim_set_error("unknown option %s", name);
     return LDSIM_EINVAL;
   }
+  return 0;
+}
+
+// dense table over all pixel ids of the current geometry: the reference's CudaDict lookup with its default
+static int set_pixel_table(ldsim_ctx* ctx, double** slot, const int32_t* keys, const double* values, int64_t n,
+                           double default_value) {
+  NEED(ctx && n >= 0 && (n == 0 || (keys && values)), "bad pixel table");
+  HIPCHK(hipSetDevice(ctx->device));
+  const LdsimConsts& h = ctx->h_consts;
+  const int64_t n_ids = (int64_t)h.n_pixels[0] * h.n_pixels[1] * h.n_tpc;
+  NEED(n_ids > 0, "pixel geometry not set");
+  if (ctx->pix_table_n != n_ids) {        // tables of another geometry cannot be mixed with this one
+    if (ctx->d_pix_thr) (void)hipFree(ctx->d_pix_thr);
+    if (ctx->d_pix_gain) (void)hipFree(ctx->d_pix_gain);
+    ctx->d_pix_thr = ctx->d_pix_gain = nullptr;
+    ctx->pix_table_n = n_ids;
+  }
+  std::vector<double> tab((size_t)n_ids, default_value);
+  for (int64_t i = 0; i < n; i++)
+    if (keys[i] >= 0 && keys[i] < n_ids) tab[(size_t)keys[i]] = values[i];   // other keys can never be looked up
+  if (!*slot) HIPCHK(hipMalloc((void**)slot, (size_t)n_ids * sizeof(double)));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(*slot, tab.data(), (size_t)n_ids * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ldsim_set_pixel_thresholds(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n,
+                                          double default_value) {
+  NEED(ctx, "null ctx");
+  return set_pixel_table(ctx, &ctx->d_pix_thr, keys, values, n, default_value);
+}
+
+extern "C" int ldsim_set_pixel_gains(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n,
+                                     double default_value) {
+  NEED(ctx, "null ctx");
+  return set_pixel_table(ctx, &ctx->d_pix_gain, keys, values, n, default_value);
+}
+
+extern "C" int ldsim_clear_pixel_tables(ldsim_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_pix_thr) (void)hipFree(ctx->d_pix_thr);
+  if (ctx->d_pix_gain) (void)hipFree(ctx->d_pix_gain);
+  ctx->d_pix_thr = ctx->d_pix_gain = nullptr;
+  ctx->pix_table_n = 0;
   return 0;
 }
 

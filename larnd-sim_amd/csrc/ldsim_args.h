@@ -44,6 +44,8 @@ struct FeeArgs {
   const int32_t* batch_first; // [n_batches] first relative segment index of each batch
   int32_t batch0;
   double threshold;
+  const double* thr_table;    // [n_pixel_ids] per-pixel thresholds (cli/simulate_pixels.py:1079-1084) or NULL -> threshold
+  const double* gain_table;   // [n_pixel_ids] per-pixel gains (:1097-1100) or NULL -> GAIN * mV / e
   double time_padding;
   // outputs
   double* adc_list;           // [U][A]

@@ -89,6 +89,10 @@ struct ldsim_ctx {
   double* d_resp = nullptr;
   int32_t ni = 0, nj = 0, nk = 0;
   int32_t resp_k_first = 0, resp_k_last = -1;  // support of the table over all cells (exact zeros outside)
+  // per-pixel discrimination thresholds / gains of the fused chain: dense tables indexed by pixel id (NULL = constant)
+  double* d_pix_thr = nullptr;
+  double* d_pix_gain = nullptr;
+  int64_t pix_table_n = 0;      // n_pixels[0] * n_pixels[1] * n_tpc the tables were built for
   // light
   double* d_eff = nullptr;
   int32_t* d_ch2tpc = nullptr;

@@ -17,6 +17,20 @@ def digitize(integral_list, gain=None):
     return out
 
 
+def load_pixel_table(filename):
+    """(keys i32, values f64, default) of a pixel thresholds / gains file -- what the reference's ``CudaDict.load``
+    reads (util/cuda_dict.py:82-88): an .npz with ``keys`` (pixel ids), ``values`` and ``default``."""
+    with np.load(filename) as data:
+        keys = np.ascontiguousarray(data["keys"], dtype=np.int32).ravel()
+        values = np.ascontiguousarray(data["values"], dtype=np.float64).ravel()
+        default = float(np.asarray(data["default"]).ravel()[0])
+    if keys.shape != values.shape:
+        raise ValueError(f"{filename}: keys and values differ in length")
+    if np.unique(keys).size != keys.size:
+        raise ValueError(f"{filename}: keys must be unique")
+    return keys, values, default
+
+
 @kernel
 def get_adc_values(pixels_signals, pixels_signals_tracks, time_ticks, adc_list, adc_ticks_list, time_padding,
                    rng_states, current_fractions, pixel_thresholds):

@@ -27,6 +27,7 @@ _ctx_device = None
 EXPORTS = [
     "ldsim_last_error", "ldsim_abi_version", "ldsim_device_count", "ldsim_ctx_create", "ldsim_ctx_destroy",
     "ldsim_set_consts", "ldsim_set_response", "ldsim_set_light_channels", "ldsim_set_light_lut", "ldsim_set_option",
+    "ldsim_set_pixel_thresholds", "ldsim_set_pixel_gains", "ldsim_clear_pixel_tables",
     "ldsim_synchronize", "ldsim_quench", "ldsim_drift", "ldsim_max_pixels", "ldsim_get_pixels",
     "ldsim_time_intervals", "ldsim_tracks_current", "ldsim_track_pixel_map", "ldsim_sum_pixel_signals",
     "ldsim_get_adc_values", "ldsim_digitize", "ldsim_light_incidence", "ldsim_sum_light_signals",
@@ -62,9 +63,19 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_consts_bytes = None
+_consts_generation = 0
+
+
+def consts_generation():
+    """Advances every time the constants frozen in the process-wide ctx actually change.  A ChargeChain freezes them once
+    and remembers this number, so a second chain built under another configuration cannot swap them under it silently."""
+    return _consts_generation
+
+
 def context(device=None, refresh_consts=True, noise_zero=False):
     """The process-wide ldsim_ctx (created on first use); constants re-frozen from ``consts`` each call."""
-    global _ctx, _ctx_device
+    global _ctx, _ctx_device, _consts_bytes, _consts_generation
     lib = load()
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) if _ctx is None else _ctx_device
@@ -75,8 +86,11 @@ def context(device=None, refresh_consts=True, noise_zero=False):
         h = C.c_void_p()
         check(lib.ldsim_ctx_create(C.c_int(device), C.byref(c), C.byref(h)))
         _ctx, _ctx_device = h, device
+        _consts_bytes, _consts_generation = bytes(c), _consts_generation + 1
     elif refresh_consts:
         check(lib.ldsim_set_consts(_ctx, C.byref(c)))
+        if bytes(c) != _consts_bytes:
+            _consts_bytes, _consts_generation = bytes(c), _consts_generation + 1
     return _ctx
 
 

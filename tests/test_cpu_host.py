@@ -131,6 +131,23 @@ def test_chunk_ranges_cut_only_at_batch_boundaries():
     assert batching.chunk_ranges(bid[:0], 10) == []
 
 
+def test_load_pixel_table_reads_the_reference_format(tmp_path):
+    """Pixel thresholds / gains files are what the reference's CudaDict.load reads (util/cuda_dict.py:82-88):
+    an .npz with keys, values, default."""
+    from larndsim_amd import fee
+    f = tmp_path / "thr.npz"
+    np.savez(f, keys=np.array([7, 3, 900001]), values=np.array([1.5e3, 2.5e3, 9.0]), default=np.array([4.2e3]))
+    keys, values, default = fee.load_pixel_table(str(f))
+    assert keys.dtype == np.int32 and values.dtype == np.float64
+    assert keys.tolist() == [7, 3, 900001] and values.tolist() == [1.5e3, 2.5e3, 9.0] and default == 4.2e3
+    np.savez(tmp_path / "dup.npz", keys=np.array([1, 1]), values=np.array([1.0, 2.0]), default=np.array([0.0]))
+    with pytest.raises(ValueError, match="unique"):
+        fee.load_pixel_table(str(tmp_path / "dup.npz"))
+    np.savez(tmp_path / "len.npz", keys=np.array([1, 2]), values=np.array([1.0]), default=np.array([0.0]))
+    with pytest.raises(ValueError, match="length"):
+        fee.load_pixel_table(str(tmp_path / "len.npz"))
+
+
 def test_synthetic_inputs_are_deterministic_and_in_schema():
     consts.load_snapshot("module0")
     a = synth.make_segments(3000, seed=20241016 + 2)

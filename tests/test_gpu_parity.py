@@ -233,7 +233,7 @@ def test_fused_chain_golden():
     ch.upload(r, np.zeros(len(r), dtype=np.int32))
     for name in ("default", "low"):
         consts.detector.DISCRIMINATION_THRESHOLD = float(g[f"threshold_{name}"])
-        ch.ctx = lib.context()
+        ch.refresh_constants()
         st = ch.run(0, len(r), want_fractions=True)
         out = ch.download()
         assert np.array_equal(out["unique_pix"], g["unique_pix"])
@@ -249,7 +249,9 @@ def test_fused_chain_golden():
         assert st.n_unique == len(g["unique_pix"]) and st.max_length == int(g["max_length"])
 
 
-def _oracle_chain(seg, response):
+def _oracle_chain(seg, response, thr_of_pixel=None, gain_of_pixel=None):
+    """Reference dataflow on the oracle; `thr_of_pixel` / `gain_of_pixel` are dense arrays over pixel ids standing for
+    the driver's pixel_thresholds_lut[unique_pix] / pixel_gains_lut[unique_pix] (cli/simulate_pixels.py:1079-1100)."""
     ref = seg.copy()
     O.quench(ref, consts.physics.BIRKS)
     O.drift(ref)
@@ -264,8 +266,11 @@ def _oracle_chain(seg, response):
     tpm = O.track_pixel_map(upix, neigh, nrad, int(nrad.max()) + 1, consts.sim.MAX_TRACKS_PER_PIXEL)
     ps, pts, ovf = O.sum_pixel_signals(sig, starts, pim, tpm, len(upix))
     tt = np.linspace(0, consts.detector.TIME_INTERVAL[1], ps.shape[1] + 1)
-    adc, ticks, frac = O.get_adc_values(ps, pts, tt, np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD))
-    return dict(unique_pix=upix, tpm=tpm, adc=adc, ticks=ticks, frac=frac, digit=O.digitize(adc), ref=ref)
+    thr = (np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD) if thr_of_pixel is None
+           else np.ascontiguousarray(thr_of_pixel[upix]))
+    adc, ticks, frac = O.get_adc_values(ps, pts, tt, thr)
+    gain = None if gain_of_pixel is None else gain_of_pixel[upix][:, None] * np.ones((1, adc.shape[1]))
+    return dict(unique_pix=upix, tpm=tpm, adc=adc, ticks=ticks, frac=frac, digit=O.digitize(adc, gain), ref=ref)
 
 
 @pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("2x2_no_modvar", "dense"), ("ndlar", "golden")])
@@ -298,6 +303,76 @@ def test_fused_chain_vs_oracle_two_batches(cfg, kind):
         assert np.array_equal(out["adc_digit"][m], o["digit"])
         hit = o["adc"] != 0
         np.testing.assert_allclose(out["current_fractions"][m][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("2x2_no_modvar", "dense")])
+def test_fused_chain_pixel_thresholds_and_gains_vs_oracle(cfg, kind):
+    """per-pixel discrimination thresholds and gains (the driver's CudaDict lookups with a default,
+    cli/simulate_pixels.py:1079-1100) in the fused chain == the oracle fed pixel_thresholds_lut[unique_pix] /
+    pixel_gains_lut[unique_pix].  Half of the pixel ids get their own value, the rest the table's default; thresholds
+    spread over 0.4-3x the nominal one so that hits appear, vanish and move."""
+    H.load_cfg(cfg)
+    seg = synth.make_segments(24, seed=23, segs_per_event=12, spill=bool(consts.sim.IS_SPILL_SIM))
+    if consts.sim.IS_SPILL_SIM:
+        loc = seg["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
+        for f in ("t0", "t0_start", "t0_end"):
+            seg[f] = seg[f] - loc * consts.sim.SPILL_PERIOD
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    resp = H.response_for(kind)
+    det = consts.detector
+    n_ids = int(det.N_PIXELS[0] * det.N_PIXELS[1] * det.TPC_BORDERS.shape[0])
+    rng = np.random.default_rng(77)
+    keys = rng.choice(n_ids, size=n_ids // 2, replace=False).astype(np.int32)
+    nominal_gain = det.GAIN * consts.units.mV / consts.units.e
+    thr_default, gain_default = 1.3 * det.DISCRIMINATION_THRESHOLD, 0.9 * nominal_gain
+    thr_vals = det.DISCRIMINATION_THRESHOLD * rng.uniform(0.4, 3.0, keys.size)
+    gain_vals = nominal_gain * rng.uniform(0.5, 1.5, keys.size)
+    thr_of_pixel = np.full(n_ids, thr_default); thr_of_pixel[keys] = thr_vals
+    gain_of_pixel = np.full(n_ids, gain_default); gain_of_pixel[keys] = gain_vals
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.run(0, len(seg), want_fractions=True)
+    plain = ch.download()
+    try:
+        # keys of another geometry can never be looked up and are skipped
+        ch.set_pixel_thresholds(np.r_[keys, np.int32(n_ids + 5)], np.r_[thr_vals, 1e30], thr_default)
+        ch.set_pixel_gains(keys, gain_vals, gain_default)
+        ch.run(0, len(seg), want_fractions=True)
+        out = ch.download()
+        # tables built for this geometry must not be applied to another one silently ...
+        H.load_cfg("ndlar" if cfg != "ndlar" else "module0")
+        with pytest.raises(lib.LdsimError, match="another pixel geometry"):
+            ChargeChain(None).run(0, len(seg))
+        # ... and that second chain froze other constants in the process-wide context: the first one must refuse to go on
+        # instead of computing with them
+        H.load_cfg(cfg)
+        with pytest.raises(lib.LdsimError, match="create a new ChargeChain"):
+            ch.run(0, len(seg))
+    finally:
+        lib.check(lib.load().ldsim_clear_pixel_tables(lib.context()))
+    assert not np.array_equal(out["adc_list"] != 0, plain["adc_list"] != 0)      # the tables did change the hits
+    assert len(table) >= 2
+    for b in range(len(table)):
+        o = _oracle_chain(seg[bid == b], resp, thr_of_pixel, gain_of_pixel)
+        m = out["batch"] == b
+        assert np.array_equal(out["unique_pix"][m], o["unique_pix"])
+        assert np.array_equal(out["adc_list"][m] != 0, o["adc"] != 0)
+        np.testing.assert_allclose(out["adc_list"][m], o["adc"], rtol=1e-5)
+        assert np.array_equal(out["adc_ticks_list"][m], o["ticks"])
+        assert np.array_equal(out["adc_digit"][m], o["digit"])
+        hit = o["adc"] != 0
+        np.testing.assert_allclose(out["current_fractions"][m][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
+    # and after clearing the tables a new chain is back on the constants
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.run(0, len(seg), want_fractions=True)
+    again = ch.download()
+    assert np.array_equal(again["unique_pix"], plain["unique_pix"])
+    assert np.array_equal(again["adc_digit"], plain["adc_digit"]) and np.array_equal(again["adc_ticks_list"], plain["adc_ticks_list"])
 
 
 @pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
@@ -641,12 +716,64 @@ def test_cli_end_to_end(tmp_path):
     ch = ChargeChain(resp)
     ch.upload(tr, bid); ch.quench_drift(); ch.run(0, len(tr), want_fractions=True)
     ref = ch.download()
-    assert np.array_equal(out["unique_pix"], ref["unique_pix"]) and np.array_equal(out["adc_list"], ref["adc_list"])
+    assert np.array_equal(out["unique_pix"], ref["unique_pix"]) and np.array_equal(out["adc_digit"], ref["adc_digit"])
+    assert np.array_equal(out["adc_ticks_list"], ref["adc_ticks_list"])
+    np.testing.assert_allclose(out["adc_list"], ref["adc_list"], rtol=1e-12, atol=0)   # not bitwise: DESIGN "Reproducibility"
     assert np.array_equal(out["event_id"], np.array([t[0] for t in table])[ref["batch"]])
     # stored un-swapped: x is the drift axis again
     by_id = {int(r["segment_id"]): r for r in seg}
     for r in out["segments"]:
         assert r["x"] == by_id[int(r["segment_id"])]["x"] and r["z"] == by_id[int(r["segment_id"])]["z"]
+
+
+def test_cli_pixel_threshold_and_gain_files(tmp_path):
+    """--pixel_thresholds_file / --pixel_gains_file (the reference's keys / values / default .npz, cli/simulate_pixels.py:
+    439-449) reach the fused chain: same result as setting the tables by hand, different from running without them, and
+    the next run without the flags is back on the constants."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sp_cli", os.path.join(repo, "larnd-sim_amd", "cli", "simulate_pixels.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    H.load_cfg("module0")
+    det = consts.detector
+    seg = synth.make_segments(40, seed=9, segs_per_event=20)
+    np.save(tmp_path / "in.npy", seg)
+    resp = synth.make_response("survey")
+    np.save(tmp_path / "resp.npy", resp)
+    n_ids = int(det.N_PIXELS[0] * det.N_PIXELS[1] * det.TPC_BORDERS.shape[0])
+    rng = np.random.default_rng(5)
+    keys = rng.choice(n_ids, size=n_ids // 3, replace=False)
+    thr = det.DISCRIMINATION_THRESHOLD * rng.uniform(0.4, 3.0, keys.size)
+    gain = det.GAIN * consts.units.mV / consts.units.e * rng.uniform(0.5, 1.5, keys.size)
+    np.savez(tmp_path / "thr.npz", keys=keys, values=thr, default=np.array([2.0 * det.DISCRIMINATION_THRESHOLD]))
+    np.savez(tmp_path / "gain.npz", keys=keys, values=gain, default=np.array([det.GAIN * consts.units.mV / consts.units.e]))
+    common = dict(config="module0", response_file=str(tmp_path / "resp.npy"))
+    with_files = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "a.npz"), pixel_thresholds_file=str(tmp_path / "thr.npz"),
+                                    pixel_gains_file=str(tmp_path / "gain.npz"), **common)
+    without = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "b.npz"), **common)
+    assert not np.array_equal(with_files["adc_digit"], without["adc_digit"])
+    H.load_cfg("module0")
+    tr = cli.prepare_tracks(seg.copy())
+    tr = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
+    bid, order, table = batching.assign_batches(tr)
+    tr, bid = np.ascontiguousarray(tr[order]), bid[order]
+    ch = ChargeChain(resp)
+    ch.upload(tr, bid); ch.quench_drift()
+    ch.run(0, len(tr), want_fractions=True)
+    plain = ch.download()
+    try:
+        ch.set_pixel_thresholds(keys, thr, 2.0 * det.DISCRIMINATION_THRESHOLD)
+        ch.set_pixel_gains(keys, gain, det.GAIN * consts.units.mV / consts.units.e)
+        ch.run(0, len(tr), want_fractions=True)
+        by_hand = ch.download()
+    finally:
+        ch.clear_pixel_tables()
+    for res, ref in ((with_files, by_hand), (without, plain)):
+        assert np.array_equal(res["unique_pix"], ref["unique_pix"]) and np.array_equal(res["adc_digit"], ref["adc_digit"])
+        assert np.array_equal(res["adc_ticks_list"], ref["adc_ticks_list"])
+        np.testing.assert_allclose(res["adc_list"], ref["adc_list"], rtol=1e-12, atol=0)
 
 
 def test_tracks_current_edge_cases_vs_oracle():
