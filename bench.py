@@ -229,7 +229,11 @@ def main():
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                                       "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},
         }
-        if not a.no_cpu_baseline:
+        if world > 1:
+            # timed on rank 0 of the single-GPU run only: at N > 1 it would keep the other ranks waiting at the barrier
+            out["cpu_baseline"] = {"value": None, "unit": "segments/s", "cores": 0, "kind": "port",
+                                   "sample": "timed in the 1-GPU run only"}
+        elif not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(response)
             except Exception as e:      # the baseline is reported, never required for the GPU number
