@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 1
+#define LDSIM_ABI_VERSION 2
 
 /* error codes */
 #define LDSIM_OK 0
@@ -87,6 +87,12 @@ typedef struct {
   int32_t light_trig_mode, enable_lut_smearing;
   int32_t n_op_channel, max_mc_truth_ids;
   double light_tick_size, mc_truth_threshold;
+  /* light waveform response (ABI 2): scintillation_model (light_sim.py:131-146), sipm_response_model (:274-300) */
+  double light_window[2];                  /* LIGHT_WINDOW: conv_ticks = ceil((w[1] - w[0]) / LIGHT_TICK_SIZE) */
+  double singlet_fraction, tau_s, tau_t;
+  double light_response_time, light_oscillation_period, impulse_tick_size;
+  int32_t sipm_response_model;             /* 0 = RLC model, 1 = measured impulse (IMPULSE_MODEL passed as an array) */
+  int32_t reserved_;
 } LdsimConsts;
 
 typedef struct ldsim_ctx ldsim_ctx;

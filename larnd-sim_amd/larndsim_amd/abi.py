@@ -39,6 +39,9 @@ class LdsimConsts(C.Structure):
         ("light_trig_mode", C.c_int32), ("enable_lut_smearing", C.c_int32),
         ("n_op_channel", C.c_int32), ("max_mc_truth_ids", C.c_int32),
         ("light_tick_size", C.c_double), ("mc_truth_threshold", C.c_double),
+        ("light_window", C.c_double * 2), ("singlet_fraction", C.c_double), ("tau_s", C.c_double), ("tau_t", C.c_double),
+        ("light_response_time", C.c_double), ("light_oscillation_period", C.c_double),
+        ("impulse_tick_size", C.c_double), ("sipm_response_model", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -47,6 +50,9 @@ class LdsimChainStats(C.Structure):
                 ("n_batches", C.c_int64), ("n_overflow", C.c_int64),
                 ("max_active", C.c_int32), ("max_neigh", C.c_int32), ("max_length", C.c_int32),
                 ("n_ambiguous", C.c_int32), ("n_dfma", C.c_int64), ("n_fallback", C.c_int64), ("n_samples", C.c_int64), ("n_wbuf", C.c_int64)]
+
+
+ABI_VERSION = 2      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):
@@ -85,4 +91,8 @@ def pack_consts(noise_zero=False):
     c.light_trig_mode, c.enable_lut_smearing = l.LIGHT_TRIG_MODE, int(bool(l.ENABLE_LUT_SMEARING))
     c.n_op_channel, c.max_mc_truth_ids = int(l.N_OP_CHANNEL), int(s.MAX_MC_TRUTH_IDS)
     c.light_tick_size, c.mc_truth_threshold = l.LIGHT_TICK_SIZE, s.MC_TRUTH_THRESHOLD
+    c.light_window[0], c.light_window[1] = float(l.LIGHT_WINDOW[0]), float(l.LIGHT_WINDOW[1])
+    c.singlet_fraction, c.tau_s, c.tau_t = l.SINGLET_FRACTION, l.TAU_S, l.TAU_T
+    c.light_response_time, c.light_oscillation_period = l.LIGHT_RESPONSE_TIME, l.LIGHT_OSCILLATION_PERIOD
+    c.impulse_tick_size, c.sipm_response_model = l.IMPULSE_TICK_SIZE, int(l.SIPM_RESPONSE_MODEL)
     return c

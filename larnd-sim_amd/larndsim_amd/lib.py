@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from . import consts
-from .abi import LdsimChainStats, LdsimConsts, LdsimTrackLayout, pack_consts
+from .abi import ABI_VERSION, LdsimChainStats, LdsimConsts, LdsimTrackLayout, pack_consts
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldsim_hip.so")
@@ -47,6 +47,10 @@ def load():
         _lib.ldsim_last_error.restype = C.c_char_p
         for name in EXPORTS:
             getattr(_lib, name)   # fail loudly on a missing symbol
+        if int(_lib.ldsim_abi_version()) != ABI_VERSION:
+            v, _lib = int(_lib.ldsim_abi_version()), None
+            raise LdsimError(f"{LIB_PATH} has ABI version {v}, this package expects {ABI_VERSION}: rebuild it "
+                             "(make -C larnd-sim_amd/csrc)")
     return _lib
 
 

@@ -19,7 +19,7 @@ Faithfulness rules (Numba types arithmetic as f64; NumPy-2 scalars do not):
   * between stages the mutated float fields are rounded through f4 (the HDF5 schema);
   * FEE noise constants are 0 (the Numba RNG stream is third-party and unpinned).
 
-Usage:  python oracle/gen_golden.py [--sets consts,qd,pixels,chain,sampled,light] [--jobs 8]
+Usage:  python oracle/gen_golden.py [--sets consts,qd,pixels,chain,sampled,light,light_response] [--jobs 8]
 """
 import argparse
 import importlib
@@ -535,6 +535,59 @@ def gen_light():
               "sum", float(out_inc.sum()))
 
 
+def gen_light_response():
+    """light_sim.calc_scintillation_effect (:148-184) and calc_light_detector_response (:303-337) on small arrays.
+    Inputs are f8 mirrors holding f4 values (Numba promotes f4 x float to f64, NumPy 2 does not), outputs are f4 so
+    that every `+=` rounds like the real kernel's store.  LIGHT_WINDOW is shortened (the functions read it at call
+    time) so that the lower bound max(itick - conv_ticks, 0) is exercised without a 9000-tick pure-Python loop."""
+    cases = (("module0", 61, dict(LIGHT_WINDOW=(1.0, 1.4), SIPM_RESPONSE_MODEL=0)),
+             ("2x2_no_modvar", 62, dict(LIGHT_WINDOW=(0.0, 0.25), SIPM_RESPONSE_MODEL=1, IMPULSE_TICK_SIZE=0.0025)))
+    for cfg, seed, over in cases:
+        ref = Ref(cfg)
+        light, sim = ref.light, ref.sim
+        rng = np.random.default_rng(seed)
+        D, T, M = 6, 1300, 3
+        for k, v in over.items():
+            setattr(light, k, v)
+        light.LIGHT_GAIN = -np.linspace(1.0, 3.5, light.N_OP_CHANNEL)          # row-indexed by the kernel: make rows differ
+        if light.SIPM_RESPONSE_MODEL == 1:
+            tt = np.arange(60) * light.IMPULSE_TICK_SIZE
+            light.IMPULSE_MODEL = np.exp(-tt / 0.03) * np.sin(tt / 0.02)       # synthetic measured impulse
+        conv_ticks = int(np.ceil((light.LIGHT_WINDOW[1] - light.LIGHT_WINDOW[0]) / light.LIGHT_TICK_SIZE))
+        assert conv_ticks < T
+        # sparse photon arrivals with a dense burst, f4 values
+        inc = np.zeros((D, T), dtype='f4')
+        hits = rng.random((D, T)) < 0.03
+        inc[hits] = rng.uniform(0.5, 400.0, hits.sum()).astype('f4')
+        inc[:, 200:230] = rng.uniform(1.0, 50.0, (D, 30)).astype('f4')
+        inc[D - 1] = 0                                                          # an empty channel
+        tid = np.full((D, T, M), -1, dtype='i8')
+        tph = np.zeros((D, T, M))
+        for d, t in zip(*np.nonzero(inc)):
+            k = int(rng.integers(1, M + 1))
+            tid[d, t, :k] = rng.choice(40, size=k, replace=False)
+            tph[d, t, :k] = float(inc[d, t]) * rng.dirichlet(np.ones(k))
+        grid = ((D, -(-T // 64)), (1, 64))
+        scint = np.zeros((D, T), dtype='f4')
+        s_tid = np.full((D, T, M), -1, dtype='i8'); s_tph = np.zeros((D, T, M))
+        ref.light_sim.calc_scintillation_effect[grid[0], grid[1]](inc.astype('f8'), tid, tph, scint, s_tid, s_tph)
+        # the driver feeds the Poisson-fluctuated array here (calc_stat_fluctuations, RNG); any array will do
+        disc = np.rint(scint.astype('f8') * 8).astype('f4')
+        resp = np.zeros((D, T), dtype='f4')
+        r_tid = np.full((D, T, M), -1, dtype='i8'); r_tph = np.zeros((D, T, M))
+        ref.light_sim.calc_light_detector_response[grid[0], grid[1]](disc.astype('f8'), s_tid, s_tph, resp, r_tid, r_tph)
+        np.savez_compressed(
+            os.path.join(GOLD, f"light_response_{cfg}.npz"), light_window=np.array(light.LIGHT_WINDOW),
+            sipm_response_model=light.SIPM_RESPONSE_MODEL, impulse_tick_size=light.IMPULSE_TICK_SIZE,
+            impulse_model=np.asarray(light.IMPULSE_MODEL, dtype='f8'), light_gain=light.LIGHT_GAIN,
+            mc_truth_threshold=sim.MC_TRUTH_THRESHOLD, light_sample_inc=inc, true_id=tid.astype('i4'), true_photons=tph,
+            scint=scint, scint_true_id=s_tid.astype('i4'), scint_true_photons=s_tph, disc=disc,
+            response=resp, response_true_id=r_tid.astype('i4'), response_true_photons=r_tph)
+        print("light_response", cfg, "conv_ticks", conv_ticks, "model", light.SIPM_RESPONSE_MODEL,
+              "scint sum", float(scint.sum()), "response sum", float(resp.sum()),
+              "truth slots used", int((s_tid >= 0).sum()), int((r_tid >= 0).sum()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sets", default="consts,qd,pixels,light,sampled,chain")
@@ -545,7 +598,7 @@ def main():
         return 0
     os.makedirs(GOLD, exist_ok=True)
     for s in a.sets.split(","):
-        {"consts": gen_consts, "qd": gen_qd, "pixels": gen_pixels, "light": gen_light,
+        {"consts": gen_consts, "qd": gen_qd, "pixels": gen_pixels, "light": gen_light, "light_response": gen_light_response,
          "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs)}[s]()
     return 0
 

@@ -685,3 +685,112 @@ int o_sum_light_signals(const OTrack* tr, int64_t n, const int32_t* voxel, const
     }
   return 0;
 }
+
+/* ---- light waveform response: light_sim.py:131-184 and :241-337 ------------------------------------
+ * Both kernels are one thread per (detector row, tick) adding into caller-initialised f4 arrays (zeros) and truth slots
+ * (-1 / 0), term by term in ascending jtick: the f4 store after every term is part of the result. */
+
+/* light_sim.scintillation_model (:131-146) */
+static double o_scintillation_model(int64_t time_tick, const LdsimConsts* c) {
+  const double tick = c->light_tick_size;
+  double p1 = c->singlet_fraction * exp(-(double)time_tick * tick / c->tau_s) * (1 - exp(-tick / c->tau_s));
+  double p3 = (1 - c->singlet_fraction) * exp(-(double)time_tick * tick / c->tau_t) * (1 - exp(-tick / c->tau_t));
+  return (p1 + p3) * (time_tick >= 0 ? 1.0 : 0.0);
+}
+
+/* light_sim.interp (:241-271) */
+static double o_interp(double idx, const double* arr, int64_t len, double low, double high) {
+  int64_t i0 = (int64_t)floor(idx);
+  if (i0 < 0) return low;
+  if (i0 > len - 1) return high;
+  if ((double)i0 == idx) return arr[i0];
+  if (i0 > len - 2) return high;
+  double v0 = arr[i0], v1 = arr[i0 + 1];
+  return v0 + (v1 - v0) * (idx - (double)i0);
+}
+
+/* light_sim.sipm_response_model (:274-300); idet is unused by the reference too */
+static double o_sipm_response_model(int64_t time_tick, const double* impulse_model, int64_t n_impulse,
+                                    const LdsimConsts* c) {
+  if (c->sipm_response_model == 0) {
+    double t = (double)time_tick * c->light_tick_size;
+    double impulse = (t >= 0 ? 1.0 : 0.0) * exp(-t / c->light_response_time) * sin(t / c->light_oscillation_period);
+    impulse /= c->light_oscillation_period * (c->light_response_time * c->light_response_time);
+    impulse *= c->light_oscillation_period * c->light_oscillation_period + c->light_response_time * c->light_response_time;
+    return impulse * c->light_tick_size;
+  }
+  double impulse = o_interp((double)time_tick * c->light_tick_size / c->impulse_tick_size, impulse_model, n_impulse, 0, 0);
+  impulse /= c->impulse_tick_size / c->light_tick_size;
+  return impulse;
+}
+
+static int64_t o_conv_ticks(const LdsimConsts* c) {
+  return (int64_t)ceil((c->light_window[1] - c->light_window[0]) / c->light_tick_size);
+}
+
+/* light_sim.calc_scintillation_effect (:148-184).  inc f4[D][T], truth i8/f8 [D][T][Mt] (Mt may be 0) */
+int o_scintillation_effect(const float* inc, const int64_t* tid, const double* tph, int32_t D, int32_t T, int32_t Mt,
+                           float* out, int64_t* out_tid, double* out_tph, const LdsimConsts* c) {
+  const int64_t conv = o_conv_ticks(c);
+  for (int64_t d = 0; d < D; d++)
+    for (int64_t i = 0; i < T; i++) {
+      float acc = out[d * T + i];
+      int64_t j0 = i - conv > 0 ? i - conv : 0;
+      for (int64_t j = j0; j <= i; j++) {
+        float x = inc[d * T + j];
+        if (x == 0) continue;
+        double w = o_scintillation_model(i - j, c);
+        acc = (float)((double)acc + w * (double)x);
+        for (int a = 0; a < Mt; a++) {
+          int64_t id = tid[(d * T + j) * Mt + a];
+          if (id == -1) break;
+          double ph = tph[(d * T + j) * Mt + a];
+          if (w * ph < c->mc_truth_threshold) continue;
+          for (int b = 0; b < Mt; b++) {
+            int64_t* slot = &out_tid[(d * T + i) * Mt + b];
+            if (*slot == id || *slot == -1) {
+              *slot = id;
+              out_tph[(d * T + i) * Mt + b] += w * ph;
+              break;
+            }
+          }
+        }
+      }
+      out[d * T + i] = acc;
+    }
+  return 0;
+}
+
+/* light_sim.calc_light_detector_response (:303-337).  light_gain is indexed by the ROW idet of the arrays, like the
+ * reference (LIGHT_GAIN[idet], not by optical channel id).  The truth part follows the reference literally, including
+ * that its slot test reads the INPUT ids at [idet, itick] (:331-333), not the output's and not at jtick. */
+int o_light_detector_response(const float* inc, const int64_t* tid, const double* tph, int32_t D, int32_t T, int32_t Mt,
+                              const double* light_gain, const double* impulse_model, int32_t n_impulse, float* out,
+                              int64_t* out_tid, double* out_tph, const LdsimConsts* c) {
+  const int64_t conv = o_conv_ticks(c);
+  for (int64_t d = 0; d < D; d++)
+    for (int64_t i = 0; i < T; i++) {
+      float acc = out[d * T + i];
+      int64_t j0 = i - conv > 0 ? i - conv : 0;
+      for (int64_t j = j0; j <= i; j++) {
+        double w = o_sipm_response_model(i - j, impulse_model, n_impulse, c);
+        acc = (float)((double)acc + light_gain[d] * w * (double)inc[d * T + j]);
+        for (int a = 0; a < Mt; a++) {
+          if (tid[(d * T + j) * Mt + a] == -1) break;
+          double ph = tph[(d * T + j) * Mt + a];
+          if (fabs(w * ph) < c->mc_truth_threshold) continue;
+          for (int b = 0; b < Mt; b++) {
+            int64_t idb = tid[(d * T + i) * Mt + b], ida = tid[(d * T + i) * Mt + a];
+            if (idb == ida || idb == -1) {
+              out_tid[(d * T + i) * Mt + b] = ida;
+              out_tph[(d * T + i) * Mt + b] += w * ph;
+              break;
+            }
+          }
+        }
+      }
+      out[d * T + i] = acc;
+    }
+  return 0;
+}
+

@@ -224,3 +224,40 @@ def sum_light_signals(tracks, voxel, track_id, n_photons_det, op_channel, lut, s
                               _p(np.ascontiguousarray(sorted_indices, dtype=np.int32)), C.c_int64(n_ticks), _p(out),
                               _p(tid), _p(tph), C.c_int(max_truth), C.byref(c))
     return out, tid[:, :, :max_truth], tph[:, :, :max_truth]
+
+
+def _light_truth(tid, tph, D, T):
+    if tid is None or tid.shape[-1] == 0:
+        return 0, None, None
+    return tid.shape[-1], np.ascontiguousarray(tid, dtype=np.int64), np.ascontiguousarray(tph, dtype=np.float64)
+
+
+def scintillation_effect(light_sample_inc, true_id=None, true_photons=None):
+    """light_sim.calc_scintillation_effect: returns (scint f4[D][T], true ids i8, true photons f8)."""
+    c = _consts()
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    D, T = inc.shape
+    Mt, tid, tph = _light_truth(true_id, true_photons, D, T)
+    out = np.zeros((D, T), dtype=np.float32)
+    otid = np.full((D, T, Mt), -1, dtype=np.int64); otph = np.zeros((D, T, Mt))
+    lib().o_scintillation_effect(_p(inc), _p(tid), _p(tph), C.c_int32(D), C.c_int32(T), C.c_int32(Mt), _p(out),
+                                 _p(otid) if Mt else None, _p(otph) if Mt else None, C.byref(c))
+    return out, otid, otph
+
+
+def light_detector_response(light_sample_inc, light_gain, impulse_model, true_id=None, true_photons=None):
+    """light_sim.calc_light_detector_response: returns (response f4[D][T], true ids i8, true photons f8)."""
+    c = _consts()
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    D, T = inc.shape
+    Mt, tid, tph = _light_truth(true_id, true_photons, D, T)
+    gain = np.ascontiguousarray(light_gain, dtype=np.float64)
+    imp = np.ascontiguousarray(impulse_model, dtype=np.float64)
+    assert gain.shape[0] >= D
+    out = np.zeros((D, T), dtype=np.float32)
+    otid = np.full((D, T, Mt), -1, dtype=np.int64); otph = np.zeros((D, T, Mt))
+    lib().o_light_detector_response(_p(inc), _p(tid), _p(tph), C.c_int32(D), C.c_int32(T), C.c_int32(Mt), _p(gain), _p(imp),
+                                    C.c_int32(imp.shape[0]), _p(out), _p(otid) if Mt else None, _p(otph) if Mt else None,
+                                    C.byref(c))
+    return out, otid, otph
+

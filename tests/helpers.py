@@ -74,3 +74,19 @@ def assert_wave_close(got, ref, rtol=1e-5, atol_peak=1e-7, what=""):
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: {bad.sum()} values out of tolerance; worst at {i}: got {got[i]!r} "
                              f"ref {ref[i]!r} peak {peak[i[:-1]]}")
+
+
+def load_light_response_case(cfg):
+    """Constants of a tests/golden/light_response_<cfg>.npz case (oracle/gen_golden.py gen_light_response): the
+    configuration's own constants with the window / SiPM model / gains the golden run used."""
+    load_cfg(cfg)
+    g = gold(f"light_response_{cfg}.npz")
+    l = consts.light
+    l.LIGHT_WINDOW = tuple(float(x) for x in g["light_window"])
+    l.SIPM_RESPONSE_MODEL = int(g["sipm_response_model"])
+    l.IMPULSE_TICK_SIZE = float(g["impulse_tick_size"])
+    l.IMPULSE_MODEL = np.asarray(g["impulse_model"], dtype=float)
+    l.LIGHT_GAIN = np.asarray(g["light_gain"], dtype=float)
+    consts.sim.MC_TRUTH_THRESHOLD = float(g["mc_truth_threshold"])
+    return g
+

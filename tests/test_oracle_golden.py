@@ -149,3 +149,25 @@ def test_light_golden(cfg):
     np.testing.assert_allclose(out, g["light_sample_inc"], rtol=3e-7, atol=0)
     assert np.array_equal(tid, g["true_id"])
     assert g["light_sample_inc"].sum() > 0
+
+
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_light_response_golden(cfg):
+    """light_sim.calc_scintillation_effect and calc_light_detector_response: the oracle is bit-identical
+    to the reference's own functions -- f4 waveforms (every term's f4 store included), truth ids and truth photons -- for
+    the RLC SiPM model (module0 case) and the measured-impulse model with interpolation (2x2 case)."""
+    g = H.load_light_response_case(cfg)
+    tid, tph = g["true_id"].astype(np.int64), g["true_photons"]
+    scint, s_id, s_ph = O.scintillation_effect(g["light_sample_inc"], tid, tph)
+    assert np.array_equal(scint, g["scint"]) and scint.dtype == np.float32
+    assert np.array_equal(s_id, g["scint_true_id"]) and np.array_equal(s_ph, g["scint_true_photons"])
+    assert (scint[-1] == 0).all() and scint.sum() > 0                      # the empty channel stays empty
+    resp, r_id, r_ph = O.light_detector_response(g["disc"], consts.light.LIGHT_GAIN, consts.light.IMPULSE_MODEL,
+                                                 g["scint_true_id"].astype(np.int64), g["scint_true_photons"])
+    assert np.array_equal(resp, g["response"])
+    assert np.array_equal(r_id, g["response_true_id"]) and np.array_equal(r_ph, g["response_true_photons"])
+    # without truth slots the waveforms are the same
+    assert np.array_equal(O.scintillation_effect(g["light_sample_inc"])[0], g["scint"])
+    assert np.array_equal(O.light_detector_response(g["disc"], consts.light.LIGHT_GAIN, consts.light.IMPULSE_MODEL)[0],
+                          g["response"])
+
