@@ -195,6 +195,25 @@ int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64_t n, const
                             float* light_sample_inc, int64_t* true_track_id, double* true_photons,
                             int32_t max_truth);
 
+/* Light waveform response, the two deterministic stages after the photon sum.  Arrays are [n_det][n_ticks]
+ * f4 and truth slots [n_det][n_ticks][max_truth] (i8 ids, f8 photons; max_truth may be 0 with NULL pointers).  Outputs are
+ * accumulated into: the caller pre-fills them like the driver does (zeros, ids -1; cli/simulate_pixels.py:1160-1162,
+ * 1172-1174).  Every term is added in ascending tick order with an f4 store after it, as the reference's kernels do.
+ * light_sim.calc_scintillation_effect[bpg,tpb](light_sample_inc, true_track_id, true_photons, scint, scint_true_track_id,
+ *                                              scint_true_photons)        -- larndsim/light_sim.py:148-184, model :131-146 */
+int ldsim_scintillation_effect(ldsim_ctx* ctx, const float* light_sample_inc, const int64_t* true_track_id,
+                               const double* true_photons, int32_t n_det, int32_t n_ticks, int32_t max_truth,
+                               float* scint, int64_t* scint_true_track_id, double* scint_true_photons);
+/* light_sim.calc_light_detector_response[bpg,tpb](light_sample_inc, true_track_id, true_photons, light_response,
+ *                                                 response_true_track_id, response_true_photons)
+ *                                                                         -- larndsim/light_sim.py:303-337, model :274-300
+ * light_gain[n_det] is LIGHT_GAIN indexed by array ROW like the reference (:320); impulse_model[n_impulse] is IMPULSE_MODEL,
+ * read when sipm_response_model == 1.  The truth part keeps the reference's slot test on the input ids at [idet, itick]. */
+int ldsim_light_detector_response(ldsim_ctx* ctx, const float* light_sample_inc, const int64_t* true_track_id,
+                                  const double* true_photons, int32_t n_det, int32_t n_ticks, int32_t max_truth,
+                                  const double* light_gain, const double* impulse_model, int32_t n_impulse,
+                                  float* response, int64_t* response_true_track_id, double* response_true_photons);
+
 /* ---- (2) device-resident chain ---------------------------------------------------------------------- */
 /* Upload `n` records (H2D) and unpack them into the ctx's SoA segment store.  `batch_id[i]` is the
  * reference's (event, TPC-group, sub-batch) batch of segment i (cli/simulate_pixels.py:864,902);

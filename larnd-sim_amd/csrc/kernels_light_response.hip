@@ -1,0 +1,96 @@
+// kernels_light_response.hip -- light waveform response:
+//   light_sim.calc_scintillation_effect        larndsim/light_sim.py:148-184  (weights: scintillation_model :131-146)
+//   light_sim.calc_light_detector_response     larndsim/light_sim.py:303-337  (weights: sipm_response_model :274-300)
+// Both are causal convolutions along the tick axis of one detector row:  out[d][i] += sum_{j = max(i-C,0)}^{i} w(i-j) x[d][j],
+// C = ceil((LIGHT_WINDOW[1] - LIGHT_WINDOW[0]) / LIGHT_TICK_SIZE), the output an f4 array the reference updates term by
+// term -- the f4 store after every term, in ascending j, is part of the result and is kept.  w depends on i-j only, so the
+// host tabulates it once per call with the reference's expressions (ldsim_abi.hip) and the kernels never call exp/sin.
+//
+// One thread per (row, tick), a workgroup = 256 consecutive ticks of one row.  The j range of the workgroup is walked in
+// chunks of JCHUNK: the chunk of x and the weights it can meet are staged in LDS; inside a chunk all lanes read the same
+// x[j] (broadcast) and consecutive weights (conflict-free).  Truth slots (optional) follow the reference literally.
+#include "ldsim_dev.h"
+
+#define LR_THREADS 256
+#define JCHUNK 1024
+
+template <bool RESPONSE>
+__global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
+    const float* __restrict__ inc, const int64_t* __restrict__ tid, const double* __restrict__ tph, int D, int T, int Mt,
+    const double* __restrict__ weights /* [C+1] */, int C, const double* __restrict__ gain /* [D] or NULL */,
+    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid, double* __restrict__ out_tph) {
+  __shared__ float s_x[JCHUNK];
+  __shared__ double s_w[JCHUNK + LR_THREADS];
+  const int d = blockIdx.y;
+  const int i0 = blockIdx.x * LR_THREADS;
+  const int i = i0 + threadIdx.x;
+  const bool live = i < T;
+  const int i_last = min(i0 + LR_THREADS, T) - 1;          // last tick of this workgroup
+  const int j_begin = max(i0 - C, 0);                       // first j any of its ticks can reach
+  const float* x = inc + (int64_t)d * T;
+  float acc = live ? out[(int64_t)d * T + i] : 0.f;
+  const double g = RESPONSE ? gain[d] : 1.0;
+  const int my_j0 = max(i - C, 0);
+
+  for (int jc = j_begin; jc <= i_last; jc += JCHUNK) {
+    const int nj = min(JCHUNK, i_last - jc + 1);
+    // weights this chunk can meet: n = i - j in [i0 - (jc + nj - 1), i_last - jc]
+    const int n_lo = max(i0 - (jc + nj - 1), 0), n_hi = min(i_last - jc, C);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nj; k += LR_THREADS) s_x[k] = x[jc + k];
+    for (int k = threadIdx.x; k <= n_hi - n_lo; k += LR_THREADS) s_w[k] = weights[n_lo + k];
+    __syncthreads();
+    if (!live) continue;
+    const int ja = max(jc, my_j0), jb = min(jc + nj - 1, i);
+    for (int j = ja; j <= jb; j++) {
+      const float xv = s_x[j - jc];
+      if (!RESPONSE && xv == 0.f) continue;                                     // light_sim.py:166-167
+      const double w = s_w[(i - j) - n_lo];
+      if (RESPONSE) acc = (float)((double)acc + g * w * (double)xv);            // :320  LIGHT_GAIN[idet] * tick_weight * x
+      else acc = (float)((double)acc + w * (double)xv);                         // :169
+      if (Mt > 0) {
+        const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
+        for (int a = 0; a < Mt; a++) {
+          if (tid[src + a] == -1) break;
+          const double ph = tph[src + a];
+          if (RESPONSE ? (fabs(w * ph) < truth_threshold) : (w * ph < truth_threshold)) continue;
+          for (int b = 0; b < Mt; b++) {
+            if (RESPONSE) {
+              // :331-335 literally: the slot test reads the INPUT ids at [idet, itick], not the output's
+              const int64_t idb = tid[dst + b], ida = tid[dst + a];
+              if (idb == ida || idb == -1) {
+                out_tid[dst + b] = ida;
+                out_tph[dst + b] += w * ph;
+                break;
+              }
+            } else {
+              const int64_t id = tid[src + a];
+              if (out_tid[dst + b] == id || out_tid[dst + b] == -1) {           // :180-183
+                out_tid[dst + b] = id;
+                out_tph[dst + b] += w * ph;
+                break;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (live) out[(int64_t)d * T + i] = acc;
+}
+
+extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid,
+                                       const double* tph, int D, int T, int Mt, const double* weights, int C,
+                                       const double* gain, float* out, int64_t* out_tid, double* out_tph) {
+  if (D <= 0 || T <= 0) return 0;
+  dim3 grid((unsigned)((T + LR_THREADS - 1) / LR_THREADS), (unsigned)D), block(LR_THREADS);
+  const double thr = ctx->h_consts.mc_truth_threshold;
+  if (response)
+    hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain, thr,
+                       out, out_tid, out_tph);
+  else
+    hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain,
+                       thr, out, out_tid, out_tph);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -614,6 +614,115 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
   return 0;
 }
 
+// ---- light waveform response: weight tables on the host, with the reference's expressions -----------------------------
+int light_response_launch(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid, const double* tph, int D,
+                          int T, int Mt, const double* weights, int C, const double* gain, float* out, int64_t* out_tid,
+                          double* out_tph);
+
+static int64_t conv_ticks(const LdsimConsts& h) {   // light_sim.py:160 / :315
+  return (int64_t)ceil((h.light_window[1] - h.light_window[0]) / h.light_tick_size);
+}
+
+// light_sim.scintillation_model(time_tick), :131-146
+static double scintillation_model(int64_t n, const LdsimConsts& h) {
+  const double tick = h.light_tick_size;
+  double p1 = h.singlet_fraction * exp(-(double)n * tick / h.tau_s) * (1 - exp(-tick / h.tau_s));
+  double p3 = (1 - h.singlet_fraction) * exp(-(double)n * tick / h.tau_t) * (1 - exp(-tick / h.tau_t));
+  return (p1 + p3) * (n >= 0 ? 1.0 : 0.0);
+}
+
+// light_sim.interp(idx, arr, low, high), :241-271
+static double interp_model(double idx, const double* arr, int64_t len, double low, double high) {
+  int64_t i0 = (int64_t)floor(idx);
+  if (i0 < 0) return low;
+  if (i0 > len - 1) return high;
+  if ((double)i0 == idx) return arr[i0];
+  if (i0 > len - 2) return high;
+  return arr[i0] + (arr[i0 + 1] - arr[i0]) * (idx - (double)i0);
+}
+
+// light_sim.sipm_response_model(idet, time_tick), :274-300 (idet is unused there as well)
+static double sipm_response_model(int64_t n, const double* impulse, int64_t n_impulse, const LdsimConsts& h) {
+  if (h.sipm_response_model == 0) {
+    double t = (double)n * h.light_tick_size;
+    double v = (t >= 0 ? 1.0 : 0.0) * exp(-t / h.light_response_time) * sin(t / h.light_oscillation_period);
+    v /= h.light_oscillation_period * (h.light_response_time * h.light_response_time);
+    v *= h.light_oscillation_period * h.light_oscillation_period + h.light_response_time * h.light_response_time;
+    return v * h.light_tick_size;
+  }
+  double v = interp_model((double)n * h.light_tick_size / h.impulse_tick_size, impulse, n_impulse, 0, 0);
+  v /= h.impulse_tick_size / h.light_tick_size;
+  return v;
+}
+
+static int light_response_stage(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid, const double* tph,
+                                int32_t n_det, int32_t n_ticks, int32_t max_truth, const std::vector<double>& weights,
+                                const double* gain, float* out, int64_t* out_tid, double* out_tph) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bo = (size_t)n_det * n_ticks, bt = bo * (size_t)max_truth;
+  Tmp dinc, dtid, dtph, dw, dg, dout, dotid, dotph;
+  CK(dinc.alloc(bo * 4 + 8)); CK(dout.alloc(bo * 4 + 8)); CK(dw.alloc(weights.size() * 8));
+  CK(dtid.alloc(bt * 8 + 8)); CK(dtph.alloc(bt * 8 + 8)); CK(dotid.alloc(bt * 8 + 8)); CK(dotph.alloc(bt * 8 + 8));
+  CK(dg.alloc((size_t)n_det * 8 + 8));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(dinc.p, inc, bo * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dout.p, out, bo * 4, hipMemcpyHostToDevice, st));          // accumulates into the caller's array
+  HIPCHK(hipMemcpyAsync(dw.p, weights.data(), weights.size() * 8, hipMemcpyHostToDevice, st));
+  if (gain) HIPCHK(hipMemcpyAsync(dg.p, gain, (size_t)n_det * 8, hipMemcpyHostToDevice, st));
+  if (max_truth) {
+    HIPCHK(hipMemcpyAsync(dtid.p, tid, bt * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dtph.p, tph, bt * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dotid.p, out_tid, bt * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dotph.p, out_tph, bt * 8, hipMemcpyHostToDevice, st));
+  }
+  CK(light_response_launch(ctx, response, dinc.as<float>(), dtid.as<int64_t>(), dtph.as<double>(), n_det, n_ticks,
+                           max_truth, dw.as<double>(), (int)weights.size() - 1, dg.as<double>(), dout.as<float>(),
+                           dotid.as<int64_t>(), dotph.as<double>()));
+  HIPCHK(hipMemcpyAsync(out, dout.p, bo * 4, hipMemcpyDeviceToHost, st));
+  if (max_truth) {
+    HIPCHK(hipMemcpyAsync(out_tid, dotid.p, bt * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_tph, dotph.p, bt * 8, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int ldsim_scintillation_effect(ldsim_ctx* ctx, const float* light_sample_inc, const int64_t* true_track_id,
+                                          const double* true_photons, int32_t n_det, int32_t n_ticks, int32_t max_truth,
+                                          float* scint, int64_t* scint_true_track_id, double* scint_true_photons) {
+  NEED(ctx && light_sample_inc && scint && n_det >= 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
+  NEED(max_truth == 0 || (true_track_id && true_photons && scint_true_track_id && scint_true_photons),
+       "truth arrays missing");
+  const LdsimConsts& h = ctx->h_consts;
+  NEED(h.light_tick_size > 0 && h.tau_s > 0 && h.tau_t > 0, "light constants not set");
+  const int64_t C = conv_ticks(h);
+  NEED(C >= 0 && C < (1 << 24), "LIGHT_WINDOW / LIGHT_TICK_SIZE out of range");
+  std::vector<double> w((size_t)C + 1);
+  for (int64_t n = 0; n <= C; n++) w[(size_t)n] = scintillation_model(n, h);
+  return light_response_stage(ctx, false, light_sample_inc, true_track_id, true_photons, n_det, n_ticks, max_truth, w,
+                              nullptr, scint, scint_true_track_id, scint_true_photons);
+}
+
+extern "C" int ldsim_light_detector_response(ldsim_ctx* ctx, const float* light_sample_inc, const int64_t* true_track_id,
+                                             const double* true_photons, int32_t n_det, int32_t n_ticks,
+                                             int32_t max_truth, const double* light_gain, const double* impulse_model,
+                                             int32_t n_impulse, float* response, int64_t* response_true_track_id,
+                                             double* response_true_photons) {
+  NEED(ctx && light_sample_inc && response && light_gain && n_det >= 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
+  NEED(max_truth == 0 || (true_track_id && true_photons && response_true_track_id && response_true_photons),
+       "truth arrays missing");
+  const LdsimConsts& h = ctx->h_consts;
+  NEED(h.light_tick_size > 0, "light constants not set");
+  NEED(h.sipm_response_model == 0 || (h.sipm_response_model == 1 && impulse_model && n_impulse > 0 && h.impulse_tick_size > 0),
+       "SIPM_RESPONSE_MODEL 1 needs IMPULSE_MODEL and IMPULSE_TICK_SIZE");
+  const int64_t C = conv_ticks(h);
+  NEED(C >= 0 && C < (1 << 24), "LIGHT_WINDOW / LIGHT_TICK_SIZE out of range");
+  std::vector<double> w((size_t)C + 1);
+  for (int64_t n = 0; n <= C; n++) w[(size_t)n] = sipm_response_model(n, impulse_model, n_impulse, h);
+  return light_response_stage(ctx, true, light_sample_inc, true_track_id, true_photons, n_det, n_ticks, max_truth, w,
+                              light_gain, response, response_true_track_id, response_true_photons);
+}
+
 // ---- (2) chain -------------------------------------------------------------------------------------------------------
 extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int32_t want_fractions,
                                   LdsimChainStats* stats) {

@@ -31,6 +31,7 @@ EXPORTS = [
     "ldsim_synchronize", "ldsim_quench", "ldsim_drift", "ldsim_max_pixels", "ldsim_get_pixels",
     "ldsim_time_intervals", "ldsim_tracks_current", "ldsim_track_pixel_map", "ldsim_sum_pixel_signals",
     "ldsim_get_adc_values", "ldsim_digitize", "ldsim_light_incidence", "ldsim_sum_light_signals",
+    "ldsim_scintillation_effect", "ldsim_light_detector_response",
     "ldsim_segments_upload", "ldsim_segments_download", "ldsim_segments_reset", "ldsim_dev_quench_drift", "ldsim_charge_chain",
     "ldsim_chain_download", "ldsim_chain_compact_hits", "ldsim_chain_kernel_ms", "ldsim_chain_kernel_ms_detail",
 ]

@@ -1,5 +1,6 @@
-"""Photon sum per (optical channel, tick) -- mirrors larndsim/light_sim.py sum_light_signals (:58-129) and
-get_nticks (:24-41).  The rest of the light chain (scintillation, SiPM response, triggers) is out of scope."""
+"""Light waveforms per (optical channel, tick) -- mirrors larndsim/light_sim.py: get_nticks (:24-41), sum_light_signals
+(:58-129), calc_scintillation_effect (:148-184) and calc_light_detector_response (:303-337).  The stages that draw random
+numbers (calc_stat_fluctuations, detector noise) and the trigger / digitisation stages are out of scope."""
 import ctypes as C
 
 import numpy as np
@@ -47,3 +48,58 @@ def sum_light_signals(segments, segment_voxel, segment_track_id, light_inc, op_c
     if mt:
         light_sample_inc_true_track_id[:] = tids
         light_sample_inc_true_photons[:] = tph
+
+
+def _truth(ids, photons):
+    """(max_truth, i8 ids, f8 photons) of a pair of truth arrays; (0, None, None) when there are no slots."""
+    if ids is None or ids.shape[-1] == 0:
+        return 0, None, None
+    return ids.shape[-1], np.ascontiguousarray(ids, dtype=np.int64), np.ascontiguousarray(photons, dtype=np.float64)
+
+
+@kernel
+def calc_scintillation_effect(light_sample_inc, light_sample_inc_true_track_id, light_sample_inc_true_photons,
+                              light_sample_inc_scint, light_sample_inc_scint_true_track_id,
+                              light_sample_inc_scint_true_photons):
+    """``calc_scintillation_effect[bpg, tpb](...)`` with the reference's argument order: the two-component scintillation
+    time profile convolved into ``light_sample_inc_scint`` (added to what the caller put there, like the reference)."""
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    n_det, n_ticks = inc.shape
+    mt, tid, tph = _truth(light_sample_inc_true_track_id, light_sample_inc_true_photons)
+    out = np.ascontiguousarray(light_sample_inc_scint, dtype=np.float32)
+    otid = np.ascontiguousarray(light_sample_inc_scint_true_track_id, dtype=np.int64) if mt else None
+    otph = np.ascontiguousarray(light_sample_inc_scint_true_photons, dtype=np.float64) if mt else None
+    lib.check(lib.load().ldsim_scintillation_effect(
+        lib.context(), lib.ptr(inc), lib.ptr(tid), lib.ptr(tph), C.c_int32(n_det), C.c_int32(n_ticks), C.c_int32(mt),
+        lib.ptr(out), lib.ptr(otid), lib.ptr(otph)))
+    light_sample_inc_scint[:] = out
+    if mt:
+        light_sample_inc_scint_true_track_id[:] = otid
+        light_sample_inc_scint_true_photons[:] = otph
+
+
+@kernel
+def calc_light_detector_response(light_sample_inc, light_sample_inc_true_track_id, light_sample_inc_true_photons,
+                                 light_response, light_response_true_track_id, light_response_true_photons):
+    """``calc_light_detector_response[bpg, tpb](...)`` with the reference's argument order: SiPM response model
+    (``consts.light.SIPM_RESPONSE_MODEL``: 0 RLC, 1 ``IMPULSE_MODEL``) times ``LIGHT_GAIN[row]`` convolved into
+    ``light_response``."""
+    light = consts.light
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    n_det, n_ticks = inc.shape
+    gain = np.ascontiguousarray(light.LIGHT_GAIN, dtype=np.float64)
+    if gain.shape[0] < n_det:
+        raise IndexError(f"LIGHT_GAIN has {gain.shape[0]} entries, the arrays have {n_det} rows")
+    imp = np.ascontiguousarray(light.IMPULSE_MODEL, dtype=np.float64)
+    mt, tid, tph = _truth(light_sample_inc_true_track_id, light_sample_inc_true_photons)
+    out = np.ascontiguousarray(light_response, dtype=np.float32)
+    otid = np.ascontiguousarray(light_response_true_track_id, dtype=np.int64) if mt else None
+    otph = np.ascontiguousarray(light_response_true_photons, dtype=np.float64) if mt else None
+    lib.check(lib.load().ldsim_light_detector_response(
+        lib.context(), lib.ptr(inc), lib.ptr(tid), lib.ptr(tph), C.c_int32(n_det), C.c_int32(n_ticks), C.c_int32(mt),
+        lib.ptr(gain), lib.ptr(imp), C.c_int32(imp.shape[0]), lib.ptr(out), lib.ptr(otid), lib.ptr(otph)))
+    light_response[:] = out
+    if mt:
+        light_response_true_track_id[:] = otid
+        light_response_true_photons[:] = otph
+

@@ -555,6 +555,63 @@ def test_chain_properties_baseline_sizes(cfg, seed_index, n):
     assert checked >= 6
 
 
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_light_response_golden(cfg):
+    """light_sim.calc_scintillation_effect / calc_light_detector_response through the C-ABI against the
+    reference's own output: the weight tables are built with the reference's expressions on the host and every term is
+    added in tick order with an f4 store, so waveforms, truth ids and truth photons are required to be bit-identical --
+    RLC SiPM model (module0 case) and measured impulse with interpolation (2x2 case), with and without truth slots."""
+    g = H.load_light_response_case(cfg)
+    inc, tid, tph = g["light_sample_inc"], g["true_id"].astype(np.int64), g["true_photons"]
+    D, T = inc.shape
+    M = tid.shape[-1]
+    grid = ((D, -(-T // 64)), (1, 64))
+    scint = np.zeros((D, T), dtype='f4')
+    s_id = np.full((D, T, M), -1, dtype='i8'); s_ph = np.zeros((D, T, M))
+    light_sim.calc_scintillation_effect[grid[0], grid[1]](inc, tid, tph, scint, s_id, s_ph)
+    assert np.array_equal(scint, g["scint"])
+    assert np.array_equal(s_id, g["scint_true_id"]) and np.array_equal(s_ph, g["scint_true_photons"])
+    resp = np.zeros((D, T), dtype='f4')
+    r_id = np.full((D, T, M), -1, dtype='i8'); r_ph = np.zeros((D, T, M))
+    light_sim.calc_light_detector_response[grid[0], grid[1]](g["disc"], s_id, s_ph, resp, r_id, r_ph)
+    assert np.array_equal(resp, g["response"])
+    assert np.array_equal(r_id, g["response_true_id"]) and np.array_equal(r_ph, g["response_true_photons"])
+    # no truth slots: same waveforms; and the kernels add to what the caller put in the output (the driver passes zeros)
+    none_i, none_p = np.zeros((D, T, 0), dtype='i8'), np.zeros((D, T, 0))
+    s2 = np.ones((D, T), dtype='f4')
+    light_sim.calc_scintillation_effect[grid[0], grid[1]](inc, none_i, none_p, s2, none_i, none_p)
+    assert not np.array_equal(s2, g["scint"]) and (s2[-1] == 1).all()            # the empty channel keeps the caller's 1
+    s3 = np.zeros((D, T), dtype='f4')
+    light_sim.calc_scintillation_effect[grid[0], grid[1]](inc, none_i, none_p, s3, none_i, none_p)
+    r3 = np.zeros((D, T), dtype='f4')
+    light_sim.calc_light_detector_response[grid[0], grid[1]](g["disc"], none_i, none_p, r3, none_i, none_p)
+    assert np.array_equal(s3, g["scint"]) and np.array_equal(r3, g["response"])
+
+
+def test_light_response_full_window_vs_oracle():
+    """The configurations' real convolution windows (module0: 9000 ticks over an 11000-tick waveform) on a few channels
+    against the oracle: covers the multi-chunk walk of the kernel and the lower bound max(itick - conv_ticks, 0)."""
+    H.load_cfg("module0")
+    light = consts.light
+    assert light.SIPM_RESPONSE_MODEL == 1 and light.IMPULSE_MODEL.shape[0] > 2   # the reference's measured impulse
+    rng = np.random.default_rng(8)
+    D, T = 3, 11000
+    inc = np.zeros((D, T), dtype='f4')
+    hit = rng.random((D, T)) < 0.002
+    inc[hit] = rng.uniform(1.0, 300.0, hit.sum()).astype('f4')
+    inc[0, :40] = 50.0
+    none_i, none_p = np.zeros((D, T, 0), dtype='i8'), np.zeros((D, T, 0))
+    grid = ((D, -(-T // 64)), (1, 64))
+    scint = np.zeros((D, T), dtype='f4')
+    light_sim.calc_scintillation_effect[grid[0], grid[1]](inc, none_i, none_p, scint, none_i, none_p)
+    ref_s = O.scintillation_effect(inc)[0]
+    assert np.array_equal(scint, ref_s) and scint[0, 9500] != 0
+    resp = np.zeros((D, T), dtype='f4')
+    light_sim.calc_light_detector_response[grid[0], grid[1]](scint, none_i, none_p, resp, none_i, none_p)
+    assert np.array_equal(resp, O.light_detector_response(scint, light.LIGHT_GAIN, light.IMPULSE_MODEL)[0])
+    assert np.abs(resp).max() > 0
+
+
 def test_light_properties_baseline_event():
     """BASELINE.json config 5's light leg (ndlar, synthetic light set-up of SURVEY §8d: 48 channels per TPC) on one full
     event: channel masking, voxel bounds, and exact linearity of the photon sum -- doubling every n_photons_det doubles
