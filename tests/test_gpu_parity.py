@@ -456,6 +456,28 @@ def test_chain_properties_full_event():
     assert st.n_overflow == 0 and st.n_batches == 2
 
 
+def test_chain_with_nothing_to_simulate():
+    """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
+    drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(64, seed=3, segs_per_event=64)
+    batching.swap_coordinates(seg)
+    for f in ("x", "x_start", "x_end"):
+        seg[f] += 1.0e4                                   # far outside every TPC box
+    bid = np.zeros(len(seg), dtype=np.int32)
+    ch = ChargeChain(synth.make_response("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    q = ch.download_segments(seg.copy())
+    assert (q["pixel_plane"] == consts.detector.DEFAULT_PLANE_INDEX).all()
+    st = ch.run(0, len(seg), want_fractions=True)
+    out = ch.download()
+    assert st.n_pairs == 0 and st.n_unique == 0 and len(out["unique_pix"]) == 0 and out["adc_list"].shape == (0, 30)
+    assert ch.compact_hits()[1] == 0
+    st = ch.run(5, 5)
+    assert st.n_segments == 0 and st.n_unique == 0 and len(ch.download()["unique_pix"]) == 0
+
+
 def _prepared_set(cfg, n, seed_index):
     """SURVEY §8d synthetic set of BASELINE config `seed_index`, in the driver's frame, batch-sorted."""
     H.load_cfg(cfg)
