@@ -43,6 +43,18 @@ def tracks_current(signals, pixels, tracks, response):
 
 
 @kernel
+def tracks_current_mc(signals, pixels, tracks, response, rng_states):
+    """The reference driver's call site (cli/simulate_pixels.py:1016) uses this Monte-Carlo estimate of the same
+    integral (detsim.py:258-348).  It draws from a Numba RNG state that all tick threads of a (segment, pixel) share, so
+    it is not reproducible even in the reference and only statistically comparable; it is not built here.  Nothing is
+    substituted silently: call ``tracks_current`` (the closed-form integral, detsim.py:351-453) at that line instead."""
+    raise NotImplementedError(
+        "detsim.tracks_current_mc is not provided: replace the call by "
+        "detsim.tracks_current[BPG, TPB](signals, neighboring_pixels, selected_tracks, response) "
+        "(deterministic integral of the same current; see INTEGRATION.md)")
+
+
+@kernel
 def get_track_pixel_map2(track_pixel_map, unique_pix, pixels, distances, max_distance):
     """``get_track_pixel_map2[bpg, tpb](track_pixel_map, unique_pix, pixels, distances, max_distance)``."""
     tpm = track_pixel_map if track_pixel_map.dtype == np.int64 and track_pixel_map.flags.c_contiguous else \

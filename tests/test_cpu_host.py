@@ -148,6 +148,13 @@ def test_load_pixel_table_reads_the_reference_format(tmp_path):
         fee.load_pixel_table(str(tmp_path / "len.npz"))
 
 
+def test_tracks_current_mc_is_refused_with_instructions():
+    """The driver's MC call site is not substituted silently: the stub says what to call instead."""
+    from larndsim_amd import detsim
+    with pytest.raises(NotImplementedError, match=r"detsim\.tracks_current\[BPG, TPB\]"):
+        detsim.tracks_current_mc[1, 64](None, None, None, None, None)
+
+
 def test_synthetic_inputs_are_deterministic_and_in_schema():
     consts.load_snapshot("module0")
     a = synth.make_segments(3000, seed=20241016 + 2)
