@@ -123,6 +123,9 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
 extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
   NEED(ctx && consts, "null argument");
   NEED(consts->n_tpc >= 0 && consts->n_tpc <= LDSIM_MAX_TPC, "n_tpc out of range");
+  // another configuration has another demand on the split path's weight pool (ndlar needs ~4x module0's): relearn it
+  // instead of keeping the high-water mark of everything this process has ever run
+  if (memcmp(&ctx->h_consts, consts, sizeof(LdsimConsts)) != 0) ctx->wbuf_learned = 0;
   ctx->h_consts = *consts;
   HIPCHK(hipMemcpyAsync(ctx->d_consts, &ctx->h_consts, sizeof(LdsimConsts), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
