@@ -456,6 +456,54 @@ def test_chain_properties_full_event():
     assert st.n_overflow == 0 and st.n_batches == 2
 
 
+def test_more_than_max_tracks_per_pixel_vs_oracle():
+    """70 short segments over the same pixels: get_track_pixel_map2 keeps the first MAX_TRACKS_PER_PIXEL = 50 in
+    (ring distance, segment index) order, sum_pixel_signals leaves the others out of the pixel sum and raises the
+    overflow flag (detsim.py:510-524, 582-607).  The fused chain (slot order from the sort, compact per-pair waveforms)
+    must keep the same 50 and sum the same charge as the oracle's literal dataflow."""
+    H.load_cfg("module0")
+    det = consts.detector
+    rng = np.random.default_rng(12)
+    n = 70
+    seg = np.zeros(n, dtype=segments_dtype)
+    b = np.sort(det.TPC_BORDERS[0], axis=-1)
+    # centre of a pixel well inside TPC 0 (TPC frame: x, y in the pixel plane, z the drift axis)
+    px, py = 40, 100
+    xc = b[0][0] + (px + 0.5) * det.PIXEL_PITCH
+    yc = b[1][0] + (py + 0.5) * det.PIXEL_PITCH
+    z0 = 0.5 * (b[2][0] + b[2][1])
+    half = 0.35 * det.PIXEL_PITCH
+    xs = xc + rng.uniform(-half, half, n); xe = xs + rng.uniform(0.02, 0.1, n) * rng.choice([-1, 1], n)
+    ys = yc + rng.uniform(-half, half, n); ye = ys + rng.uniform(-0.1, 0.1, n)
+    zs = z0 + rng.uniform(-1.0, 1.0, n); ze = zs + rng.uniform(-0.15, 0.15, n)
+    seg["x_start"], seg["x_end"], seg["y_start"], seg["y_end"], seg["z_start"], seg["z_end"] = xs, xe, ys, ye, zs, ze
+    for a in "xyz":
+        seg[a] = 0.5 * (seg[a + "_start"] + seg[a + "_end"])
+    seg["dx"] = np.sqrt((xe - xs) ** 2 + (ye - ys) ** 2 + (ze - zs) ** 2)
+    seg["dEdx"] = 2.1
+    seg["dE"] = seg["dEdx"] * seg["dx"]
+    seg["segment_id"] = np.arange(n); seg["event_id"] = 0; seg["pdg_id"] = 13
+    bid = np.zeros(n, dtype=np.int32)
+    resp = synth.make_response("survey")
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    st = ch.run(0, n, want_fractions=True)
+    out = ch.download()
+    o = _oracle_chain(seg, resp)
+    assert st.n_overflow > 0 and st.max_active >= 1
+    full = (o["tpm"] >= 0).sum(axis=1) == consts.sim.MAX_TRACKS_PER_PIXEL
+    assert full.any()                                       # some pixel really filled all 50 slots
+    assert np.array_equal(out["unique_pix"], o["unique_pix"])
+    assert np.array_equal(out["track_pixel_map"], o["tpm"])
+    assert np.array_equal(out["adc_list"] != 0, o["adc"] != 0)
+    np.testing.assert_allclose(out["adc_list"], o["adc"], rtol=1e-5)
+    assert np.array_equal(out["adc_ticks_list"], o["ticks"])
+    assert np.array_equal(out["adc_digit"], o["digit"])
+    hit = o["adc"] != 0
+    np.testing.assert_allclose(out["current_fractions"][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
+
+
 def test_chain_with_nothing_to_simulate():
     """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
     drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""
