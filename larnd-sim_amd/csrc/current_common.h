@@ -2,7 +2,6 @@
 // and the weights / correlation kernel pair (kernels_split.hip).
 #pragma once
 #include "ldsim_args.h"
-#include "erfcx_table.h"
 
 #define CUR_THREADS 256
 #define NWAVE 4
@@ -153,47 +152,6 @@ __device__ __forceinline__ bool slice_valid_at(const LdsimConsts* c, double t_st
   return (t0 < time_tick) && (time_tick < t0 + c->time_window);
 }
 
-
-// ---- rho without catastrophic cancellation and with one exp on the common path ----------------------------------
-// The reference evaluates exp(b^2/4a - delta + log(factor) + log(integral)) with
-// integral ~ erf(hi) - erf(lo) (detsim.py:150-157).  Same value, restated through erfcx(x) = exp(x^2) erfc(x)
-// (piecewise degree-9 polynomials, 1 ulp, tools/gen_erfcx_table.py): for lo, hi of the same sign
-//   exp(E) (erf(hi) - erf(lo)) = exp(E - A1^2) [erfcx(A1) - exp(-(A2^2 - A1^2)) erfcx(A2)],  A1 <= A2 the magnitudes,
-// which is accurate where the literal difference cancels (checked against 40-digit arithmetic: <= 5e-14 relative).
-__device__ __forceinline__ double tab_eval(const double (*T)[ERFCX_DEG + 1], int n, double x) {
-  int i = (int)(x * 8.0);
-  i = i < n - 1 ? i : n - 1;
-  const double s = (x - (i * 0.125 + 0.0625)) * 16.0;
-  const double* c = T[i];
-  double p = c[ERFCX_DEG];
-#pragma unroll
-  for (int d = ERFCX_DEG - 1; d >= 0; d--) p = fma(p, s, c[d]);
-  return p;
-}
-__device__ __forceinline__ double erfcx_pos(double x) {   // x >= 0
-  if (x < 16.0) return tab_eval(erfcx_tab, ERFCX_N, x);
-  const double t = 1.0 / (2 * x * x);
-  double acc = 1.0, term = 1.0;
-#pragma unroll
-  for (int m = 1; m < 9; m++) {
-    term = -term * (2 * m - 1) * t;
-    acc += term;
-  }
-  return acc / (x * 1.7724538509055160273);
-}
-__device__ __forceinline__ double erf_pos(double x) { return x >= 6.0 ? 1.0 : tab_eval(erf_tab, ERF_N, x); }
-
-// exp(E) * (erf(hi) - erf(lo)),  hi > lo
-__device__ __forceinline__ double exp_erf_diff(double E, double lo, double hi) {
-  if (lo < 0 && hi > 0) return exp(E) * (erf_pos(hi) + erf_pos(-lo));
-  const double al = fabs(lo), ah = fabs(hi);
-  const double A1 = fmin(al, ah), A2 = fmax(al, ah);
-  if (A1 < 2.0) return exp(E) * (erf_pos(A2) - erf_pos(A1));
-  const double e1 = exp(E - A1 * A1);
-  const double t = (A2 - A1) * (A2 + A1);
-  const double tail = t < 45.0 ? exp(-t) * erfcx_pos(A2) : 0.0;
-  return e1 * (erfcx_pos(A1) - tail);
-}
 
 // LDS row layout: one pad double per 8*M elements so that the 8*M-element lane stride of the sliding window
 // becomes 8*M+1 doubles -> conflict-free ds_read_b64 (MI355X_MICROARCH.md, LDS banking)
