@@ -121,7 +121,7 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * demand and the launch is repeated when it was exhausted, so this only affects the first launches; setting it forgets
  * the size learned so far), "split_max_items" (validation: pairs with more weight items than this are recomputed by
  * the monolithic kernel; 0 = the built-in capacity: 512 items at TIME_SAMPLING/RESPONSE_SAMPLING = 1, 2048 at 2),
- * "debug_phases" (timing tools only, tools/phase_timing*.py: bit mask that drops phases of the tracks_current kernels;
+ * "debug_phases" (timing tools only, tools/phase_timing3.py: bit mask that drops phases of the tracks_current kernels;
  * results are wrong unless it is 15, the default).  An unknown name returns LDSIM_EINVAL. */
 int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
 /* Per-pixel discrimination thresholds and gains of the fused chain -- the reference driver's
