@@ -504,6 +504,29 @@ def test_more_than_max_tracks_per_pixel_vs_oracle():
     np.testing.assert_allclose(out["current_fractions"][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("cfg,seeds", [("module0", (0, 1, 2, 3, 4)), ("ndlar", (202, 203))])
+def test_fused_chain_fuzz_slice_vs_oracle(cfg, seeds):
+    """A slice of tools/fuzz_chain.py (the full run: 130 cases over module0 / 2x2 dense / ndlar, 3.2e4 pairs, 6e3 hits,
+    no mismatch): two events of ten segments per seed, the seed picks the flavour -- plain, short tracks, long segments
+    (several slice chunks, overflow fallback), heavily ionising (hits on neighbours, several per pixel), medium -- and
+    the fused chain must match the oracle: pixels, track map, hit slots, ticks and ADC counts exactly, charges and
+    fractions to 1e-5."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_chain", os.path.join(repo, "tools", "fuzz_chain.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    H.load_cfg(cfg)
+    resp = H.response_for("survey")
+    n_hits = 0
+    for seed in seeds:
+        problems, st, nh = fz.check_case(seed, cfg, resp)
+        assert not problems, f"seed {seed}: {problems}"
+        n_hits += nh
+    assert n_hits > 20
+
+
 def test_chain_with_nothing_to_simulate():
     """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
     drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""

@@ -1,0 +1,100 @@
+"""Differential fuzz of the fused chain against the oracle: many seeds, varied segment shapes (length, steepness, drift
+distance, energy), two events per case.  python tools/fuzz_chain.py [cfg] [n_seeds] [first_seed]
+Prints one line per failing case and a summary; exits non-zero on any mismatch."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'larnd-sim_amd')); sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..')); sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+import numpy as np
+import helpers as H
+from larndsim_amd import batching, consts, synth
+from larndsim_amd.chain import ChargeChain
+from oracle import oracle as O
+
+
+def oracle_chain(seg, response):
+    ref = seg.copy()
+    O.quench(ref, consts.physics.BIRKS); O.drift(ref)
+    nmax = O.max_pixels(ref)
+    r = int(np.ceil(ref["tran_diff"].max() * 5 / consts.detector.PIXEL_PITCH))
+    P = (2 * r + 1) * nmax + (1 + 2 * r) * r * 2
+    _, neigh, nrad, _ = O.get_pixels(ref, nmax, P, r)
+    upix = O.unique_pixels(neigh)
+    starts, T = O.time_intervals(ref)
+    sig = O.tracks_current(ref, neigh, T, response)
+    pim = O.pixel_index_map(neigh, upix)
+    tpm = O.track_pixel_map(upix, neigh, nrad, int(nrad.max()) + 1, consts.sim.MAX_TRACKS_PER_PIXEL)
+    ps, pts, _ = O.sum_pixel_signals(sig, starts, pim, tpm, len(upix))
+    tt = np.linspace(0, consts.detector.TIME_INTERVAL[1], ps.shape[1] + 1)
+    adc, ticks, frac = O.get_adc_values(ps, pts, tt, np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD))
+    return dict(unique_pix=upix, tpm=tpm, adc=adc, ticks=ticks, frac=frac, digit=O.digitize(adc))
+
+
+def make_case(seed, cfg):
+    """Two events of 10 segments; per seed a different flavour of segment shapes."""
+    rng = np.random.default_rng(1000 + seed)
+    flavour = seed % 5
+    max_len = (60.0, 3.0, 60.0, 60.0, 12.0)[flavour]
+    seg = synth.make_segments(20, seed=5000 + seed, segs_per_event=10, spill=bool(consts.sim.IS_SPILL_SIM),
+                              max_track_len=max_len)
+    if flavour == 2:                       # long segments: many slice chunks, waveforms past one tile
+        for a in ("x", "y", "z"):
+            d = seg[a + "_end"] - seg[a + "_start"]
+            seg[a + "_end"] = seg[a + "_start"] + d * rng.uniform(2.0, 8.0, len(seg)).astype('f4')
+            seg[a] = 0.5 * (seg[a + "_start"] + seg[a + "_end"])
+        seg["dx"] = np.sqrt(sum((seg[a + "_end"] - seg[a + "_start"]).astype('f8') ** 2 for a in "xyz"))
+        seg["dE"] = seg["dEdx"] * seg["dx"]
+    if flavour == 3:                       # heavily ionising: hits on neighbours, several hits per pixel
+        seg["dEdx"] *= rng.uniform(3.0, 12.0, len(seg)).astype('f4')
+        seg["dE"] = seg["dEdx"] * seg["dx"]
+    if consts.sim.IS_SPILL_SIM:
+        loc = seg["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
+        for f in ("t0", "t0_start", "t0_end"):
+            seg[f] = seg[f] - loc * consts.sim.SPILL_PERIOD
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    return seg[order], bid[order], table
+
+
+def check_case(seed, cfg, resp):
+    seg, bid, table = make_case(seed, cfg)
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid); ch.quench_drift()
+    st = ch.run(0, len(seg), want_fractions=True)
+    out = ch.download()
+    problems = []
+    for b in range(len(table)):
+        if not (bid == b).any():
+            continue
+        o = oracle_chain(seg[bid == b], resp)
+        m = out["batch"] == b
+        if not np.array_equal(out["unique_pix"][m], o["unique_pix"]): problems.append(f"batch {b}: unique pixels"); continue
+        if not np.array_equal(out["track_pixel_map"][m], o["tpm"]): problems.append(f"batch {b}: track map")
+        if not np.array_equal(out["adc_list"][m] != 0, o["adc"] != 0): problems.append(f"batch {b}: hit slots"); continue
+        hit = o["adc"] != 0
+        if hit.any():
+            rel = np.abs(out["adc_list"][m][hit] - o["adc"][hit]) / np.abs(o["adc"][hit])
+            if rel.max() > 1e-5: problems.append(f"batch {b}: charge rel {rel.max():.2e}")
+            if not np.array_equal(out["adc_ticks_list"][m], o["ticks"]): problems.append(f"batch {b}: ticks")
+            if not np.array_equal(out["adc_digit"][m], o["digit"]): problems.append(f"batch {b}: adc counts")
+            fr = np.abs(out["current_fractions"][m][hit] - o["frac"][hit])
+            if (fr > 1e-5 * np.abs(o["frac"][hit]) + 1e-9).any(): problems.append(f"batch {b}: fractions {fr.max():.2e}")
+    return problems, st, int((out["adc_list"] != 0).sum())
+
+
+if __name__ == "__main__":
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "module0"
+    n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    H.load_cfg(cfg)
+    O.build()
+    resp = H.response_for("dense" if cfg == "2x2_no_modvar" else "survey")
+    bad, hits, pairs, amb, fb, t0 = 0, 0, 0, 0, 0, time.time()
+    for seed in range(first, first + n_seeds):
+        problems, st, nh = check_case(seed, cfg, resp)
+        hits += nh; pairs += st.n_pairs; amb += st.n_ambiguous; fb += st.n_fallback
+        if problems:
+            bad += 1
+            print(f"seed {seed} (flavour {seed % 5}): " + "; ".join(problems), flush=True)
+        if (seed - first) % 10 == 9:
+            print(f"  ... {seed - first + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+    print(f"{cfg}: {n_seeds} cases, {pairs} pairs, {hits} hits, ambiguous shifts {amb}, fallback pairs {fb}: {bad} mismatching cases")
+    sys.exit(1 if bad else 0)
