@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--segments", type=int, default=SEGS_PER_GPU)
     ap.add_argument("--response", default="survey", choices=["survey", "dense", "golden"])
+    ap.add_argument("--config", default="module0", choices=["module0", "2x2_no_modvar", "ndlar"],
+                    help="detector configuration of the synthetic workload (SURVEY 8d seeds); the contract line is the "
+                         "default, module0 = BASELINE configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fractions", type=int, default=1, help="compute backtracking fractions (reference always does)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / all-gather path even with one rank")
@@ -111,13 +114,19 @@ def main():
         tdist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=300), rank=rank, world_size=world,
                                  device_id=torch.device("cuda", local_rank))
 
-    consts.load_snapshot("module0")
+    consts.load_snapshot(a.config)
     for k in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOISE"):
         setattr(consts.detector, k, 0)     # the reference's RNG stream is third-party/unpinned: noise off
+    seed_index = {"module0": 2, "2x2_no_modvar": 3, "ndlar": 5}[a.config]      # BASELINE config number
 
     # ---- workload: global set of world x 100k segments, this rank's shard of its batches ----------------------------
     n_total = a.segments * world
-    seg_all = synth.make_segments(n_total, seed=synth.SEED_BASE + 2, segs_per_event=5000)
+    seg_all = synth.make_segments(n_total, seed=synth.SEED_BASE + seed_index, segs_per_event=5000,
+                                  spill=bool(consts.sim.IS_SPILL_SIM))
+    if consts.sim.IS_SPILL_SIM:            # the driver subtracts the spill offset again (cli/simulate_pixels.py:574-582)
+        loc = seg_all["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
+        for f in ("t0", "t0_start", "t0_end"):
+            seg_all[f] = seg_all[f] - loc * consts.sim.SPILL_PERIOD
     batching.swap_coordinates(seg_all)
     bid_all, order, table = batching.assign_batches(seg_all)
     idx, bid = ldist.shard_segments(bid_all, order, table, rank, world)
@@ -187,20 +196,27 @@ def main():
         ms_step = 1e3 * elapsed / a.steps
         value = n_job * a.steps / elapsed
         split = acc["w_ms"] > 0
-        # dominant kernel of the path: weights_kernel (split path, default) or the monolithic current_kernel
-        dom_ms = acc["w_ms"] if split else acc["cur_ms"]
+        M = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
+        # dominant kernel of the path: the longer of the split path's two kernels (weights_kernel on module0 / 2x2,
+        # mac_kernel on ndlar), or the monolithic current_kernel when the split path is off
+        if not split:
+            dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
+        elif acc["w_ms"] >= acc["m_ms"]:
+            dom_name, dom_ms = f"weights_kernel<{M}>", acc["w_ms"]
+        else:
+            dom_name, dom_ms = f"mac_kernel<{M}>", acc["m_ms"]
         dom_s = dom_ms * 1e-3
         achieved = acc["bytes"] / dom_s / 1e9 if dom_s > 0 else 0.0
         mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
         tflops = 2.0 * acc["dfma"] / mac_s / 1e12 if mac_s > 0 else 0.0
         nl = max(acc["launches"], 1)
         out = {
-            "metric": "edep segments/s end-to-end (quench->ADC), module0 config",
+            "metric": f"edep segments/s end-to-end (quench->ADC), {a.config} config",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"module0, {a.segments} synthetic straight-track segments per GPU "
-                                   f"(seed 20241018, 5000/event), full charge chain quench->drift->pixels->"
+            "config": {"workload": f"{a.config}, {a.segments} synthetic straight-track segments per GPU "
+                                   f"(seed {synth.SEED_BASE + seed_index}, 5000/event), full charge chain quench->drift->pixels->"
                                    f"tracks_current->pixel sum->ADC+digitize, backtracking fractions "
                                    f"{'on' if a.fractions else 'off'}",
                        "response": f"synthetic '{a.response}' (45,45,1950) f64", "noise": "off",
@@ -208,13 +224,14 @@ def main():
                        "unique_pixels_per_segment": acc["U"] / max(acc["S"], 1),
                        "hits_per_step": acc["hits"] // max(a.steps, 1),
                        "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "weights_kernel<1>" if split else "current_kernel<1>",
+            "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_*: FETCH_SIZE x2 per the
                          # gfx950 correction + WRITE_SIZE) -- only valid for the default workload/chunking
-                         "traffic": PROFILED_TRAFFIC_BYTES if (a.segments == SEGS_PER_GPU and a.response == "survey"
-                                                               and a.fractions and split) else None,
+                         "traffic": PROFILED_TRAFFIC_BYTES if (a.config == "module0" and a.segments == SEGS_PER_GPU
+                                                               and a.response == "survey" and a.fractions and split
+                                                               and dom_name == "weights_kernel<1>") else None,
                          "launch_ms_avg": dom_ms / nl,
                          "launches": acc["launches"],
                          "algorithmic_bytes_per_launch": acc["bytes"] / nl,
@@ -224,7 +241,7 @@ def main():
                                            "current_kernel_ms_avg": acc["f_ms"] / nl,
                                            "pixel_adc_kernel_ms_avg": acc["adc_ms"] / nl,
                                            "charge_samples_per_launch": acc["samples"] / nl},
-                         "valu_f64": {"kernel": "mac_kernel<1>" if split else "current_kernel<1>",
+                         "valu_f64": {"kernel": f"mac_kernel<{M}>" if split else f"current_kernel<{M}>",
                                       "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                                       "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},
