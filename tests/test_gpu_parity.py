@@ -527,6 +527,51 @@ def test_fused_chain_fuzz_slice_vs_oracle(cfg, seeds):
     assert n_hits > 20
 
 
+def test_boundary_refuses_misuse_and_stays_usable():
+    """Misuse of the C-ABI through the Python layer fails loudly with a message that names the problem (status code +
+    ldsim_last_error -> LdsimError), and the context computes correctly afterwards."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(40, seed=4, segs_per_event=20)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    resp = synth.make_response("survey")
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.run(0, len(seg))
+    good = ch.download()
+    assert (good["adc_list"] != 0).sum() > 5
+    with pytest.raises(lib.LdsimError, match="outside the resident store"):
+        ch.run(0, len(seg) + 1)
+    with pytest.raises(lib.LdsimError, match="outside the resident store"):
+        ch.run(10, 5)
+    with pytest.raises(lib.LdsimError, match="record count differs"):
+        ch.download_segments(seg[:7].copy())
+    with pytest.raises(lib.LdsimError, match="unknown option"):
+        lib.set_option("no_such_option", 1)
+    with pytest.raises(ValueError, match="differ in length"):
+        ch.set_pixel_thresholds(np.arange(3), np.ones(2), 1.0)
+    # FEE noise is refused (the reference's RNG stream is not reproduced), not silently dropped
+    consts.detector.RESET_NOISE_CHARGE = 900.0
+    try:
+        noisy = ChargeChain(resp)
+        with pytest.raises(lib.LdsimError, match="FEE noise must be 0"):
+            noisy.run(0, len(seg))
+    finally:
+        consts.detector.RESET_NOISE_CHARGE = 0
+    # decreasing batch ids are refused at upload; the previous upload is what stays resident is not promised, so upload again
+    fresh = ChargeChain(resp)
+    with pytest.raises(lib.LdsimError, match="non-decreasing"):
+        fresh.upload(seg, bid[::-1].copy())
+    fresh.upload(seg, bid)
+    fresh.quench_drift()
+    fresh.run(0, len(seg))
+    again = fresh.download()
+    assert np.array_equal(again["unique_pix"], good["unique_pix"]) and np.array_equal(again["adc_digit"], good["adc_digit"])
+    assert np.array_equal(again["adc_ticks_list"], good["adc_ticks_list"])
+
+
 def test_chain_with_nothing_to_simulate():
     """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
     drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""
