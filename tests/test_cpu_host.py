@@ -25,6 +25,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert l.ldsim_abi_version() == abi.ABI_VERSION == 2
 
 
+def test_graft_entry_build_succeeds():
+    """The driver's build check: __graft_entry__.build() compiles the HIP library and the oracle and imports the package
+    (an incremental make here).  It once asserted a stale ABI version after the header had moved on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(REPO, "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    ge.build()
+    assert callable(ge.smoke)
+
+
 def test_no_cpu_fallback_without_gpu():
     if lib.device_count() > 0:
         pytest.skip("GPU present")
