@@ -59,29 +59,7 @@ def make_layout(dtype):
     return lay
 
 
-def oracle_dtype(dtype=None):
-    """All-f8 mirror of the hot-path fields (+ i4 pixel_plane): the flat record the oracle works on."""
-    return np.dtype([(n, 'f8') for n in FIELDS[:-1]] + [('pixel_plane', 'i4'), ('_pad', 'i4')])
-
-
 def store_codes(dtype):
     """dtype code per field as it is *stored* in ``dtype`` (F8 when absent)."""
     lay = make_layout(dtype)
     return np.array(list(lay.dtype), dtype=np.int32), np.array(list(lay.offset), dtype=np.int32)
-
-
-def to_oracle(tracks):
-    """Structured array of any layout -> flat f8 oracle records."""
-    out = np.zeros(tracks.shape[0], dtype=oracle_dtype())
-    for n in FIELDS:
-        if n in tracks.dtype.names:
-            out[n] = tracks[n]
-    return out
-
-
-def from_oracle(orec, tracks, fields=None):
-    """Copy (already narrowed) oracle fields back into a structured array."""
-    for n in (fields or FIELDS):
-        if n in tracks.dtype.names:
-            tracks[n] = orec[n]
-    return tracks

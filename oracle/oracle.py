@@ -18,9 +18,31 @@ if os.path.join(_REPO, "larnd-sim_amd") not in sys.path:
 
 from larndsim_amd import consts  # noqa: E402
 from larndsim_amd.abi import LdsimConsts, pack_consts  # noqa: E402
-from larndsim_amd.layout import FIELDS, from_oracle, oracle_dtype, store_codes, to_oracle  # noqa: E402
+from larndsim_amd.layout import FIELDS, store_codes  # noqa: E402
 
 _lib = None
+
+
+def oracle_dtype():
+    """All-f8 mirror of the hot-path fields (+ i4 pixel_plane): the flat record the C oracle works on."""
+    return np.dtype([(n, 'f8') for n in FIELDS[:-1]] + [('pixel_plane', 'i4'), ('_pad', 'i4')])
+
+
+def to_oracle(tracks):
+    """Structured array of any layout -> flat f8 oracle records."""
+    out = np.zeros(tracks.shape[0], dtype=oracle_dtype())
+    for n in FIELDS:
+        if n in tracks.dtype.names:
+            out[n] = tracks[n]
+    return out
+
+
+def from_oracle(orec, tracks, fields=None):
+    """Copy (already narrowed) oracle fields back into a structured array."""
+    for n in (fields or FIELDS):
+        if n in tracks.dtype.names:
+            tracks[n] = orec[n]
+    return tracks
 
 
 def build():
