@@ -1,15 +1,19 @@
-// kernels_split.hip -- a9-a12 as two kernels (option "split_kernels"):
+// kernels_split.hip -- a9-a12 as two kernels (the default path; option "split_kernels", 0 = monolithic kernels_current.hip):
 //
 //   weights_kernel<M>   one workgroup per (segment, pixel) pair: evaluates every charge sample once and emits the
 //                       pair's binned weights  A[cell][shift]  as compact "items" (cell id, first shift, #8-shift
-//                       blocks, offset into a global f64 arena) plus the window-edge corrections.  It touches no
-//                       response rows, needs ~45 KB of LDS and ~135 VGPRs -> 3 workgroups per CU.
-//   mac_kernel<M>       one workgroup per pair: streams the pair's items; per item the response row segment and the
+//                       blocks, offset into a shared f64 pool in HBM) plus the window-edge corrections.  It touches no
+//                       response rows (the rare edge path reads single table entries): 128 VGPRs (+52 B/lane of
+//                       scratch, outer code only), 37.7 KB of LDS -> 4 workgroups per CU.
+//   mac_kernel<M>       one workgroup per pair: walks the pair's items; per item the response row segment and the
 //                       item's weights are prefetched into registers one item ahead, staged in wave-private LDS and
-//                       correlated with the register-tiled sliding window of kernels_current.hip.  ~30 KB LDS.
+//                       correlated with the register-tiled sliding window of kernels_current.hip.  M = 1: item list
+//                       copied to LDS, 128 VGPRs, 31.8 KB -> 4 workgroups per CU; M = 2: descriptors read from HBM two
+//                       items ahead, 168 VGPRs, 39.8 KB -> 3 workgroups per CU.
 //
-// Pairs that exceed the fixed item / correction capacities are flagged and recomputed by the monolithic
-// current_kernel (kernels_current.hip), which has no such limits.
+// Pairs that exceed a per-pair capacity (items, corrections, runs) are flagged and recomputed by the monolithic
+// current_kernel (kernels_current.hip), which has no such limits.  The weight pool is sized by chain.hip from the
+// demand of earlier launches; a launch that exhausted it is repeated, never used.
 #include "current_common.h"
 
 // items per pair: 512 at M = 1 (mac_kernel<1> keeps the list in LDS); at M = 2 a 64-shift chunk covers half as many
