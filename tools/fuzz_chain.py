@@ -10,6 +10,9 @@ from larndsim_amd.chain import ChargeChain
 from oracle import oracle as O
 
 
+N_FLAVOURS = 8
+
+
 def oracle_chain(seg, response):
     ref = seg.copy()
     O.quench(ref, consts.physics.BIRKS); O.drift(ref)
@@ -29,10 +32,12 @@ def oracle_chain(seg, response):
 
 
 def make_case(seed, cfg):
-    """Two events of 10 segments; per seed a different flavour of segment shapes."""
+    """Two events of 10 segments; per seed a different flavour of segment shapes: 0 plain, 1 short tracks, 2 long segments,
+    3 heavily ionising, 4 medium, 5 hugging the TPC faces (pixel ids off the plane), 6 very short segments, 7 nearly along
+    the drift axis or nearly perpendicular to x (the degenerate-geometry corners of z_interval, detsim.py:42-112)."""
     rng = np.random.default_rng(1000 + seed)
-    flavour = seed % 5
-    max_len = (60.0, 3.0, 60.0, 60.0, 12.0)[flavour]
+    flavour = seed % N_FLAVOURS
+    max_len = (60.0, 3.0, 60.0, 60.0, 12.0, 60.0, 60.0, 60.0)[flavour]
     seg = synth.make_segments(20, seed=5000 + seed, segs_per_event=10, spill=bool(consts.sim.IS_SPILL_SIM),
                               max_track_len=max_len)
     if flavour == 2:                       # long segments: many slice chunks, waveforms past one tile
@@ -44,6 +49,32 @@ def make_case(seed, cfg):
         seg["dE"] = seg["dEdx"] * seg["dx"]
     if flavour == 3:                       # heavily ionising: hits on neighbours, several hits per pixel
         seg["dEdx"] *= rng.uniform(3.0, 12.0, len(seg)).astype('f4')
+        seg["dE"] = seg["dEdx"] * seg["dx"]
+    if flavour == 5:                       # push every track towards the nearest x / y face of its TPC box (edep-sim frame:
+        b = np.sort(np.asarray(consts.detector.TPC_BORDERS), axis=-1)      # z <-> x are swapped w.r.t. TPC_BORDERS)
+        mid = {"z": 0.5 * (seg["z_start"] + seg["z_end"]), "y": 0.5 * (seg["y_start"] + seg["y_end"])}
+        for a, ib in (("z", 0), ("y", 1)):
+            lo, hi = b[:, ib, 0].min(), b[:, ib, 1].max()
+            shift = np.where(mid[a] - lo < hi - mid[a], lo - mid[a] + 0.3, hi - mid[a] - 0.3).astype('f4')
+            shift = shift * (rng.random(len(seg)) < 0.5)
+            for f in (a, a + "_start", a + "_end"):
+                seg[f] = seg[f] + shift
+    if flavour == 6:                       # very short segments around the original midpoints
+        for a in ("x", "y", "z"):
+            d = (seg[a + "_end"] - seg[a + "_start"]) * rng.uniform(0.02, 0.1, len(seg)).astype('f4')
+            seg[a + "_start"] = seg[a] - 0.5 * d; seg[a + "_end"] = seg[a] + 0.5 * d
+        seg["dx"] = np.sqrt(sum((seg[a + "_end"] - seg[a + "_start"]).astype('f8') ** 2 for a in "xyz"))
+        seg["dE"] = seg["dEdx"] * seg["dx"]
+    if flavour == 7:                       # edep-sim x is the drift axis, z becomes the TPC frame's x after the swap
+        squash = "z" if seed % 2 else "y"  # nearly perpendicular to TPC x / y ...
+        k = rng.uniform(1e-3, 2e-2, len(seg)).astype('f4')
+        d = (seg[squash + "_end"] - seg[squash + "_start"]) * k
+        seg[squash + "_start"] = seg[squash] - 0.5 * d; seg[squash + "_end"] = seg[squash] + 0.5 * d
+        if seed % 4 >= 2:                  # ... and half of those nearly along the drift axis as well
+            other = "y" if squash == "z" else "z"
+            d = (seg[other + "_end"] - seg[other + "_start"]) * k
+            seg[other + "_start"] = seg[other] - 0.5 * d; seg[other + "_end"] = seg[other] + 0.5 * d
+        seg["dx"] = np.sqrt(sum((seg[a + "_end"] - seg[a + "_start"]).astype('f8') ** 2 for a in "xyz"))
         seg["dE"] = seg["dEdx"] * seg["dx"]
     if consts.sim.IS_SPILL_SIM:
         loc = seg["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
@@ -93,7 +124,7 @@ if __name__ == "__main__":
         hits += nh; pairs += st.n_pairs; amb += st.n_ambiguous; fb += st.n_fallback
         if problems:
             bad += 1
-            print(f"seed {seed} (flavour {seed % 5}): " + "; ".join(problems), flush=True)
+            print(f"seed {seed} (flavour {seed % N_FLAVOURS}): " + "; ".join(problems), flush=True)
         if (seed - first) % 10 == 9:
             print(f"  ... {seed - first + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
     print(f"{cfg}: {n_seeds} cases, {pairs} pairs, {hits} hits, ambiguous shifts {amb}, fallback pairs {fb}: {bad} mismatching cases")
