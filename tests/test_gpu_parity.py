@@ -504,12 +504,13 @@ def test_more_than_max_tracks_per_pixel_vs_oracle():
     np.testing.assert_allclose(out["current_fractions"][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("cfg,seeds", [("module0", (0, 1, 2, 3, 4)), ("ndlar", (202, 203))])
+@pytest.mark.parametrize("cfg,seeds", [("module0", (0, 1, 2, 3, 4, 5, 6, 7)), ("ndlar", (202, 203))])
 def test_fused_chain_fuzz_slice_vs_oracle(cfg, seeds):
     """A slice of tools/fuzz_chain.py (the full runs: 700 cases over module0 / 2x2 dense / ndlar, 1.7e5 pairs, 3.2e4 hits,
     no mismatch): two events of ten segments per seed, the seed picks the flavour -- plain, short tracks, long segments
-    (several slice chunks, overflow fallback), heavily ionising (hits on neighbours, several per pixel), medium -- and
-    the fused chain must match the oracle: pixels, track map, hit slots, ticks and ADC counts exactly, charges and
+    (several slice chunks, overflow fallback), heavily ionising (hits on neighbours, several per pixel), medium, hugging
+    the TPC faces (pixel ids off the plane), very short segments, nearly along the drift axis -- and the fused chain must
+    match the oracle: pixels, track map, hit slots, ticks and ADC counts exactly, charges and
     fractions to 1e-5."""
     import importlib.util
     import os
