@@ -44,6 +44,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
   a.prune_log = ctx->prune_log;
   a.tail_log = ctx->tail_log;
   a.debug_phases = ctx->debug_phases;
+  a.numba_f32 = ctx->numba_f32;
   a.split_max_items = ctx->split_max_items;
 }
 

@@ -24,6 +24,8 @@ struct PairGeo {
   double Dx, Dy, Dz, Dr;   // segment and its length
   double dirx, diry, dirz;
   double sT, sL, q;
+  double sT2, sL2, s3;     // sT^2, sL^2 as rho's delta / a use them (f64) and the sigma product of its `factor`
+  double rT, rL;           // sigma^2 / (sigma * sigma as _b types it): 1 unless numba_f32 (detsim.py:116-118)
   double z_start_int, z_step, x_step, y_step, x_start, y_start, sgnx, sgny;
   double t_start, z_anode, dV;
   int z_steps;
@@ -33,8 +35,14 @@ struct PairGeo {
 __device__ __forceinline__ double sgn(double x) { return x >= 0 ? 1.0 : -1.0; }
 
 // detsim.py:42-112
+// nf32: Numba types f32 (op) f32 as f32 -- with f4 record fields the spots below are single precision
+// (detsim.py:74-79; the oracle's F32SUB / F32MUL / F32DIV, oracle/ldsim_oracle.c:270-291)
+__device__ __forceinline__ double f32sub(double a, double b, bool nf32) { return nf32 ? (double)((float)a - (float)b) : a - b; }
+__device__ __forceinline__ double f32mul(double a, double b, bool nf32) { return nf32 ? (double)((float)a * (float)b) : a * b; }
+__device__ __forceinline__ double f32div(double a, double b, bool nf32) { return nf32 ? (double)((float)a / (float)b) : a / b; }
+
 __device__ __forceinline__ void z_interval(const double* sp, const double* ep, double x_p, double y_p, double tol,
-                                           double& z_poca, double& z_lo, double& z_hi) {
+                                           double& z_poca, double& z_lo, double& z_hi, bool nf32) {
   const double *start, *end;
   z_poca = z_lo = z_hi = 0;
   if (sp[0] > ep[0]) {
@@ -47,11 +55,11 @@ __device__ __forceinline__ void z_interval(const double* sp, const double* ep, d
     return;
   }
   double xs = start[0], ys = start[1], xe = end[0], ye = end[1];
-  double m = (ye - ys) / (xe - xs);
-  double q = (xe * ys - xs * ye) / (xe - xs);
+  double m = f32div(f32sub(ye, ys, nf32), f32sub(xe, xs, nf32), nf32);
+  double q = f32div(f32sub(f32mul(xe, ys, nf32), f32mul(xs, ye, nf32), nf32), f32sub(xe, xs, nf32), nf32);
   double a = m, b = -1, cc = q;
-  double x_poca = (b * (b * x_p - a * y_p) - a * cc) / (a * a + b * b);
-  double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
+  double x_poca = (b * (b * x_p - a * y_p) - f32mul(a, cc, nf32)) / (f32mul(a, a, nf32) + b * b);
+  double dx = f32sub(end[0], start[0], nf32), dy = f32sub(end[1], start[1], nf32), dz = f32sub(end[2], start[2], nf32);
   double length = sqrt(dx * dx + dy * dy + dz * dz);
   double d0 = dx / length, d2 = dz / length;
   double doca;
@@ -62,12 +70,13 @@ __device__ __forceinline__ void z_interval(const double* sp, const double* ep, d
     doca = sqrt((x_p - end[0]) * (x_p - end[0]) + (y_p - end[1]) * (y_p - end[1]));
     x_poca = end[0];
   } else {
-    doca = fabs(a * x_p + b * y_p + cc) / sqrt(a * a + b * b);
+    doca = fabs(a * x_p + b * y_p + cc) / sqrt(f32mul(a, a, nf32) + b * b);
   }
   double zp = start[2] + (x_poca - start[0]) / d0 * d2;
   if (tol > doca) {
-    double length2D = sqrt((xe - xs) * (xe - xs) + (ye - ys) * (ye - ys));
-    double dir2x = (end[0] - start[0]) / length2D;
+    double dxs = f32sub(xe, xs, nf32), dys = f32sub(ye, ys, nf32);
+    double length2D = sqrt(dxs * dxs + dys * dys);
+    double dir2x = f32sub(end[0], start[0], nf32) / length2D;
     double deltaL2D = sqrt(tol * tol - doca * doca);
     double x_plus = x_poca + deltaL2D * dir2x;
     double x_minus = x_poca - deltaL2D * dir2x;
@@ -106,17 +115,21 @@ static __device__ void pair_geometry(const CurArgs& A, int64_t seg, int64_t pID,
   } else {
     end[0] = xs; end[1] = ys; end[2] = zs; start[0] = xe; start[1] = ye; start[2] = ze;
   }
-  g.Dx = end[0] - start[0]; g.Dy = end[1] - start[1]; g.Dz = end[2] - start[2];
+  const bool nf32 = A.numba_f32 != 0;
+  g.Dx = f32sub(end[0], start[0], nf32); g.Dy = f32sub(end[1], start[1], nf32); g.Dz = f32sub(end[2], start[2], nf32);
   double length = sqrt(g.Dx * g.Dx + g.Dy * g.Dy + g.Dz * g.Dz);
   g.Dr = length;
   g.dirx = g.Dx / length; g.diry = g.Dy / length; g.dirz = g.Dz / length;
   g.sT = s.f[LDSIM_TRAN_DIFF][seg];
   g.sL = s.f[LDSIM_LONG_DIFF][seg];
   g.q = s.f[LDSIM_N_ELECTRONS][seg];
+  g.sT2 = g.sT * g.sT; g.sL2 = g.sL * g.sL;
+  g.s3 = f32mul(f32mul(g.sT, g.sT, nf32), g.sL, nf32);
+  g.rT = g.sT2 / f32mul(g.sT, g.sT, nf32); g.rL = g.sL2 / f32mul(g.sL, g.sL, nf32);
   double impact = fmax(sqrt((5 * g.sT) * (5 * g.sT) + (5 * g.sT) * (5 * g.sT)),
                        sqrt(c->pixel_pitch * c->pixel_pitch + c->pixel_pitch * c->pixel_pitch) / 2) * 2;
   double z_poca, z_s, z_e;
-  z_interval(start, end, x_p, y_p, impact, z_poca, z_s, z_e);
+  z_interval(start, end, x_p, y_p, impact, z_poca, z_s, z_e, nf32);
   if (z_poca == 0) return;
   g.x_p = x_p; g.y_p = y_p;
   g.sx = start[0]; g.sy = start[1]; g.sz = start[2];

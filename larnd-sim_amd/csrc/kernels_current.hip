@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
       s_jcell[lane] = (short)j;
       // separable parts of rho's b and delta (detsim.py:114-118,146-148)
       double ddx = x - g.sx, ddy = y - g.sy;
-      double iT2 = 1.0 / (g.sT * g.sT), i2T = 1.0 / (2 * g.sT * g.sT);
+      double iT2 = g.rT / g.sT2, i2T = 1.0 / (2 * g.sT * g.sT);   // _b: sigma*sigma as typed (detsim.py:116)
       s_px[lane][0] = ddx * iT2 * (g.Dx / g.Dr);
       s_px[lane][1] = ddx * ddx * i2T;
       s_py[lane][0] = ddy * iT2 * (g.Dy / g.Dr);
@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
   // per-pair constants of rho (detsim.py:135-148)
   const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
   const double i2T = 1.0 / (2 * g.sT * g.sT), i2L = 1.0 / (2 * g.sL * g.sL);
-  const double iL2 = 1.0 / (g.sL * g.sL);
+  const double iL2 = g.rL / g.sL2;
   const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
-  const double factor = g.q / g.Dr / (g.sT * g.sT * g.sL * sqrt(8 * M_PI * M_PI * M_PI));
+  const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
   const double sqrt_a_2 = 2 * sqrt(a);
   const double inv_sa2 = 1.0 / sqrt_a_2, inv4a = 1.0 / (4 * a);
   const double pref = factor * sqrt(M_PI) * inv_sa2 * g.dV;

@@ -1,0 +1,633 @@
+// kernels_qweights.hip -- a9-a12, weights stage of the split path, default form ("weights_mode" 1).
+//
+// The reference evaluates, for every charge sample (ix, iy, iz) of a (segment, pixel) pair, the closed form of the line
+// integral of a 3-D Gaussian (detsim.py:120-159: 2 erf, exp, 2 log) -- ~6.4e4 samples per pair.  The closed form is
+//      rho(x, y, z) = q / (Dr (2 pi)^(3/2) sT sT sL)  *  Int_0^Dr ds  gT(x - sx - s ux) gT(y - sy - s uy) gL(z - sz - s uz)
+// and the integrand is a product of three 1-D Gaussians.  A Gauss-Legendre rule along the segment (N nodes, chosen from
+// the segment length in units of the Gaussian's width along it so that the rule is exact to 1e-12 of the on-axis density;
+// measured in tools/quad_nodes.py) therefore turns the binned weights into a sum of N separable terms
+//      A[i][j][shift] = sum_n  w_n  X_n[i] Y_n[j] Z_n[shift],     X_n[i] = sum_{ix in response column i} gT(x_ix - sx - s_n ux), ...
+// i.e. ~120 N one-dimensional exponentials and a small (cells x shifts x N) product per pair instead of 6.4e4 closed-form
+// evaluations.  All terms are positive (no erf cancellation), every bin is owned by one thread and the nodes are added in
+// a fixed order, so the weights are bitwise reproducible.  The sample grid, the response cell of every sample, the
+// response shift of every z slice and the window-edge predicates are the reference's own (shared with weights_kernel).
+//
+// Pairs whose segment is longer than ~130 widths (N > 256: sT -> 0 next to the anode) and pairs that exceed the item /
+// correction / run capacities are flagged and recomputed by the monolithic current_kernel, like in weights_kernel.
+#include "split_common.h"
+
+#define QNB 16            // quadrature nodes per batch (tables of one batch live in LDS)
+#define QTILES 512        // (cell, 8-shift block) tiles per column group: two per thread, accumulated in registers
+#define QCOLS 32          // response columns per group
+#define Q_CELLS 512       // response cells per group
+
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, const double* __restrict__ glx,
+                                                                  const double* __restrict__ glw, int qn_max) {
+  const CurArgs& A = S.c;
+  const LdsimConsts* c = A.c;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  int32_t* hdr = S.hdr + pair * HDR_INTS;
+
+  int64_t seg, pID;
+  {
+    int32_t v = A.pair_val[pair];
+    seg = A.seg_begin + v / A.P;
+    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
+  }
+  int T = A.T;
+  if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
+
+  PairGeo g;
+  pair_geometry(A, seg, pID, g);
+  auto write_empty = [&]() {
+    if (tid < HDR_INTS) hdr[tid] = 0;
+  };
+  if (!g.ok) { write_empty(); return; }
+  if (A.debug_phases & 0x100) { write_empty(); return; }      // timing tools: stop after the geometry
+  const int NS = c->sampled_points;
+  const double dt = c->time_sampling, dtr = c->response_sampling, TW = c->time_window;
+  const double bin = c->response_bin_size;
+
+  __shared__ double s_X[QNB][QCOLS], s_Y[QNB][NJ_MAX], s_Z[QNB][ZC], s_Zi[QNB][ZC];
+  __shared__ double s_C[NEDGE][NU_MAX];
+  __shared__ double s_dx[NS_MAX], s_dy[NS_MAX], s_dz[ZC], s_Q[QNB];
+  __shared__ int s_shift[ZC], s_inval[ZC];
+  __shared__ short s_icell[NS_MAX], s_jcell[NS_MAX], s_colof[NS_MAX], s_coli[NS_MAX], s_colstart[NS_MAX + 1];
+  __shared__ short s_jstart[NJ_MAX + 1], s_ustart[NU_MAX + 1];
+  __shared__ unsigned char s_ixord[NS_MAX], s_iyord[NS_MAX], s_zord[ZC];
+  __shared__ unsigned char s_tmask[QTILES], s_culo[Q_CELLS], s_cuhi[Q_CELLS];
+  __shared__ unsigned short s_boff[Q_CELLS], s_li[Q_CELLS];
+  __shared__ double s_rng[8];
+  __shared__ int s_misc[24];
+  __shared__ unsigned long long s_base64;
+
+  // ---- sample -> response cell maps; member lists ordered by response index (x: wave 0, y: wave 1) ----------------
+  if (wv == 0) {
+    int i = -1;
+    double ddx = 0;
+    if (lane < NS) {
+      double x = g.x_start + g.sgnx * (lane * g.x_step - 4 * g.sT);
+      double xd = fabs(g.x_p - x);
+      if (!(xd > bin * A.ni)) {
+        i = (int)py_round(xd / bin - 0.5);
+        if (i < 0 || i >= A.ni) i = -1;
+      }
+      s_icell[lane] = (short)i;
+      ddx = x - g.sx;
+      s_dx[lane] = ddx;
+    }
+    int leader = lane;
+    for (int q = 0; q < NS; q++) {
+      int iq = __shfl(i, q);
+      if (q < leader && iq == i) leader = q;
+    }
+    bool is_leader = (lane < NS) && (i >= 0) && (leader == lane);
+    int slot = 0;   // rank of this column's i among the distinct i  -> cells come out sorted by (i, j)
+    for (int q = 0; q < NS; q++) {
+      int iq = __shfl(i, q);
+      bool lq = __shfl((int)is_leader, q);
+      if (lq && iq < i) slot++;
+    }
+    int myslot = (i < 0 || lane >= NS) ? -1 : slot;
+    int ncol = __popcll(__ballot(is_leader));
+    if (lane < NS) s_colof[lane] = (short)myslot;
+    if (is_leader) s_coli[slot] = (short)i;
+    int posn = 0;
+    for (int q = 0; q < NS; q++) {
+      int sq = __shfl(myslot, q);
+      if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
+    }
+    if (myslot >= 0) s_ixord[posn] = (unsigned char)lane;
+    if (is_leader) s_colstart[slot] = (short)posn;
+    int nvalid = __popcll(__ballot(myslot >= 0));
+    double lo = myslot >= 0 ? ddx : 1e300, hi = myslot >= 0 ? ddx : -1e300;
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fmin(lo, __shfl_down(lo, off));
+      hi = fmax(hi, __shfl_down(hi, off));
+    }
+    if (lane == 0) {
+      s_colstart[ncol] = (short)nvalid;
+      s_misc[0] = ncol;
+      s_rng[0] = lo;
+      s_rng[1] = hi;
+      s_misc[16] = 0;   // items emitted
+      s_misc[17] = 0;   // corrections emitted
+      s_misc[18] = 0;   // overflow
+      s_misc[19] = 0;   // runs
+    }
+  } else if (wv == 1) {
+    int j = -1;
+    double ddy = 0;
+    if (lane < NS) {
+      double y = g.y_start + g.sgny * (lane * g.y_step - 4 * g.sT);
+      double yd = fabs(g.y_p - y);
+      if (!(yd > bin * A.nj)) {
+        j = (int)py_round(yd / bin - 0.5);
+        if (j < 0 || j >= A.nj) j = -1;
+      }
+      s_jcell[lane] = (short)j;
+      ddy = y - g.sy;
+      s_dy[lane] = ddy;
+    }
+    int jmin = (j >= 0) ? j : (1 << 20), jmax = j;
+    double lo = j >= 0 ? ddy : 1e300, hi = j >= 0 ? ddy : -1e300;
+    for (int off = 32; off > 0; off >>= 1) {
+      jmin = min(jmin, __shfl_xor(jmin, off));
+      jmax = max(jmax, __shfl_xor(jmax, off));
+      lo = fmin(lo, __shfl_xor(lo, off));
+      hi = fmax(hi, __shfl_xor(hi, off));
+    }
+    // members of one j are contiguous in s_iyord; s_jstart[j'] = number of valid samples with j < jmin + j'
+    int posn = 0, below = 0;
+    for (int q = 0; q < NS; q++) {
+      int jq = __shfl(j, q);
+      if (jq >= 0 && j >= 0 && (jq < j || (jq == j && q < lane))) posn++;
+      if (jq >= 0 && jq < jmin + lane) below++;
+    }
+    if (j >= 0) s_iyord[posn] = (unsigned char)lane;
+    if (jmax >= jmin && lane <= jmax - jmin + 1 && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
+    if (lane == 0) {
+      s_misc[1] = jmin;
+      s_misc[2] = jmax;
+      s_rng[2] = lo;
+      s_rng[3] = hi;
+    }
+  }
+  __syncthreads();
+  const int ncol = s_misc[0], jmin = s_misc[1], jmax = s_misc[2];
+  const int NJ = jmax - jmin + 1;
+  if (ncol == 0 || NJ <= 0 || NJ > NJ_MAX) { write_empty(); return; }
+  if (A.debug_phases & 0x200) { write_empty(); return; }      // timing tools: stop after the sample maps
+
+  const double V = TW / dtr;
+  int edge_k[NEDGE] = {0, -1, -1};
+  int k_top;
+  {
+    int ka = (int)floor(V - 0.5 - 1e-6);
+    if ((double)ka + 0.5 >= V - 1e-6) ka--;
+    int kn = (int)ceil(V + 0.5 + 1e-6);
+    k_top = kn - 1;
+    int ne = 1;
+    for (int k = ka + 1; k <= k_top && ne < NEDGE; k++) edge_k[ne++] = k;
+    if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;
+  }
+  const int k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
+  const int k_stage_lo = max(0, A.k_first);
+
+  int it0 = 0;
+  if (g.t_start < 0) {
+    int cand = (int)ceil(-g.t_start / dt) - 1;
+    if (cand < 0) cand = 0;
+    while (g.t_start + cand * dt < 0.) cand++;
+    it0 = cand;
+  }
+  int iz_lo = 0, iz_hi = g.z_steps - 1;
+  if (A.prune_log > 0 && g.z_step > 0) {
+    double cz = sqrt(2.0 * A.prune_log) * g.sL;
+    double zl = g.sz - cz, zh = g.sz + g.Dz + cz;
+    double fl = floor((zl - g.z_start_int) / g.z_step) - 1, fh = ceil((zh - g.z_start_int) / g.z_step) + 1;
+    if (fl > iz_lo) iz_lo = (int)fmin(fl, (double)g.z_steps);
+    if (fh < iz_hi) iz_hi = (int)fmax(fh, -1.0);
+  }
+  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
+  const double i2T = 1.0 / (2 * g.sT2), i2L = 1.0 / (2 * g.sL2);
+  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
+  const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
+  // numba_f32: _b divides by sigma*sigma typed f32 while delta and a use the f64 square (detsim.py:116-118,141-148), so per
+  // axis the exponent is -[(d - r u s)^2 + u^2 s^2 (1 - r^2)] / (2 sigma^2), r = sigma^2 / (sigma*sigma)_f32: still one
+  // Gaussian per axis (centre scaled by r) times a factor that depends on the node only.  r = 1, kappa = 0 otherwise.
+  const double uxr = ux * g.rT, uyr = uy * g.rT, uzr = uz * g.rL;
+  const double kappa = (ux * ux + uy * uy) * (1.0 - g.rT * g.rT) * i2T + uz * uz * (1.0 - g.rL * g.rL) * i2L;
+
+  // ---- the part of the segment that can reach the sample box, and the Gauss-Legendre rule on it --------------------------------
+  // a node whose distance to the box along any axis exceeds G widths adds less than exp(-G^2/2) of the on-axis density
+  const double G = sqrt(2.0 * ((A.prune_log > 0 ? A.prune_log : 43.0) + 7.0));
+  double s_lo = 0, s_hi = g.Dr;
+  {
+    const double z0 = g.z_start_int + iz_lo * g.z_step - g.sz, z1 = g.z_start_int + iz_hi * g.z_step - g.sz;
+    const double lo3[3] = {s_rng[0], s_rng[2], fmin(z0, z1)}, hi3[3] = {s_rng[1], s_rng[3], fmax(z0, z1)};
+    const double u3[3] = {ux, uy, uz}, w3[3] = {sqrt(g.sT2), sqrt(g.sT2), sqrt(g.sL2)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double lo = lo3[k] - G * w3[k], hi = hi3[k] + G * w3[k];
+      if (u3[k] != 0.0) {
+        const double sa = lo / u3[k], sb = hi / u3[k];
+        s_lo = fmax(s_lo, fmin(sa, sb));
+        s_hi = fmin(s_hi, fmax(sa, sb));
+      } else if (lo > 0 || hi < 0) {
+        s_hi = -1;   // the segment does not move along this axis and the box is out of reach
+      }
+    }
+  }
+  if (!(s_hi > s_lo) || iz_hi < iz_lo) { write_empty(); return; }
+  const double qlen = s_hi - s_lo;
+  const double ratio = qlen * sqrt(2.0 * a);           // length in units of the Gaussian's width along the segment
+  const double nq_f = ceil(6.0 + 1.9 * ratio);
+  const bool too_long = !(nq_f <= (double)qn_max);
+  const int NQ = too_long ? 0 : (int)nq_f;
+  const double* __restrict__ gx_tab = glx + (int64_t)NQ * (NQ - 1) / 2;
+  const double* __restrict__ gw_tab = glw + (int64_t)NQ * (NQ - 1) / 2;
+  const double wscale = factor * g.dV * 0.5 * qlen;
+  const bool do_prune = A.prune_log > 0;
+  // bins below exp(-prune_log) of the weight of an on-axis interior sample are not emitted
+  const double thr = do_prune ? exp(-A.prune_log) * factor * g.dV * sqrt(M_PI / a) : 0.0;
+
+  auto slice_shift = [&](int iz, double& z, double& t0, bool count) -> int {
+    z = g.z_start_int + iz * g.z_step;
+    t0 = fabs(z - g.z_anode) / c->v_drift - TW;
+    int it_ref = (int)((t0 + 0.5 * TW - g.t_start) / dt);
+    if (it_ref < 0) it_ref = 0;
+    double tt = g.t_start + it_ref * dt;
+    double val = (tt - t0) / dtr;
+    double kr = py_round(val);
+    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
+    return (int)kr - M * it_ref;
+  };
+  {
+    int smin = 1 << 30, smax = -(1 << 30);
+    for (int iz = iz_lo + tid; iz <= iz_hi; iz += CUR_THREADS) {
+      double z, t0;
+      int sh = slice_shift(iz, z, t0, false);
+      smin = min(smin, sh);
+      smax = max(smax, sh);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      smin = min(smin, __shfl_down(smin, off));
+      smax = max(smax, __shfl_down(smax, off));
+    }
+    if (lane == 0) {
+      s_misc[8 + wv] = smin;
+      s_misc[12 + wv] = smax;
+    }
+  }
+  __syncthreads();
+  const int sh_min = min(min(s_misc[8], s_misc[9]), min(s_misc[10], s_misc[11]));
+  const int sh_max = max(max(s_misc[12], s_misc[13]), max(s_misc[14], s_misc[15]));
+  int it_w0 = it0, it_w1 = T;
+  if (sh_min <= sh_max) {
+    int lo = (k_stage_lo - sh_max) / M - 1, hi = (k_stage_hi - sh_min) / M + 2;
+    it_w0 = max(it_w0, lo);
+    it_w1 = min(it_w1, hi);
+  }
+  if (sh_min > sh_max || it_w1 <= it_w0 || k_stage_hi < k_stage_lo) { write_empty(); return; }
+  if (A.debug_phases & 0x400) { write_empty(); return; }      // timing tools: stop after the shift scan
+  if (too_long) {
+    // hand the pair to the monolithic kernel
+    if (tid < HDR_INTS) hdr[tid] = (tid == 7) ? 1 : 0;
+    if (tid == 0) atomicAdd(&A.counters[6], 1ull);
+    return;
+  }
+
+  constexpr int IMAX = ItemCap<M>::value;
+  Item* items = S.items + pair * IMAX;
+  Corr* corr = S.corr + pair * CMAX;
+
+  int iz_next = iz_lo;
+  while (iz_next <= iz_hi) {
+    __syncthreads();
+    // ---- this chunk's slices: response shift, edge flags, member lists ordered by shift (wave 0) ------------------------------
+    if (wv == 0) {
+      int nmax = min(ZC, iz_hi - iz_next + 1);
+      int sh = 0, inval = 0;
+      if (lane < nmax) {
+        int iz = iz_next + lane;
+        double z, t0;
+        sh = slice_shift(iz, z, t0, true);
+        s_dz[lane] = z - g.sz;
+        s_shift[lane] = sh;
+#pragma unroll
+        for (int e = 0; e < NEDGE; e++) {
+          // a correction is needed only where the correlation would use this slice's weight at a tick the reference
+          // does not: the edge index must be inside the staged response range, reachable by this shift (an integer tick)
+          // and that tick inside the stored window; everything else is dropped at the end anyway
+          bool need = false;
+          const int num = edge_k[e] - sh;
+          if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+            const int it_e = num / M;
+            if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+              int64_t kk;
+              need = !(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e]);
+            }
+          }
+          if (need) inval |= 1 << e;
+        }
+        s_inval[lane] = inval;
+      }
+      int pmin = lane < nmax ? sh : (1 << 30), pmax = lane < nmax ? sh : -(1 << 30);
+      for (int off = 1; off < 64; off <<= 1) {
+        int a1 = __shfl_up(pmin, off), a2 = __shfl_up(pmax, off);
+        if (lane >= off) { pmin = min(pmin, a1); pmax = max(pmax, a2); }
+      }
+      bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
+      unsigned long long fm = __ballot(fits);
+      int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
+      int lo = __shfl(pmin, n - 1), hi = __shfl(pmax, n - 1);
+      // slices of the chunk ordered by shift (|z - z_anode| need not be monotone in iz): s_zord, s_ustart[u]
+      int posn = 0, below = 0, anyinv = 0;
+      for (int q = 0; q < n; q++) {
+        int sq = __shfl(sh, q);
+        if (lane < n && (sq < sh || (sq == sh && q < lane))) posn++;
+        if (sq < lo + lane) below++;
+      }
+      if (lane < n) s_zord[posn] = (unsigned char)lane;
+      if (lane < hi - lo + 1) s_ustart[lane] = (short)below;
+      if (lane == 0) s_ustart[hi - lo + 1] = (short)n;
+      anyinv = (lane < n) ? inval : 0;
+      for (int off = 32; off > 0; off >>= 1) anyinv |= __shfl_xor(anyinv, off);
+      if (lane == 0) {
+        s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
+        s_misc[20] = anyinv;
+        int r = s_misc[19];
+        if (r < RUNS_MAX) hdr[8 + r] = s_misc[16]; else s_misc[18] = 1;
+        s_misc[19] = r + 1;
+      }
+    }
+    for (int i = tid; i < NEDGE * NU_MAX; i += CUR_THREADS) (&s_C[0][0])[i] = 0;
+    __syncthreads();
+    const int n_sl = s_misc[3], u_min = s_misc[4];
+    const int NU = s_misc[5] - u_min + 1;
+    const int NU8 = (NU + 7) & ~7, NB8 = NU8 >> 3;
+    const int edge_mask = s_misc[20];
+    const int cols_per_group = max(1, min(min(QTILES / (NJ * NB8), Q_CELLS / NJ), QCOLS));
+
+    for (int col0 = 0; col0 < ncol; col0 += cols_per_group) {
+      const int gcols = min(cols_per_group, ncol - col0);
+      const int ncell = gcols * NJ;
+      const int ntiles = ncell * NB8;
+      // this thread's tiles: (cell, 8-shift block), block index fastest
+      int tcell[2], tblk[2];
+      double acc[2][8];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int t = tid + r * CUR_THREADS;
+        tcell[r] = t < ntiles ? t / NB8 : -1;
+        tblk[r] = t < ntiles ? t - tcell[r] * NB8 : 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[r][q] = 0;
+      }
+      for (int n0 = 0; n0 < NQ; n0 += QNB) {
+        const int nb = min(QNB, NQ - n0);
+        __syncthreads();      // the previous batch's tables are no longer read
+        // ---- tables of this node batch: one task per (table bin, node), node fastest -------------------------------------------
+        {
+          const int nX = gcols * nb, nY = NJ * nb, nZ = NU * nb;
+          const int ntask = nX + nY + nZ;
+          for (int task = tid; task < ntask && (A.debug_phases & 1); task += CUR_THREADS) {
+            int kind, rel;
+            if (task < nX) { kind = 0; rel = task; }
+            else if (task < nX + nY) { kind = 1; rel = task - nX; }
+            else { kind = 2; rel = task - nX - nY; }
+            const int b = rel / nb, n = rel - b * nb;
+            const double sn = s_lo + 0.5 * qlen * (1.0 + gx_tab[n0 + n]);
+            if (kind == 0) {
+              const double cen = sn * uxr;
+              double sum = 0;
+              for (int k = s_colstart[col0 + b]; k < s_colstart[col0 + b + 1]; k++) {
+                const double d = s_dx[s_ixord[k]] - cen;
+                sum += exp(-d * d * i2T);
+              }
+              s_X[n][b] = sum;
+            } else if (kind == 1) {
+              const double cen = sn * uyr;
+              double sum = 0;
+              for (int k = s_jstart[b]; k < s_jstart[b + 1]; k++) {
+                const double d = s_dy[s_iyord[k]] - cen;
+                sum += exp(-d * d * i2T);
+              }
+              s_Y[n][b] = sum;
+            } else {
+              const double cen = sn * uzr;
+              double sum = 0, sumi = 0;
+              for (int k = s_ustart[b]; k < s_ustart[b + 1]; k++) {
+                const int sl = s_zord[k];
+                const double d = s_dz[sl] - cen;
+                const double e = exp(-d * d * i2L);
+                sum += e;
+                if (s_inval[sl]) sumi += e;      // refined per edge below when several edges are flagged
+              }
+              double wn = wscale * gw_tab[n0 + n];
+              if (kappa != 0.0) wn *= exp(-sn * sn * kappa);
+              s_Z[n][b] = wn * sum;
+              s_Zi[n][b] = wn * sumi;
+            }
+          }
+          // shifts beyond NU inside the last 8-block read as zero
+          for (int i = tid; i < nb * (NU8 - NU); i += CUR_THREADS) {
+            const int n = i / (NU8 - NU), u = NU + i % (NU8 - NU);
+            s_Z[n][u] = 0;
+          }
+        }
+        __syncthreads();
+        // ---- this batch's share of the bins -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          if (tcell[r] >= 0 && (A.debug_phases & 2)) {
+            const int col = tcell[r] / NJ, jj = tcell[r] - col * NJ;
+            const int u0 = tblk[r] * 8;
+            for (int n = 0; n < nb; n++) {
+              const double xy = s_X[n][col] * s_Y[n][jj];
+              const double* zr = &s_Z[n][u0];
+#pragma unroll
+              for (int q = 0; q < 8; q++) acc[r][q] = fma(xy, zr[q], acc[r][q]);
+            }
+          }
+        }
+        // ---- window-edge corrections: C_e[u] += sum_n Zi_e[n][u] * sum_cells X[n][col] Y[n][j] R[cell][edge_k[e]] ----------------
+        if (edge_mask && (A.debug_phases & 4)) {
+#pragma unroll
+          for (int e = 0; e < NEDGE; e++) {
+            if (!(edge_mask & (1 << e))) continue;
+            const bool single = (edge_mask & (edge_mask - 1)) == 0;   // one flagged edge: s_Zi already holds its table
+            if (!single) {
+              __syncthreads();
+              for (int task = tid; task < NU * nb; task += CUR_THREADS) {
+                const int b = task / nb, n = task - b * nb;
+                const double sn = s_lo + 0.5 * qlen * (1.0 + gx_tab[n0 + n]);
+                const double cen = sn * uzr;
+                double sumi = 0;
+                for (int k = s_ustart[b]; k < s_ustart[b + 1]; k++) {
+                  const int sl = s_zord[k];
+                  if (s_inval[sl] & (1 << e)) {
+                    const double d = s_dz[sl] - cen;
+                    sumi += exp(-d * d * i2L);
+                  }
+                }
+                double wn = wscale * gw_tab[n0 + n];
+                if (kappa != 0.0) wn *= exp(-sn * sn * kappa);
+                s_Zi[n][b] = wn * sumi;
+              }
+            }
+            {
+              // every wave takes the nodes n = wv, wv + 4, ..: one response read per cell serves all of them
+              double part[QNB / NWAVE];
+#pragma unroll
+              for (int m = 0; m < QNB / NWAVE; m++) part[m] = 0;
+              for (int cl = lane; cl < ncell; cl += 64) {
+                const int col = cl / NJ, jj = cl - col * NJ;
+                const double r = A.resp[((int64_t)s_coli[col0 + col] * A.nj + (jmin + jj)) * A.nk + edge_k[e]];
+#pragma unroll
+                for (int m = 0; m < QNB / NWAVE; m++) {
+                  const int n = wv + NWAVE * m;
+                  if (n < nb) part[m] = fma(s_X[n][col] * s_Y[n][jj], r, part[m]);
+                }
+              }
+#pragma unroll
+              for (int m = 0; m < QNB / NWAVE; m++) {
+                double p = part[m];
+                for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+                if (lane == 0 && wv + NWAVE * m < nb) s_Q[wv + NWAVE * m] = p;
+              }
+            }
+            __syncthreads();
+            if (tid < NU) {
+              double cv = s_C[e][tid];
+              for (int n = 0; n < nb; n++) cv = fma(s_Zi[n][tid], s_Q[n], cv);
+              s_C[e][tid] = cv;
+            }
+          }
+        }
+      }
+      // ---- active bins of every cell, items, pool offsets ---------------------------------------------------------------------------
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (tcell[r] >= 0) {
+          unsigned m = 0;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const bool in = tblk[r] * 8 + q < NU;
+            if (in && (do_prune ? acc[r][q] > thr : acc[r][q] != 0.0)) m |= 1u << q;
+          }
+          s_tmask[tid + r * CUR_THREADS] = (unsigned char)m;
+        }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        int nact = 0, nblk_tot = 0;
+        for (int base = 0; base < ncell; base += 64) {
+          const int cell = base + lane;
+          unsigned long long mk = 0;
+          if (cell < ncell)
+            for (int b8 = 0; b8 < NB8; b8++) mk |= (unsigned long long)s_tmask[cell * NB8 + b8] << (8 * b8);
+          const bool act = mk != 0;
+          const int ulo = act ? __ffsll((long long)mk) - 1 : 0, uhi = act ? 63 - __clzll((long long)mk) : 0;
+          unsigned long long am = __ballot(act);
+          int nb8 = act ? ((uhi - (ulo & ~7)) / 8 + 1) : 0;
+          int sc = nb8;
+          for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(sc, off);
+            if (lane >= off) sc += o;
+          }
+          if (cell < ncell) {
+            s_culo[cell] = act ? (unsigned char)ulo : (unsigned char)255;
+            s_cuhi[cell] = (unsigned char)uhi;
+            s_li[cell] = (unsigned short)(nact + __popcll(am & ((1ull << lane) - 1ull)));
+            s_boff[cell] = (unsigned short)(nblk_tot + sc - nb8);
+          }
+          nact += __popcll(am);
+          nblk_tot += __shfl(sc, 63);
+        }
+        if (lane == 0) {
+          s_misc[6] = nact;
+          s_misc[7] = nblk_tot;
+          int have = s_misc[16];
+          unsigned long long need = (unsigned long long)nblk_tot * 8ull;
+          unsigned long long base = 0;
+          const int item_cap = (A.split_max_items > 0 && A.split_max_items < IMAX) ? A.split_max_items : IMAX;
+          bool ok = (have + nact <= item_cap) && !s_misc[18];
+          if (ok && need) {
+            base = atomicAdd(S.cursor, need);
+            if (base + need > S.wbuf_cap) ok = false;
+          }
+          if (!ok) s_misc[18] = 1;
+          s_base64 = base;
+        }
+      }
+      __syncthreads();
+      if (!s_misc[18] && s_misc[6] > 0 && (A.debug_phases & 8)) {
+        const int have = s_misc[16];
+        const unsigned long long base = s_base64;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int cell = tcell[r];
+          if (cell < 0 || s_culo[cell] == 255) continue;
+          const int ulo = s_culo[cell], uhi = s_cuhi[cell];
+          const int ulo8 = ulo & ~7, u0 = tblk[r] * 8;
+          if (u0 < ulo8 || u0 > uhi) continue;
+          const unsigned long long wo = base + (unsigned long long)s_boff[cell] * 8ull;
+          double* dst = S.wbuf + wo + (u0 - ulo8);
+#pragma unroll
+          for (int q = 0; q < 8; q++) dst[q] = (u0 + q >= ulo && u0 + q <= uhi) ? acc[r][q] : 0.0;
+          if (u0 == ulo8) {
+            const int col = cell / NJ, jj = cell - col * NJ;
+            Item itx;
+            itx.cell_nblk = (s_coli[col0 + col] * A.nj + (jmin + jj)) | (((uhi - ulo8) / 8 + 1) << 16);
+            itx.sbase = u_min + ulo8;
+            itx.woff_lo = (uint32_t)(wo & 0xFFFFFFFFull);
+            itx.woff_hi = (uint32_t)(wo >> 32);
+            items[have + s_li[cell]] = itx;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0 && !s_misc[18]) s_misc[16] += s_misc[6];
+    }
+    // ---- window-edge corrections of this chunk -> (tick, value) list ------------------------------------------------
+    __syncthreads();
+    if (wv == 0 && edge_mask) {
+      for (int e = 0; e < NEDGE; e++) {
+        double cv = (lane < NU) ? s_C[e][lane] : 0.0;
+        int num = edge_k[e] - (u_min + lane);
+        bool ok = (edge_k[e] >= 0) && (lane < NU) && cv != 0.0 && num >= 0 && (num % M) == 0;
+        unsigned long long om = __ballot(ok);
+        int have = s_misc[17];
+        int cnt = __popcll(om);
+        if (have + cnt > CMAX) {
+          if (lane == 0) s_misc[18] = 1;
+        } else if (ok) {
+          Corr cr;
+          cr.tick = num / M;
+          cr.pad = 0;
+          cr.val = cv;
+          corr[have + __popcll(om & ((1ull << lane) - 1ull))] = cr;
+        }
+        if (lane == 0 && have + cnt <= CMAX) s_misc[17] = have + cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+    iz_next += n_sl;
+  }
+  if (tid == 0) atomicAdd(&A.counters[1], (unsigned long long)NQ);
+  __syncthreads();
+  if (tid == 0) {
+    hdr[0] = s_misc[18] ? 0 : s_misc[16];
+    hdr[1] = s_misc[18] ? 0 : s_misc[17];
+    hdr[2] = it0;
+    hdr[3] = T;
+    hdr[4] = it_w0;
+    hdr[5] = it_w1;
+    hdr[6] = s_misc[18] ? 0 : min(s_misc[19], RUNS_MAX);   // an overflowed pair exposes no runs to mac_kernel
+    hdr[7] = s_misc[18];            // 1 = capacity overflow: the monolithic kernel recomputes this pair
+    int r = min(s_misc[19], RUNS_MAX);
+    hdr[8 + r] = s_misc[16];
+    if (s_misc[18]) atomicAdd(&A.counters[6], 1ull);
+  }
+}
+
+extern "C++" int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M) {
+  if (S.c.n_pairs == 0) return 0;
+  if (!ctx->d_glx || !ctx->d_glw) {
+    ldsim_set_error("Gauss-Legendre tables missing");
+    return LDSIM_ESTATE;
+  }
+  if (M == 1)
+    hipLaunchKernelGGL(qweights_kernel<1>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, ctx->d_glx,
+                       ctx->d_glw, ctx->gl_nmax);
+  else
+    hipLaunchKernelGGL(qweights_kernel<2>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, ctx->d_glx,
+                       ctx->d_glw, ctx->gl_nmax);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -14,37 +14,7 @@
 // Pairs that exceed a per-pair capacity (items, corrections, runs) are flagged and recomputed by the monolithic
 // current_kernel (kernels_current.hip), which has no such limits.  The weight pool is sized by chain.hip from the
 // demand of earlier launches; a launch that exhausted it is repeated, never used.
-#include "current_common.h"
-
-// items per pair: 512 at M = 1 (mac_kernel<1> keeps the list in LDS); at M = 2 a 64-shift chunk covers half as many
-// slices (twice the runs, twice the items) and ndlar's pairs are heavier still -- mac_kernel<2> reads the list from HBM,
-// so the capacity only costs scratch memory (32 KB per pair)
-template <int M> struct ItemCap { static constexpr int value = M == 1 ? 512 : 2048; };
-#define CMAX 192        // edge corrections per pair
-#define RUNS_MAX 8      // sorted runs (slice chunks) per pair
-#define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
-#define W_ARENA 3072
-#define W_CELLS 512
-
-struct Item {
-  int32_t cell_nblk;   // cell | nblk << 16
-  int32_t sbase;       // response shift of weight[0]:  k = M*it + sbase + u
-  uint32_t woff_lo, woff_hi;
-};
-struct Corr {
-  int32_t tick, pad;
-  double val;
-};
-
-struct SplitArgs {
-  CurArgs c;
-  Item* items;            // [n_pairs][ItemCap<M>::value]
-  int32_t* hdr;           // [n_pairs][HDR_INTS]
-  Corr* corr;             // [n_pairs][CMAX]
-  double* wbuf;           // weight arena
-  unsigned long long wbuf_cap;   // doubles
-  unsigned long long* cursor;    // bump allocator (doubles)
-};
+#include "split_common.h"
 
 // =============================================================================================================
 template <int M>
@@ -109,7 +79,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
       s_icell[lane] = (short)i;
       s_jcell[lane] = (short)j;
       double ddx = x - g.sx, ddy = y - g.sy;
-      double iT2 = 1.0 / (g.sT * g.sT), i2T = 1.0 / (2 * g.sT * g.sT);
+      double iT2 = g.rT / g.sT2, i2T = 1.0 / (2 * g.sT * g.sT);   // _b: sigma*sigma as typed (detsim.py:116)
       s_px[lane][0] = ddx * iT2 * (g.Dx / g.Dr);
       s_px[lane][1] = ddx * ddx * i2T;
       s_py[lane][0] = ddy * iT2 * (g.Dy / g.Dr);
@@ -193,9 +163,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
   }
   const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
   const double i2T = 1.0 / (2 * g.sT * g.sT), i2L = 1.0 / (2 * g.sL * g.sL);
-  const double iL2 = 1.0 / (g.sL * g.sL);
+  const double iL2 = g.rL / g.sL2;
   const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
-  const double factor = g.q / g.Dr / (g.sT * g.sT * g.sL * sqrt(8 * M_PI * M_PI * M_PI));
+  const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
   const double sqrt_a_2 = 2 * sqrt(a);
   const double inv_sa2 = 1.0 / sqrt_a_2, inv4a = 1.0 / (4 * a);
   const double pref = factor * sqrt(M_PI) * inv_sa2 * g.dV;
@@ -751,6 +721,7 @@ extern "C++" int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void*
   const int M = split_M(ctx, args);
   if (!M) return 1;
   SplitArgs S = split_args(args, items, hdr, corr, wbuf, wbuf_cap, cursor);
+  if (ctx->weights_mode == 1) return qweights_launch(ctx, S, M);
   if (M == 1) hipLaunchKernelGGL(weights_kernel<1>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   else hipLaunchKernelGGL(weights_kernel<2>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   HIPCHK(hipGetLastError());

@@ -101,6 +101,42 @@ struct Tmp {
     }                              \
   } while (0)
 
+// Gauss-Legendre nodes and weights of every rule N = 1..nmax (Newton on P_N from the Chebyshev guess, long double):
+// rule N occupies entries [N(N-1)/2, N(N-1)/2 + N), nodes ascending.  Used by qweights_kernel (kernels_qweights.hip).
+static int make_gl_tables(ldsim_ctx* ctx, int nmax) {
+  const size_t total = (size_t)nmax * (nmax + 1) / 2;
+  std::vector<double> x(total), w(total);
+  const long double PI = 3.14159265358979323846264338327950288L;
+  for (int n = 1; n <= nmax; n++) {
+    const size_t off = (size_t)n * (n - 1) / 2;
+    for (int k = 0; k < (n + 1) / 2; k++) {
+      long double z = cosl(PI * (k + 0.75L) / (n + 0.5L)), pp = 1;
+      for (int it = 0; it < 100; it++) {
+        long double p1 = 1, p2 = 0;
+        for (int j = 1; j <= n; j++) {
+          long double p3 = p2;
+          p2 = p1;
+          p1 = ((2 * j - 1) * z * p2 - (j - 1) * p3) / j;
+        }
+        pp = n * (z * p1 - p2) / (z * z - 1);
+        long double z1 = z;
+        z = z1 - p1 / pp;
+        if (fabsl(z - z1) < 1e-19L) break;
+      }
+      const long double wt = 2 / ((1 - z * z) * pp * pp);
+      x[off + k] = (double)-z;
+      x[off + n - 1 - k] = (double)z;
+      w[off + k] = w[off + n - 1 - k] = (double)wt;
+    }
+  }
+  HIPCHK(hipMalloc((void**)&ctx->d_glx, total * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&ctx->d_glw, total * sizeof(double)));
+  HIPCHK(hipMemcpy(ctx->d_glx, x.data(), total * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_glw, w.data(), total * sizeof(double), hipMemcpyHostToDevice));
+  ctx->gl_nmax = nmax;
+  return 0;
+}
+
 // ---- context ------------------------------------------------------------------------------------------------------
 extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx** out) {
   NEED(consts && out, "null argument");
@@ -116,6 +152,7 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
   HIPCHK(hipStreamCreate(&ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+  CK(make_gl_tables(ctx, 256));
   *out = ctx;
   return ldsim_set_consts(ctx, consts);
 }
@@ -137,7 +174,8 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
-                  ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p,  ctx->d_pix_thr, ctx->d_pix_gain};
+                  ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p,  ctx->d_pix_thr, ctx->d_pix_gain,
+                  ctx->d_glx, ctx->d_glw};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : ctx->scratch)
@@ -164,6 +202,12 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
+  else if (!strcmp(name, "weights_mode")) { ctx->weights_mode = value != 0; ctx->wbuf_learned = 0; }
+  else if (!strcmp(name, "numba_f32")) ctx->numba_f32 = value != 0;
+  else if (!strcmp(name, "quad_max_nodes")) {
+    if (!(value >= 8 && value <= 256)) { ldsim_set_error("quad_max_nodes must be in [8, 256]"); return LDSIM_EINVAL; }
+    ctx->gl_nmax = (int)value;
+  }
   else {
     ldsim_set_error("unknown option %s", name);
     return LDSIM_EINVAL;

@@ -21,6 +21,7 @@ struct CurArgs {
   double prune_log;
   double tail_log;        // split path: samples below exp(-tail_log) of the peak density are evaluated in f32 (0 = off)
   int32_t debug_phases;
+  int32_t numba_f32;      // 1: the sub-expressions Numba types f32 for f4 record fields are evaluated in float (oracle: o_set_numba_f32)
   int32_t split_max_items;   // validation knob: pairs with more items than this take the monolithic kernel (0 = capacity)
   unsigned long long* counters;  // [0] ambiguous-rounding slices, [5] DFMA lanes, [6] pairs sent to the fallback
   const int32_t* only_flagged;   // if set: run only pairs whose only_flagged[pair*flag_stride + 7] != 0
@@ -63,4 +64,6 @@ int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void* items, void*
                          unsigned long long wbuf_cap, unsigned long long* cursor);
 int split_launch_mac(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
                      unsigned long long wbuf_cap, unsigned long long* cursor);
+struct SplitArgs;
+int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M);
 int split_sizes(const ldsim_ctx* ctx, const CurArgs& args, size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes);

@@ -107,6 +107,11 @@ struct ldsim_ctx {
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
   int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
   int split_max_items = 0;          // validation knob, see CurArgs
+  int weights_mode = 1;             // split path, weights stage: 1 = qweights_kernel (Gauss-Legendre along the segment), 0 = weights_kernel (per-sample closed form)
+  int numba_f32 = 0;                // 1: evaluate the sub-expressions Numba types f32 for f4 record fields in float
+  double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2
+  double* d_glw = nullptr;
+  int gl_nmax = 0;
   double wbuf_learned = 0;          // high-water demand per pair seen so far (x1.25): later calls size the pool with it
   int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments

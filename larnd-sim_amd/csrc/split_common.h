@@ -1,0 +1,35 @@
+// split_common.h -- records handed from the weights kernels (kernels_split.hip: per-sample weights_kernel,
+// kernels_qweights.hip: quadrature qweights_kernel) to mac_kernel.
+#pragma once
+#include "current_common.h"
+
+// items per pair: 512 at M = 1 (mac_kernel<1> keeps the list in LDS); at M = 2 a 64-shift chunk covers half as many
+// slices (twice the runs, twice the items) and ndlar's pairs are heavier still -- mac_kernel<2> reads the list from HBM,
+// so the capacity only costs scratch memory (32 KB per pair)
+template <int M> struct ItemCap { static constexpr int value = M == 1 ? 512 : 2048; };
+#define CMAX 192        // edge corrections per pair
+#define RUNS_MAX 8      // sorted runs (slice chunks) per pair
+#define HDR_INTS 24     // n_items, n_corr, it0, T, it_w0, it_w1, nruns, flags, run_start[9]
+#define W_ARENA 3072
+#define W_CELLS 512
+
+struct Item {
+  int32_t cell_nblk;   // cell | nblk << 16
+  int32_t sbase;       // response shift of weight[0]:  k = M*it + sbase + u
+  uint32_t woff_lo, woff_hi;
+};
+struct Corr {
+  int32_t tick, pad;
+  double val;
+};
+
+struct SplitArgs {
+  CurArgs c;
+  Item* items;            // [n_pairs][ItemCap<M>::value]
+  int32_t* hdr;           // [n_pairs][HDR_INTS]
+  Corr* corr;             // [n_pairs][CMAX]
+  double* wbuf;           // weight arena
+  unsigned long long wbuf_cap;   // doubles
+  unsigned long long* cursor;    // bump allocator (doubles)
+};
+

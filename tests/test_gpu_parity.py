@@ -796,25 +796,38 @@ def test_light_properties_baseline_event():
     assert np.array_equal(one.sum(axis=1) > 0, seen)
 
 
-@pytest.mark.parametrize("cfg,kind", [("module0", "dense"), ("ndlar", "golden")])
-def test_split_kernels_equal_monolithic(cfg, kind):
-    """weights_kernel + mac_kernel (default) vs the monolithic current_kernel on 2 x 600 segments: same hits,
-    charges equal to rounding (summation order differs), incl. an item cap that sends many pairs through the overflow
-    fallback.  A weight pool that starts far too small is grown and the launch repeated: bit-identical to a roomy one."""
+def _two_event_set(cfg, seed, n=1200):
     H.load_cfg(cfg)
-    seg = synth.make_segments(1200, seed=33, segs_per_event=600, spill=bool(consts.sim.IS_SPILL_SIM))
+    seg = synth.make_segments(n, seed=seed, segs_per_event=n // 2, spill=bool(consts.sim.IS_SPILL_SIM))
     if consts.sim.IS_SPILL_SIM:
         loc = seg["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
         for f in ("t0", "t0_start", "t0_end"):
             seg[f] = seg[f] - loc * consts.sim.SPILL_PERIOD
     batching.swap_coordinates(seg)
     bid, order, table = batching.assign_batches(seg)
-    seg, bid = seg[order], bid[order]
+    return seg[order], bid[order]
+
+
+def _reset_current_options():
+    for name, v in (("split_kernels", 1), ("weights_mode", 1), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
+                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0)):
+        lib.set_option(name, v)
+
+
+@pytest.mark.parametrize("cfg,kind", [("module0", "dense"), ("ndlar", "golden")])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_split_kernels_equal_monolithic(cfg, kind, mode):
+    """weights stage + mac_kernel (default) vs the monolithic current_kernel on 2 x 600 segments, for both weights stages
+    (weights_mode 1 = qweights_kernel, Gauss-Legendre along the segment; 0 = weights_kernel, the closed form per sample):
+    same hits, charges equal to rounding (summation order / quadrature differ), incl. an item cap that sends many pairs
+    through the overflow fallback.  A weight pool that starts far too small is grown and the launch repeated."""
+    seg, bid = _two_event_set(cfg, 33)
     ch = ChargeChain(H.response_for(kind))
     ch.upload(seg, bid)
     ch.quench_drift()
     res = {}
     try:
+        lib.set_option("weights_mode", mode)
         for name, split, cap, max_items in (("mono", 0, 6144, 0), ("split", 1, 65536, 0), ("tiny", 1, 50, 0),
                                             ("capped", 1, 6144, 60)):
             lib.set_option("split_kernels", split)
@@ -829,15 +842,13 @@ def test_split_kernels_equal_monolithic(cfg, kind):
             if name == "capped":
                 assert st.n_fallback > 0.2 * st.n_pairs   # the fallback really carried a good share
     finally:
-        lib.set_option("split_kernels", 1)
-        lib.set_option("wbuf_doubles_per_pair", 6144)
-        lib.set_option("split_max_items", 0)
+        _reset_current_options()
     a = res["mono"]
     assert (a["adc_list"] != 0).sum() > 100
-    # regrown pool == roomy pool: the same pairs take the same path, so only the order-dependent last bit of
-    # weights_kernel's LDS sums may move (see test_chain_properties_baseline_sizes)
+    # regrown pool == roomy pool: the same pairs take the same path.  qweights_kernel is bitwise reproducible (every bin
+    # is owned by one thread); weights_kernel's LDS atomics may move the last bit (see test_chain_properties_baseline_sizes)
     for k in res["split"]:
-        if k in ("adc_list", "current_fractions"):
+        if mode == 0 and k in ("adc_list", "current_fractions"):
             np.testing.assert_allclose(res["tiny"][k], res["split"][k], rtol=1e-12, atol=1e-15, err_msg=k)
         else:
             assert np.array_equal(res["split"][k], res["tiny"][k]), k
@@ -849,6 +860,92 @@ def test_split_kernels_equal_monolithic(cfg, kind):
         assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
         assert np.array_equal(a["adc_digit"], b["adc_digit"])
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("ndlar", "golden")])
+def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
+    """qweights_kernel hands pairs that need more Gauss-Legendre nodes than "quad_max_nodes" to the monolithic kernel
+    (the shipped cap of 256 covers segments up to ~130 Gaussian widths long): with a cap of 12 most pairs go that way and
+    the result must not change; prune_log = 0 (every bin kept) must not change it either; and two runs are bitwise equal."""
+    seg, bid = _two_event_set(cfg, 37)
+    ch = ChargeChain(H.response_for(kind))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    res = {}
+    try:
+        for name, cap, prune in (("default", 256, 30.0), ("again", 256, 30.0), ("cap12", 12, 30.0), ("keepall", 256, 0.0)):
+            lib.set_option("quad_max_nodes", cap)
+            lib.set_option("prune_log", prune)
+            st = ch.run(0, len(seg), want_fractions=True)
+            res[name] = ch.download()
+            if name == "default":
+                assert st.n_fallback < 0.01 * st.n_pairs
+                assert 6 <= st.n_samples / st.n_pairs < 64       # n_samples counts quadrature nodes in this mode
+            if name == "cap12":
+                assert st.n_fallback > 0.3 * st.n_pairs
+    finally:
+        _reset_current_options()
+    a = res["default"]
+    assert (a["adc_list"] != 0).sum() > 100
+    for k in a:
+        assert np.array_equal(a[k], res["again"][k]), f"{k}: not bitwise reproducible"
+    for name in ("cap12", "keepall"):
+        b = res[name]
+        assert np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"])
+        assert np.array_equal(a["adc_list"] != 0, b["adc_list"] != 0)
+        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=1e-9)
+        assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
+        assert np.array_equal(a["adc_digit"], b["adc_digit"])
+        np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_numba_f32_typing_mode_vs_oracle(mode):
+    """Option "numba_f32": the sub-expressions Numba types float32 for f4 record fields (detsim.py:74-79,116-118,141,387)
+    are evaluated in float, in both weights stages and the monolithic kernel; checked against the oracle's switch
+    (o_set_numba_f32) on the materialising tracks_current and through the fused chain."""
+    H.load_cfg("module0")
+    response = H.response_for("golden")
+    seg = synth.make_segments(24, seed=41, segs_per_event=24)
+    batching.swap_coordinates(seg)
+    ref = H.quench_drift(O, seg)
+    nmax = O.max_pixels(ref)
+    r = int(np.ceil(ref["tran_diff"].max() * 5 / consts.detector.PIXEL_PITCH))
+    P = (2 * r + 1) * nmax + (1 + 2 * r) * r * 2
+    _, neigh, nrad, _ = O.get_pixels(ref, nmax, P, r)
+    starts, T = O.time_intervals(ref)
+    plain = O.tracks_current(ref, neigh, T, response)
+    O.lib().o_set_numba_f32(1)
+    try:
+        typed = O.tracks_current(ref, neigh, T, response)
+    finally:
+        O.lib().o_set_numba_f32(0)
+    assert np.abs(typed - plain).max() > 0          # the switch really changes the waveforms
+    try:
+        lib.set_option("numba_f32", 1)
+        got = np.zeros_like(typed)
+        detsim.tracks_current[1, 1](got, neigh, ref, response)       # monolithic kernel (materialising stage call)
+        H.assert_wave_close(got, typed, what="numba_f32 stage call")
+        # fused chain (weights stage `mode` + mac_kernel) on the same records: compare the pixel charges with a chain
+        # assembled from the typed oracle waveforms
+        lib.set_option("weights_mode", mode)
+        ch = ChargeChain(response)
+        ch.upload(ref, np.zeros(len(ref), dtype=np.int32))
+        st = ch.run(0, len(ref), want_fractions=False)
+        out = ch.download()
+    finally:
+        _reset_current_options()
+    upix = O.unique_pixels(neigh)
+    pim = O.pixel_index_map(neigh, upix)
+    tpm = O.track_pixel_map(upix, neigh, nrad, int(nrad.max()) + 1, consts.sim.MAX_TRACKS_PER_PIXEL)
+    ps, pts, _ = O.sum_pixel_signals(typed, starts, pim, tpm, len(upix))
+    tt = np.linspace(0, consts.detector.TIME_INTERVAL[1], ps.shape[1] + 1)
+    adc, ticks, _ = O.get_adc_values(ps, pts, tt, np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD))
+    assert np.array_equal(upix, out["unique_pix"])
+    assert np.array_equal(adc != 0, out["adc_list"] != 0) and (adc != 0).sum() > 10
+    np.testing.assert_allclose(out["adc_list"], adc, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(ticks, out["adc_ticks_list"])
+    assert np.array_equal(O.digitize(adc), out["adc_digit"])
 
 
 @pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("ndlar", "golden")])
@@ -870,12 +967,13 @@ def test_f32_tail_class_equals_all_f64(cfg, kind):
     ch.quench_drift()
     res = {}
     try:
+        lib.set_option("weights_mode", 0)      # the tail class belongs to the per-sample weights_kernel
         for tl in (0.0, 14.0):
             lib.set_option("tail_log", tl)
             ch.run(0, len(seg), want_fractions=True)
             res[tl] = ch.download()
     finally:
-        lib.set_option("tail_log", 14.0)
+        _reset_current_options()
     a, b = res[0.0], res[14.0]
     assert (a["adc_list"] != 0).sum() > 100
     assert np.array_equal(a["unique_pix"], b["unique_pix"])
