@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 2
+#define LDSIM_ABI_VERSION 3
 
 /* error codes */
 #define LDSIM_OK 0
@@ -258,6 +258,30 @@ int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, 
 /* Device pointers of the last chain call's compact hit list (for a collective without a host round trip):
  * hits are (batch i32, pixel i32, adc u8-as-i32, tick f64) rows for every written ADC slot. */
 int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes);
+
+/* ---- device-resident light leg (cli/simulate_pixels.py:749-797 and :1120-1153 on the resident segments) ---------- */
+/* lightLUT.calculate_light_incidence[bpg,tpb](tracks, lut, light_sim_dat, track_light_voxel) over ALL resident segments,
+ * after ldsim_dev_quench_drift (it needs n_photons and pixel_plane): n_photons_det [n][n_out] f4, t0_det [n][n_out] f4
+ * (LIGHT_TRIG_MODE 0 only) and voxel [n][3] i4 stay in HBM; segments outside every TPC hold zeros. */
+int ldsim_dev_light_incidence(ldsim_ctx* ctx, int32_t n_out_channels);
+/* rows [seg_begin, seg_end) of those arrays to host; any pointer may be NULL */
+int ldsim_dev_light_incidence_download(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* n_photons_det,
+                                       float* t0_det, int32_t* voxel);
+/* inputs of light_sim.get_nticks (larndsim/light_sim.py:24-41) for the rows of one batch: min / max of t0_det over the
+ * entries with n_photons_det > 0, and whether there is any (trigger mode 0) */
+int ldsim_dev_light_t0_range(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* t0_min, float* t0_max,
+                             int32_t* any);
+/* light_sim.sum_light_signals[...] for the resident segments [seg_begin, seg_end) (one batch of the reference's loop):
+ * light_sample_inc [n_det][n_ticks] f4 and, with max_truth = MAX_MC_TRUTH_IDS > 0, the truth slots [n_det][n_ticks][max_truth]
+ * (i8 ids from segment_track_id[seg_end - seg_begin], f8 photons) are initialised (0 / -1) and filled in HBM.  Segments are
+ * visited per detector in descending n_photons_det like the driver's argsort (cli/simulate_pixels.py:1141-1144; equal
+ * values, which numpy's unstable sort leaves unpinned, by descending index). */
+int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, const int32_t* op_channel, int32_t n_det,
+                        const int64_t* segment_track_id, int32_t max_truth, double start_time, int32_t n_ticks);
+/* results of the last ldsim_dev_sum_light to host; any pointer may be NULL */
+int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* true_track_id, double* true_photons);
+/* HIP-event durations of the last ldsim_dev_light_incidence launch and the last ldsim_dev_sum_light call */
+int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms);
 
 /* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
 int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);

@@ -94,19 +94,25 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   unsigned long long* counters = (unsigned long long*)(misc + 256);
   HIPCHK(hipMemsetAsync(misc, 0, 512, st));
 
-  // batch id range of this call (ids are non-decreasing; negative = skip)
+  // batch id range of this call: the non-negative ids are non-decreasing (checked at upload against the host copy kept
+  // in the ctx), so the first and the last one are the range; negative = not simulated
   int32_t b_first = 0, b_last = 0;
   {
-    std::vector<int32_t> hb(n);
-    HIPCHK(hipMemcpyAsync(hb.data(), ctx->seg.batch + seg_begin, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    bool any = false;
-    for (int64_t i = 0; i < n; i++)
-      if (hb[i] >= 0) {
-        if (!any) { b_first = hb[i]; any = true; }
-        b_last = hb[i];
-      }
-    if (!any) return 0;
+    if ((int64_t)ctx->h_batch.size() < seg_end) {
+      ldsim_set_error("resident batch ids missing: ldsim_segments_upload first");
+      return LDSIM_ESTATE;
+    }
+    const int32_t* hb = ctx->h_batch.data() + seg_begin;
+    int64_t i0 = 0, i1 = n - 1;
+    while (i0 < n && hb[i0] < 0) i0++;
+    if (i0 == n) return 0;
+    while (hb[i1] < 0) i1--;
+    b_first = hb[i0];
+    b_last = hb[i1];
+    if (b_last < b_first) {
+      ldsim_set_error("batch ids of the resident segments are not non-decreasing");
+      return LDSIM_EINVAL;
+    }
   }
   const int32_t batch0 = b_first;
   const int64_t n_batches = (int64_t)b_last - b_first + 1;

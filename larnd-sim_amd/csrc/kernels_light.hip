@@ -1,6 +1,20 @@
 // kernels_light.hip -- a17 lightLUT.calculate_light_incidence (larndsim/lightLUT.py:15-136) and
-// a18 light_sim.sum_light_signals (larndsim/light_sim.py:58-129).
+// a18 light_sim.sum_light_signals (larndsim/light_sim.py:58-129), for host-buffer stage calls and for the
+// device-resident light leg (ldsim_dev_light_incidence / ldsim_dev_sum_light).
 // The LUT is held as SoA planes (vis, t0, t0_avg, time_dist) instead of the reference's structured array.
+//
+// a17: a workgroup owns a tile of consecutive segments; 1 thread per segment finds the voxel (lightLUT.py:15-63) once,
+//      then all threads stream the tile's [segment][channel] outputs in one coalesced run (the write dominates:
+//      8 or 4 bytes per (segment, channel)).
+// a18: the reference gives every (detector, tick) a thread that walks ALL segments.  Here the work is proportional to
+//      the photons that actually arrive:
+//      * without truth slots (MAX_MC_TRUTH_IDS = 0): sum_light_scatter_kernel -- a workgroup per (detector, tick tile)
+//        keeps the tile in LDS as f64 and its threads deposit the batch's contributions;
+//      * with truth slots: every (segment, detector) emits its contributions as records keyed by
+//        (detector, tick, position of the segment in the detector's descending-photons order, profile bin); one stable
+//        radix sort puts each (detector, tick) cell's records in the order the reference's loop visits them
+//        (light_sim.py:86,99) and one thread per cell replays them: same f4 accumulation order, same first-come
+//        truth slots (light_sim.py:103-110,119-127).
 #include "ldsim_dev.h"
 
 __device__ __forceinline__ void get_voxel(const LdsimConsts* c, double x, double y, double z, int itpc, int nx, int ny,
@@ -17,189 +31,363 @@ __device__ __forceinline__ void get_voxel(const LdsimConsts* c, double x, double
   k = min(nz - 1, max(0, k));
 }
 
-// one thread per (segment, output channel): the N x n_op x 8 B output write dominates, keep it coalesced
-__global__ void __launch_bounds__(256) light_incidence_kernel(SegStore s, const LdsimConsts* __restrict__ c,
-                                                              const float* __restrict__ vis, const float* __restrict__ t0lut,
-                                                              int nx, int ny, int nz, int ndet,
-                                                              const double* __restrict__ eff, const int32_t* __restrict__ ch2tpc,
-                                                              int n_out, float* __restrict__ nph, float* __restrict__ t0det,
-                                                              int32_t* __restrict__ voxel) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= s.n * n_out) return;
-  int64_t it = idx / n_out;
-  int o = (int)(idx % n_out);
-  int itpc = s.pixel_plane[it];
-  if (itpc == c->default_plane_index || itpc < 0 || itpc >= c->n_tpc) return;
-  int i, j, k;
-  get_voxel(c, s.f[LDSIM_X][it], s.f[LDSIM_Y][it], s.f[LDSIM_Z][it], itpc, nx, ny, nz, i, j, k);
-  if (o == 0) {
-    voxel[it * 3 + 0] = i;
-    voxel[it * 3 + 1] = j;
-    voxel[it * 3 + 2] = k;
-  }
-  int imod = itpc / 2;
-  int channel_offset = (n_out < c->n_op_channel) ? n_out * imod : 0;
-  int op = o + channel_offset, li = o % ndet;
-  int64_t vb = (((int64_t)i * ny + j) * nz + k) * ndet + li;
-  double v = (double)vis[vb] * (ch2tpc[op] == itpc ? 1 : 0);
-  nph[idx] = (float)(eff[op] * v * s.f[LDSIM_N_PHOTONS][it]);
-  if (c->light_trig_mode == 0) {
-    const double ns = 1.0, mus = 1e-6 * 1e9;
-    t0det[idx] = (float)(((double)t0lut[vb] * ns + s.f[LDSIM_T0][it] * mus) / mus);
-  }
-}
-
-// literal (detector, tick) thread like the reference: f32 accumulator updated in sorted_indices order
-__global__ void __launch_bounds__(64) sum_light_signals_kernel(SegStore s, const LdsimConsts* __restrict__ c,
-                                                               const int32_t* __restrict__ voxel,
-                                                               const int64_t* __restrict__ track_id,
-                                                               const float* __restrict__ nph, int n_inc,
-                                                               const int32_t* __restrict__ op_channel, int n_det,
-                                                               const float* __restrict__ t0_avg,
-                                                               const float* __restrict__ time_dist, int ny, int nz,
-                                                               int ndet_lut, int nprof, double start_time,
-                                                               const int32_t* __restrict__ sorted_idx, int64_t n_ticks,
-                                                               float* __restrict__ out, int64_t* __restrict__ true_id,
-                                                               double* __restrict__ true_ph, int max_truth) {
-  int idet = blockIdx.x;
-  int64_t itick = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (idet >= n_det || itick >= n_ticks) return;
-  const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
-  const int64_t n = s.n;
-  double st = itick * tick + start_time, en = st + tick;
-  int opch = op_channel[idet];
-  int idet_lut = opch % ndet_lut;
-  float acc = out[(int64_t)idet * n_ticks + itick];
-  for (int64_t q = 0; q < n; q++) {
-    int64_t itrk = sorted_idx[(int64_t)idet * n + q];
-    float ph = nph[itrk * n_inc + opch];
-    if (!(ph > 0)) continue;
-    double track_time = s.f[LDSIM_T0][itrk];
-    double track_end = track_time + nprof * ns / mus;
-    if (track_end < st || track_time > en) continue;
-    const int32_t* vx = voxel + itrk * 3;
-    int64_t lb = ((((int64_t)vx[0] * ny + vx[1]) * nz + vx[2]) * ndet_lut + idet_lut);
-    if (c->enable_lut_smearing) {
-      const float* prof = time_dist + lb * nprof;
-      for (int ip = 0; ip < nprof; ip++) {
-        double pt = track_time + ip * ns / mus;
-        if (pt < en && pt > st) {
-          double photons = (double)ph * (double)prof[ip] / tick;
-          acc = (float)((double)acc + photons);
-          if (photons > c->mc_truth_threshold)
-            for (int k = 0; k < max_truth; k++) {
-              int64_t* tid = &true_id[((int64_t)idet * n_ticks + itick) * max_truth + k];
-              if (*tid == -1 || *tid == track_id[itrk]) {
-                *tid = track_id[itrk];
-                true_ph[((int64_t)idet * n_ticks + itick) * max_truth + k] += photons;
-                break;
-              }
-            }
-        }
-      }
+#define LI_SEGS 32     // segments per workgroup tile
+// Outputs are [n][n_out] relative to seg0.  `fill` = 1: segments outside every TPC get zeros (resident arrays are not
+// pre-filled by a caller); 0: they are left untouched like the reference (lightLUT.py:86-88) for caller-owned arrays.
+__global__ void __launch_bounds__(256) light_incidence_kernel(SegStore s, const LdsimConsts* __restrict__ c, int64_t seg0,
+                                                              int64_t n, const float* __restrict__ vis,
+                                                              const float* __restrict__ t0lut, int nx, int ny, int nz,
+                                                              int ndet, const double* __restrict__ eff,
+                                                              const int32_t* __restrict__ ch2tpc, int n_out,
+                                                              float* __restrict__ nph, float* __restrict__ t0det,
+                                                              int32_t* __restrict__ voxel, int fill) {
+  __shared__ int64_t s_vb[LI_SEGS];
+  __shared__ int s_tpc[LI_SEGS];
+  __shared__ double s_np[LI_SEGS], s_t0[LI_SEGS];
+  const int64_t r0 = (int64_t)blockIdx.x * LI_SEGS;
+  const int nt = (int)min((int64_t)LI_SEGS, n - r0);
+  if (nt <= 0) return;
+  if (threadIdx.x < nt) {
+    const int64_t r = r0 + threadIdx.x, it = seg0 + r;
+    int itpc = s.pixel_plane[it];
+    if (itpc == c->default_plane_index || itpc < 0 || itpc >= c->n_tpc) {
+      itpc = -1;
+      if (fill) { voxel[r * 3 + 0] = 0; voxel[r * 3 + 1] = 0; voxel[r * 3 + 2] = 0; }
     } else {
-      double pt = track_time + (double)t0_avg[lb] * ns / mus;
-      if (pt < en && pt > st) {
-        double photons = (double)ph / tick;
-        acc = (float)((double)acc + photons);
-        if (photons > c->mc_truth_threshold)
-          for (int k = 0; k < max_truth; k++) {
-            int64_t* tid = &true_id[((int64_t)idet * n_ticks + itick) * max_truth + k];
-            if (*tid == -1 || *tid == track_id[itrk]) {
-              *tid = track_id[itrk];
-              true_ph[((int64_t)idet * n_ticks + itick) * max_truth + k] += photons;
-              break;
-            }
-          }
-      }
+      int i, j, k;
+      get_voxel(c, s.f[LDSIM_X][it], s.f[LDSIM_Y][it], s.f[LDSIM_Z][it], itpc, nx, ny, nz, i, j, k);
+      voxel[r * 3 + 0] = i;
+      voxel[r * 3 + 1] = j;
+      voxel[r * 3 + 2] = k;
+      s_vb[threadIdx.x] = (((int64_t)i * ny + j) * nz + k) * ndet;
+      s_np[threadIdx.x] = s.f[LDSIM_N_PHOTONS][it];
+      s_t0[threadIdx.x] = s.f[LDSIM_T0][it];
     }
+    s_tpc[threadIdx.x] = itpc;
   }
-  out[(int64_t)idet * n_ticks + itick] = acc;
+  __syncthreads();
+  const bool trig0 = c->light_trig_mode == 0;
+  const double ns = 1.0, mus = 1e-6 * 1e9;
+  // flat walk over the tile's [segment][channel] block: consecutive threads write consecutive addresses
+  int sl = (int)(threadIdx.x / n_out), o = (int)(threadIdx.x % n_out);
+  const int dsl = 256 / n_out, d_o = 256 % n_out;
+  while (sl < nt) {
+    const int64_t idx = (r0 + sl) * (int64_t)n_out + o;
+    const int itpc = s_tpc[sl];
+    if (itpc >= 0) {
+      const int channel_offset = (n_out < c->n_op_channel) ? n_out * (itpc / 2) : 0;
+      const int op = o + channel_offset;
+      const int64_t vb = s_vb[sl] + (o % ndet);
+      const double v = (double)vis[vb] * (ch2tpc[op] == itpc ? 1 : 0);
+      nph[idx] = (float)(eff[op] * v * s_np[sl]);
+      if (trig0) t0det[idx] = (float)(((double)t0lut[vb] * ns + s_t0[sl] * mus) / mus);
+    } else if (fill) {
+      nph[idx] = 0.f;
+      if (trig0) t0det[idx] = 0.f;
+    }
+    sl += dsl;
+    o += d_o;
+    if (o >= n_out) { o -= n_out; sl++; }
+  }
 }
 
+// min / max of t0_det over the entries with n_photons_det > 0 (light_sim.get_nticks, light_sim.py:34-39), as ordered ints
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__global__ void __launch_bounds__(256) light_t0_range_kernel(const float* __restrict__ nph, const float* __restrict__ t0det,
+                                                             int64_t total, int* __restrict__ res) {
+  int lo = 0x7fffffff, hi = (int)0x80000000, any = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    if (nph[i] > 0) {
+      const int v = f2ord(t0det[i]);
+      lo = min(lo, v);
+      hi = max(hi, v);
+      any = 1;
+    }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off));
+    hi = max(hi, __shfl_xor(hi, off));
+    any |= __shfl_xor(any, off);
+  }
+  if ((threadIdx.x & 63) == 0 && any) {
+    atomicMin(&res[0], lo);
+    atomicMax(&res[1], hi);
+    atomicOr(&res[2], 1);
+  }
+}
 
-// Scatter form of the photon sum for the (default) case without truth slots: one workgroup per (detector, tick tile)
-// keeps the tile in LDS as f64 and every thread walks its share of the segments, adding each contribution to the one
-// tick whose (start, end) window the reference's strict inequalities select (candidates it-1, it, it+1 are tested with
-// the reference's own expressions).  Work is O(n_det * tiles * S + contributions) instead of O(n_det * n_ticks * S).
-// The accumulation order differs from the reference's sorted loop, so the f32 result can differ in the last bits.
+struct LightSum {
+  SegStore s;
+  const LdsimConsts* c;
+  int64_t seg0, n;                // resident range; per-segment arrays below are relative to seg0
+  const int32_t* voxel;           // [n][3]
+  const float* nph;               // [n][n_inc]
+  int n_inc;
+  const int32_t* op_channel;      // [n_det]
+  int n_det;
+  const float* t0_avg;
+  const float* time_dist;
+  int ny, nz, ndet_lut, nprof;
+  double start_time;
+  int64_t n_ticks;
+};
+
+// every photon deposit of (segment r, detector row idet), in the reference's order (profile bin ascending);
+// f(tick, profile bin, photons).  The tick is the one whose open window (start, end) holds the arrival time, tested
+// with the reference's own expressions on the three candidates around floor((t - start) / tick) (light_sim.py:81-82,100,117)
+template <class F>
+__device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int idet, F f) {
+  const LdsimConsts* c = L.c;
+  const int opch = L.op_channel[idet];
+  const float ph = L.nph[r * L.n_inc + opch];
+  if (!(ph > 0)) return;
+  const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
+  const double track_time = L.s.f[LDSIM_T0][L.seg0 + r];
+  const double track_end = track_time + L.nprof * ns / mus;
+  const int32_t* vx = L.voxel + r * 3;
+  const int64_t lb = ((((int64_t)vx[0] * L.ny + vx[1]) * L.nz + vx[2]) * L.ndet_lut + (opch % L.ndet_lut));
+  auto at = [&](double pt, int ip, double photons) {
+    const double fl = floor((pt - L.start_time) / tick);
+    if (!(fl > -2.0 && fl < (double)L.n_ticks + 1.0)) return;
+    const int64_t it0 = (int64_t)fl;
+    for (int64_t it = it0 - 1; it <= it0 + 1; it++) {
+      if (it < 0 || it >= L.n_ticks) continue;
+      const double st = it * tick + L.start_time, en = st + tick;
+      if (track_end < st || track_time > en) continue;
+      if (pt < en && pt > st) f(it, ip, photons);
+    }
+  };
+  if (c->enable_lut_smearing) {
+    const float* prof = L.time_dist + lb * L.nprof;
+    // photons = n_photons_det * time_profile[iprof] / LIGHT_TICK_SIZE: Numba types the f4 * f4 product f4 (light_sim.py:100)
+    for (int ip = 0; ip < L.nprof; ip++) {
+      const float pp = ph * prof[ip];
+      at(track_time + ip * ns / mus, ip, (double)pp / tick);
+    }
+  } else {
+    at(track_time + (double)L.t0_avg[lb] * ns / mus, 0, (double)ph / tick);
+  }
+}
+
+// ---- without truth slots: scatter into an LDS tick tile ------------------------------------------------------------------
+// The accumulation order differs from the reference's sorted loop (f64 tile, one f4 rounding at the end), so the f4
+// result can differ from the reference's in the last bits.
 #define LTILE 8192
-__global__ void __launch_bounds__(256) sum_light_scatter_kernel(SegStore s, const LdsimConsts* __restrict__ c,
-                                                                const int32_t* __restrict__ voxel,
-                                                                const float* __restrict__ nph, int n_inc,
-                                                                const int32_t* __restrict__ op_channel, int n_det,
-                                                                const float* __restrict__ t0_avg,
-                                                                const float* __restrict__ time_dist, int ny, int nz,
-                                                                int ndet_lut, int nprof, double start_time,
-                                                                int64_t n_ticks, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) sum_light_scatter_kernel(LightSum L, float* __restrict__ out) {
   __shared__ double acc[LTILE];
   const int idet = blockIdx.x;
   const int64_t tile0 = (int64_t)blockIdx.y * LTILE;
-  const int tlen = (int)min((int64_t)LTILE, n_ticks - tile0);
-  if (idet >= n_det || tlen <= 0) return;
-  const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
+  const int tlen = (int)min((int64_t)LTILE, L.n_ticks - tile0);
+  if (idet >= L.n_det || tlen <= 0) return;
   for (int i = threadIdx.x; i < tlen; i += 256) acc[i] = 0;
   __syncthreads();
-  const int opch = op_channel[idet];
-  const int idet_lut = opch % ndet_lut;
-  auto deposit = [&](double pt, double photons) {
-    double f = floor((pt - start_time) / tick);
-    if (!(f > -2.0 && f < (double)n_ticks + 1.0)) return;
-    int64_t it0 = (int64_t)f;
-    for (int64_t it = it0 - 1; it <= it0 + 1; it++) {
-      if (it < tile0 || it >= tile0 + tlen) continue;
-      double st = it * tick + start_time, en = st + tick;
-      if (pt < en && pt > st) atomicAdd(&acc[it - tile0], photons);
-    }
-  };
-  for (int64_t itrk = threadIdx.x; itrk < s.n; itrk += 256) {
-    float ph = nph[itrk * n_inc + opch];
-    if (!(ph > 0)) continue;
-    double track_time = s.f[LDSIM_T0][itrk];
-    const int32_t* vx = voxel + itrk * 3;
-    int64_t lb = ((((int64_t)vx[0] * ny + vx[1]) * nz + vx[2]) * ndet_lut + idet_lut);
-    if (c->enable_lut_smearing) {
-      const float* prof = time_dist + lb * nprof;
-      for (int ip = 0; ip < nprof; ip++) {
-        float p = prof[ip];
-        if (p != 0.f) deposit(track_time + ip * ns / mus, (double)ph * (double)p / tick);
+  int touched = 0;
+  for (int64_t r = threadIdx.x; r < L.n; r += 256)
+    light_deposits(L, r, idet, [&](int64_t it, int, double photons) {
+      if (it >= tile0 && it < tile0 + tlen && photons != 0.0) {
+        atomicAdd(&acc[it - tile0], photons);
+        touched = 1;
       }
-    } else {
-      deposit(track_time + (double)t0_avg[lb] * ns / mus, (double)ph / tick);
-    }
-  }
-  __syncthreads();
+    });
+  if (!__syncthreads_or(touched)) return;      // nothing arrived in this tile: the output keeps what it holds
   for (int i = threadIdx.x; i < tlen; i += 256) {
-    int64_t o = (int64_t)idet * n_ticks + tile0 + i;
-    out[o] = (float)((double)out[o] + acc[i]);
+    const int64_t o = (int64_t)idet * L.n_ticks + tile0 + i;
+    if (acc[i] != 0.0) out[o] = (float)((double)out[o] + acc[i]);
   }
 }
 
+// ---- with truth slots: records sorted into the reference's visiting order --------------------------------------------------------
+#define LK_TICK_BITS 16
+#define LK_RANK_BITS 20
+#define LK_IP_BITS 7
+// rank[idet][r] = position of segment r in sorted_indices[idet] (stage call: the caller's order)
+__global__ void light_rank_from_sorted_kernel(const int32_t* __restrict__ sorted_idx, int n_det, int64_t n,
+                                              int32_t* __restrict__ rank) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)n_det * n) return;
+  const int64_t idet = p / n, q = p - idet * n;
+  const int32_t r = sorted_idx[p];
+  if (r >= 0 && r < n) rank[idet * n + r] = (int32_t)q;
+}
+// resident path: order of cli/simulate_pixels.py:1141-1144, np.argsort(n_photons_det)[::-1] per detector: descending
+// photons; equal photons (the reference's sort is not stable, their order is unpinned) by descending segment index
+__global__ void light_order_keys_kernel(LightSum L, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)L.n_det * L.n) return;
+  const int64_t idet = p / L.n, r = p - idet * L.n;
+  const float ph = L.nph[r * L.n_inc + L.op_channel[idet]];
+  const unsigned int bits = ph > 0 ? ~(unsigned int)__float_as_int(ph) : 0xFFFFFFFFu;
+  keys[p] = ((unsigned long long)idet << 52) | ((unsigned long long)bits << LK_RANK_BITS) |
+            (unsigned long long)((~(unsigned int)r) & ((1u << LK_RANK_BITS) - 1));
+  vals[p] = (int32_t)r;
+}
+__global__ void light_rank_from_order_kernel(const int32_t* __restrict__ vals, int n_det, int64_t n,
+                                             int32_t* __restrict__ rank) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)n_det * n) return;
+  const int64_t idet = p / n;
+  rank[idet * n + vals[p]] = (int32_t)(p - idet * n);
+}
+// one thread per (segment, detector): number of deposits
+__global__ void light_count_kernel(LightSum L, int32_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L.n * L.n_det) return;
+  const int64_t r = p / L.n_det;
+  const int idet = (int)(p - r * L.n_det);
+  int cnt = 0;
+  light_deposits(L, r, idet, [&](int64_t, int, double) { cnt++; });
+  count[p] = cnt;
+}
+__global__ void light_fill_kernel(LightSum L, const int32_t* __restrict__ offs, const int32_t* __restrict__ rank,
+                                  unsigned long long* __restrict__ keys, int32_t* __restrict__ vals,
+                                  int32_t* __restrict__ rec_seg, double* __restrict__ rec_ph) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L.n * L.n_det) return;
+  const int64_t r = p / L.n_det;
+  const int idet = (int)(p - r * L.n_det);
+  int64_t w = offs[p];
+  const unsigned long long rk = (unsigned long long)(unsigned int)rank[(int64_t)idet * L.n + r];
+  light_deposits(L, r, idet, [&](int64_t it, int ip, double photons) {
+    keys[w] = ((unsigned long long)idet << (LK_TICK_BITS + LK_RANK_BITS + LK_IP_BITS)) |
+              ((unsigned long long)it << (LK_RANK_BITS + LK_IP_BITS)) | (rk << LK_IP_BITS) | (unsigned long long)ip;
+    vals[w] = (int32_t)w;
+    rec_seg[w] = (int32_t)r;
+    rec_ph[w] = photons;
+    w++;
+  });
+}
+// one thread per (detector, tick) cell that received something: replay its records in order (light_sim.py:101-110,118-127)
+__global__ void light_replay_kernel(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
+                                    const int32_t* __restrict__ rec_seg, const double* __restrict__ rec_ph, int64_t n_rec,
+                                    const int64_t* __restrict__ track_id, int64_t n_ticks, double truth_threshold,
+                                    float* __restrict__ out, int64_t* __restrict__ true_id, double* __restrict__ true_ph,
+                                    int max_truth) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const int SH = LK_RANK_BITS + LK_IP_BITS;
+  const unsigned long long cell = keys[i] >> SH;
+  if (i > 0 && (keys[i - 1] >> SH) == cell) return;
+  const int64_t idet = (int64_t)(cell >> LK_TICK_BITS), it = (int64_t)(cell & ((1u << LK_TICK_BITS) - 1));
+  const int64_t o = idet * n_ticks + it;
+  float acc = out[o];
+  for (int64_t j = i; j < n_rec && (keys[j] >> SH) == cell; j++) {
+    const int32_t w = vals[j];
+    const double photons = rec_ph[w];
+    acc = (float)((double)acc + photons);
+    if (photons > truth_threshold) {
+      const int64_t id = track_id[rec_seg[w]];
+      for (int k = 0; k < max_truth; k++) {
+        int64_t* tid = &true_id[o * max_truth + k];
+        if (*tid == -1 || *tid == id) {
+          *tid = id;
+          true_ph[o * max_truth + k] += photons;
+          break;
+        }
+      }
+    }
+  }
+  out[o] = acc;
+}
+
 extern "C++" {
-int light_launch_incidence(ldsim_ctx* ctx, int n_out, float* nph, float* t0det, int32_t* voxel) {
-  int64_t total = ctx->seg.n * n_out;
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(light_incidence_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg,
-                     ctx->d_consts, ctx->d_lut_vis, ctx->d_lut_t0, ctx->lut_nx, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet,
-                     ctx->d_eff, ctx->d_ch2tpc, n_out, nph, t0det, voxel);
+int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
+int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
+static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
+
+int light_launch_incidence(ldsim_ctx* ctx, int64_t seg0, int64_t n, int n_out, float* nph, float* t0det, int32_t* voxel,
+                           int fill) {
+  if (n == 0 || n_out == 0) return 0;
+  hipLaunchKernelGGL(light_incidence_kernel, dim3((unsigned)((n + LI_SEGS - 1) / LI_SEGS)), dim3(256), 0, ctx->stream,
+                     ctx->seg, ctx->d_consts, seg0, n, ctx->d_lut_vis, ctx->d_lut_t0, ctx->lut_nx, ctx->lut_ny,
+                     ctx->lut_nz, ctx->lut_ndet, ctx->d_eff, ctx->d_ch2tpc, n_out, nph, t0det, voxel, fill);
   HIPCHK(hipGetLastError());
   return 0;
 }
-int light_launch_sum(ldsim_ctx* ctx, const int32_t* voxel, const int64_t* track_id, const float* nph, int n_inc,
-                     const int32_t* op_channel, int n_det, const int32_t* sorted_idx, double start_time, int64_t n_ticks,
-                     float* out, int64_t* true_id, double* true_ph, int max_truth) {
-  if (n_det == 0 || n_ticks == 0) return 0;
+
+int light_launch_t0_range(ldsim_ctx* ctx, const float* nph, const float* t0det, int64_t total, int* d_res) {
+  const int init[3] = {0x7fffffff, (int)0x80000000, 0};
+  HIPCHK(hipMemcpyAsync(d_res, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  if (total > 0) {
+    hipLaunchKernelGGL(light_t0_range_kernel, dim3((unsigned)min((int64_t)2048, (total + 255) / 256)), dim3(256), 0,
+                       ctx->stream, nph, t0det, total, d_res);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// Photon sum over resident segments [seg0, seg0 + n).  voxel / nph / track_id are relative to seg0.  sorted_idx (device,
+// [n_det][n]) = the caller's visiting order, or NULL = descending photons per detector.  Uses ctx->light_tmp[].
+int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* voxel, const int64_t* track_id,
+                     const float* nph, int n_inc, const int32_t* op_channel, int n_det, const int32_t* sorted_idx,
+                     double start_time, int64_t n_ticks, float* out, int64_t* true_id, double* true_ph, int max_truth) {
+  if (n_det == 0 || n_ticks == 0 || n == 0) return 0;
+  LightSum L;
+  L.s = ctx->seg; L.c = ctx->d_consts; L.seg0 = seg0; L.n = n; L.voxel = voxel; L.nph = nph; L.n_inc = n_inc;
+  L.op_channel = op_channel; L.n_det = n_det; L.t0_avg = ctx->d_lut_t0avg; L.time_dist = ctx->d_lut_td;
+  L.ny = ctx->lut_ny; L.nz = ctx->lut_nz; L.ndet_lut = ctx->lut_ndet; L.nprof = ctx->lut_nprof;
+  L.start_time = start_time; L.n_ticks = n_ticks;
+  hipStream_t st = ctx->stream;
   if (max_truth == 0) {
-    hipLaunchKernelGGL(sum_light_scatter_kernel, dim3(n_det, (unsigned)((n_ticks + LTILE - 1) / LTILE)), dim3(256), 0,
-                       ctx->stream, ctx->seg, ctx->d_consts, voxel, nph, n_inc, op_channel, n_det, ctx->d_lut_t0avg,
-                       ctx->d_lut_td, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->lut_nprof, start_time, n_ticks, out);
+    hipLaunchKernelGGL(sum_light_scatter_kernel, dim3(n_det, (unsigned)((n_ticks + LTILE - 1) / LTILE)), dim3(256), 0, st,
+                       L, out);
     HIPCHK(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(sum_light_signals_kernel, dim3(n_det, (unsigned)((n_ticks + 63) / 64)), dim3(64), 0, ctx->stream,
-                     ctx->seg, ctx->d_consts, voxel, track_id, nph, n_inc, op_channel, n_det, ctx->d_lut_t0avg,
-                     ctx->d_lut_td, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->lut_nprof, start_time, sorted_idx,
-                     n_ticks, out, true_id, true_ph, max_truth);
+  if (n_det > (1 << 12) || n_ticks > (1 << LK_TICK_BITS) || n > (1 << LK_RANK_BITS) || ctx->lut_nprof > (1 << LK_IP_BITS) ||
+      (int64_t)n_det * n >= 0x7fffffffLL) {
+    ldsim_set_error("photon sum with truth slots: at most 4096 detectors, 65536 ticks, 2^20 segments per call and a "
+                    "128-bin time profile (got %d, %lld, %lld, %d)", n_det, (long long)n_ticks, (long long)n, ctx->lut_nprof);
+    return LDSIM_EINVAL;
+  }
+  const int64_t np = (int64_t)n_det * n;
+  DevBuf* T = ctx->light_tmp;
+  int rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[0], (size_t)np * 4))) return rc;          // rank
+  if ((rc = ldsim_ensure_buf(ctx, &T[1], (size_t)np * 4 + 16))) return rc;     // count, then offsets in T[2]
+  if ((rc = ldsim_ensure_buf(ctx, &T[2], (size_t)np * 4 + 16))) return rc;
+  int32_t* d_rank = (int32_t*)T[0].p;
+  int32_t* d_count = (int32_t*)T[1].p;
+  int32_t* d_offs = (int32_t*)T[2].p;
+  if (sorted_idx) {
+    HIPCHK(hipMemsetAsync(d_rank, 0, (size_t)np * 4, st));
+    hipLaunchKernelGGL(light_rank_from_sorted_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, sorted_idx, n_det, n, d_rank);
+  } else {
+    if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)np * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)np * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)np * 4))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[6], (size_t)np * 4))) return rc;
+    hipLaunchKernelGGL(light_order_keys_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, (unsigned long long*)T[3].p,
+                       (int32_t*)T[5].p);
+    HIPCHK(hipGetLastError());
+    if ((rc = sort_pairs(ctx, (unsigned long long*)T[3].p, (unsigned long long*)T[4].p, (int32_t*)T[5].p, (int32_t*)T[6].p,
+                         np)))
+      return rc;
+    hipLaunchKernelGGL(light_rank_from_order_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, (const int32_t*)T[6].p, n_det,
+                       n, d_rank);
+  }
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(light_count_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_count);
+  HIPCHK(hipGetLastError());
+  if ((rc = sort_exclusive_scan_i32(ctx, d_count, d_offs, np))) return rc;
+  int32_t last_off = 0, last_cnt = 0;
+  HIPCHK(hipMemcpyAsync(&last_off, d_offs + (np - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&last_cnt, d_count + (np - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t n_rec = (int64_t)last_off + last_cnt;
+  if (n_rec == 0) return 0;
+  if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)n_rec * 8))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)n_rec * 8))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)n_rec * 4))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[6], (size_t)n_rec * 4))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[7], (size_t)n_rec * 4))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[8], (size_t)n_rec * 8))) return rc;
+  unsigned long long *k0 = (unsigned long long*)T[3].p, *k1 = (unsigned long long*)T[4].p;
+  int32_t *v0 = (int32_t*)T[5].p, *v1 = (int32_t*)T[6].p, *rseg = (int32_t*)T[7].p;
+  double* rph = (double*)T[8].p;
+  hipLaunchKernelGGL(light_fill_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_offs, d_rank, k0, v0, rseg, rph);
+  HIPCHK(hipGetLastError());
+  if ((rc = sort_pairs(ctx, k0, k1, v0, v1, n_rec))) return rc;
+  hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, rseg, rph, n_rec, track_id,
+                     n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
   HIPCHK(hipGetLastError());
   return 0;
 }

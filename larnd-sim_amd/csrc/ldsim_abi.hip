@@ -27,9 +27,10 @@ int fee_launch_sum_pixel_signals(ldsim_ctx*, double*, const float*, const double
 int fee_launch_adc_dense(ldsim_ctx*, const double*, const double*, int64_t, int, int, const double*, double, double*,
                          double*, double*);
 int fee_launch_digitize(ldsim_ctx*, const double*, const double*, double*, int64_t);
-int light_launch_incidence(ldsim_ctx*, int, float*, float*, int32_t*);
-int light_launch_sum(ldsim_ctx*, const int32_t*, const int64_t*, const float*, int, const int32_t*, int, const int32_t*,
-                     double, int64_t, float*, int64_t*, double*, int);
+int light_launch_incidence(ldsim_ctx*, int64_t, int64_t, int, float*, float*, int32_t*, int);
+int light_launch_t0_range(ldsim_ctx*, const float*, const float*, int64_t, int*);
+int light_launch_sum(ldsim_ctx*, int64_t, int64_t, const int32_t*, const int64_t*, const float*, int, const int32_t*, int,
+                     const int32_t*, double, int64_t, float*, int64_t*, double*, int);
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
@@ -152,6 +153,7 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
   HIPCHK(hipStreamCreate(&ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->evl[i]));
   CK(make_gl_tables(ctx, 256));
   *out = ctx;
   return ldsim_set_consts(ctx, consts);
@@ -182,6 +184,13 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   for (int i = 0; i < 8; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (int i = 0; i < 4; i++)
+    if (ctx->evl[i]) (void)hipEventDestroy(ctx->evl[i]);
+  for (DevBuf* b : {&ctx->light_nph, &ctx->light_t0, &ctx->light_vox, &ctx->light_out, &ctx->light_tid, &ctx->light_tph,
+                    &ctx->light_opc, &ctx->light_trk})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& b : ctx->light_tmp)
+    if (b.p) (void)hipFree(b.p);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -316,6 +325,18 @@ extern "C" int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float
   return 0;
 }
 
+// The segment store is shared by the device-resident chain and the host-buffer stage calls (which upload their own
+// records into it).  A chain entry point that finds the store filled by a stage call refuses to run on those records.
+#define NEED_RESIDENT(ctx)                                                                                         \
+  do {                                                                                                             \
+    if ((ctx)->seg_owner != 1) {                                                                                   \
+      ldsim_set_error("%s", (ctx)->seg_owner == 2                                                                  \
+                                ? "a host-buffer stage call replaced the resident segments: ldsim_segments_upload again" \
+                                : "no resident segments: call ldsim_segments_upload first");                         \
+      return LDSIM_ESTATE;                                                                                         \
+    }                                                                                                              \
+  } while (0)
+
 // ---- resident segments ----------------------------------------------------------------------------------------------
 static int seg_reserve(ldsim_ctx* ctx, int64_t n) {
   if (n > ctx->seg.cap) {
@@ -335,13 +356,17 @@ static int seg_reserve(ldsim_ctx* ctx, int64_t n) {
   return 0;
 }
 
+// batch_id_is_resident: the call comes from ldsim_segments_upload (the store then belongs to the device-resident chain);
+// every host-buffer stage call passes false and takes the store over
 static int upload_tracks(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* lay,
-                         const int32_t* batch_id) {
+                         const int32_t* batch_id, bool batch_id_is_resident = false) {
   NEED(ctx && lay && n >= 0 && (tracks || n == 0), "bad tracks argument");
   NEED(lay->itemsize > 0, "bad layout");
   HIPCHK(hipSetDevice(ctx->device));
   CK(seg_reserve(ctx, n));
   ctx->seg.n = n;
+  ctx->seg_owner = batch_id_is_resident ? 1 : 2;
+  ctx->light_n = -1;
   ctx->seg_layout = *lay;
   for (int f = 0; f < LDSIM_NFIELDS; f++) ctx->seg.store_code[f] = lay->offset[f] >= 0 ? lay->dtype[f] : LDSIM_F8;
   if (n == 0) return 0;
@@ -370,26 +395,43 @@ static int download_tracks(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimT
 
 extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                      const int32_t* batch_id) {
-  if (batch_id)
-    for (int64_t i = 1; i < n; i++)
-      if (batch_id[i] >= 0 && batch_id[i - 1] >= 0 && batch_id[i] < batch_id[i - 1]) {
-        ldsim_set_error("batch ids must be non-decreasing (segment %lld)", (long long)i);
-        return LDSIM_EINVAL;
+  NEED(ctx, "null ctx");
+  try {
+    ctx->h_batch.assign((size_t)(n > 0 ? n : 0), 0);
+  } catch (const std::exception&) {
+    ldsim_set_error("out of host memory for %lld batch ids", (long long)n);
+    return LDSIM_EINVAL;
+  }
+  if (batch_id) {
+    int32_t last = -1;       // last non-negative id seen: ids < 0 (not simulated) may sit anywhere in between
+    for (int64_t i = 0; i < n; i++) {
+      if (batch_id[i] >= 0) {
+        if (batch_id[i] < last) {
+          ldsim_set_error("batch ids must be non-decreasing (segment %lld has %d after %d)", (long long)i, batch_id[i], last);
+          return LDSIM_EINVAL;
+        }
+        last = batch_id[i];
       }
-  CK(upload_tracks(ctx, tracks, n, layout, batch_id));
+      ctx->h_batch[(size_t)i] = batch_id[i];
+    }
+  }
+  CK(upload_tracks(ctx, tracks, n, layout, batch_id, true));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 extern "C" int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
   NEED(ctx && tracks && layout, "null argument");
+  NEED_RESIDENT(ctx);
   return download_tracks(ctx, tracks, n, layout);
 }
 
 extern "C" int ldsim_segments_reset(ldsim_ctx* ctx) {
   NEED(ctx, "null ctx");
+  NEED_RESIDENT(ctx);
   NEED(ctx->seg.n == 0 || ctx->raw.p, "no uploaded records");
   HIPCHK(hipSetDevice(ctx->device));
+  ctx->light_n = -1;
   return seg_launch_unpack(ctx, &ctx->seg_layout, ctx->seg.n);
 }
 
@@ -414,6 +456,7 @@ static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {
 
 extern "C" int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode) {
   NEED(ctx, "null ctx");
+  NEED_RESIDENT(ctx);
   return run_quench_drift(ctx, mode, 1, 1);
 }
 
@@ -613,7 +656,7 @@ extern "C" int ldsim_light_incidence(ldsim_ctx* ctx, const void* tracks, int64_t
   HIPCHK(hipMemsetAsync(dn.p, 0, bc, ctx->stream));
   HIPCHK(hipMemsetAsync(dt.p, 0, bc, ctx->stream));
   HIPCHK(hipMemsetAsync(dv.p, 0, (size_t)n * 12, ctx->stream));
-  CK(light_launch_incidence(ctx, n_out, dn.as<float>(), dt.as<float>(), dv.as<int32_t>()));
+  CK(light_launch_incidence(ctx, 0, n, n_out, dn.as<float>(), dt.as<float>(), dv.as<int32_t>(), 0));
   if (bc) {
     HIPCHK(hipMemcpyAsync(nph, dn.p, bc, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(t0det, dt.p, bc, hipMemcpyDeviceToHost, ctx->stream));
@@ -649,7 +692,7 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
     HIPCHK(hipMemcpyAsync(dtid.p, true_id, bo * max_truth * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dtph.p, true_ph, bo * max_truth * 8, hipMemcpyHostToDevice, ctx->stream));
   }
-  CK(light_launch_sum(ctx, dv.as<int32_t>(), dti.as<int64_t>(), dn.as<float>(), n_inc, dop.as<int32_t>(), n_det,
+  CK(light_launch_sum(ctx, 0, n, dv.as<int32_t>(), dti.as<int64_t>(), dn.as<float>(), n_inc, dop.as<int32_t>(), n_det,
                       dsi.as<int32_t>(), start_time, n_ticks, dout.as<float>(), dtid.as<int64_t>(), dtph.as<double>(),
                       max_truth));
   HIPCHK(hipMemcpyAsync(out, dout.p, bo * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -658,6 +701,150 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
     HIPCHK(hipMemcpyAsync(true_ph, dtph.p, bo * max_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- device-resident light leg ------------------------------------------------------------------------------------------------
+// a17 over all resident segments (cli/simulate_pixels.py:795-797, after quench + drift): n_photons_det / t0_det / voxel stay
+// in HBM for the per-batch photon sums.
+extern "C" int ldsim_dev_light_incidence(ldsim_ctx* ctx, int32_t n_out) {
+  NEED(ctx && n_out > 0, "bad argument");
+  NEED_RESIDENT(ctx);
+  NEED(ctx->d_lut_vis && ctx->d_eff, "light LUT / channel tables not set");
+  NEED(n_out <= ctx->n_light_ch, "more output channels than light channels configured");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->seg.n;
+  const size_t bc = (size_t)n * n_out * 4;
+  const bool trig0 = ctx->h_consts.light_trig_mode == 0;
+  CK(ldsim_ensure_buf(ctx, &ctx->light_nph, bc));
+  if (trig0) CK(ldsim_ensure_buf(ctx, &ctx->light_t0, bc));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_vox, (size_t)n * 12));
+  HIPCHK(hipEventRecord(ctx->evl[0], ctx->stream));
+  CK(light_launch_incidence(ctx, 0, n, n_out, (float*)ctx->light_nph.p, (float*)ctx->light_t0.p, (int32_t*)ctx->light_vox.p,
+                            1));
+  HIPCHK(hipEventRecord(ctx->evl[1], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->evl[0], ctx->evl[1]));
+  ctx->ms_light_inc = ms;
+  ctx->light_n_out = n_out;
+  ctx->light_n = n;
+  return 0;
+}
+
+#define NEED_LIGHT_INC(ctx)                                                                                      \
+  do {                                                                                                           \
+    NEED_RESIDENT(ctx);                                                                                          \
+    if ((ctx)->light_n != (ctx)->seg.n) {                                                                        \
+      ldsim_set_error("light incidence of the resident segments not computed: ldsim_dev_light_incidence first"); \
+      return LDSIM_ESTATE;                                                                                       \
+    }                                                                                                            \
+  } while (0)
+
+extern "C" int ldsim_dev_light_incidence_download(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* nph,
+                                                  float* t0det, int32_t* voxel) {
+  NEED(ctx, "null ctx");
+  NEED_LIGHT_INC(ctx);
+  NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
+  const int64_t n = seg_end - seg_begin;
+  const size_t row = (size_t)ctx->light_n_out * 4;
+  if (n == 0) return 0;
+  if (nph) HIPCHK(hipMemcpyAsync(nph, (char*)ctx->light_nph.p + seg_begin * row, n * row, hipMemcpyDeviceToHost, ctx->stream));
+  if (t0det) {
+    NEED(ctx->h_consts.light_trig_mode == 0, "t0_det is only computed in trigger mode 0 (lightLUT.py:126-131)");
+    HIPCHK(hipMemcpyAsync(t0det, (char*)ctx->light_t0.p + seg_begin * row, n * row, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (voxel) HIPCHK(hipMemcpyAsync(voxel, (char*)ctx->light_vox.p + seg_begin * 12, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// light_sim.get_nticks needs min / max of t0_det over the entries with photons (light_sim.py:34-39); the host finishes
+// the expression so that its scalar typing stays the caller's
+extern "C" int ldsim_dev_light_t0_range(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* t0_min, float* t0_max,
+                                        int32_t* any) {
+  NEED(ctx && t0_min && t0_max && any, "null argument");
+  NEED_LIGHT_INC(ctx);
+  NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
+  NEED(ctx->h_consts.light_trig_mode == 0, "t0_det is only computed in trigger mode 0");
+  CK(ldsim_ensure_buf(ctx, &ctx->light_tmp[0], 64));
+  const int64_t total = (seg_end - seg_begin) * ctx->light_n_out;
+  const size_t off = (size_t)seg_begin * ctx->light_n_out;
+  CK(light_launch_t0_range(ctx, (const float*)ctx->light_nph.p + off, (const float*)ctx->light_t0.p + off, total,
+                           (int*)ctx->light_tmp[0].p));
+  int res[3];
+  HIPCHK(hipMemcpyAsync(res, ctx->light_tmp[0].p, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto ord2f = [](int v) { int i = v >= 0 ? v : v ^ 0x7fffffff; float f; memcpy(&f, &i, 4); return f; };
+  *any = res[2];
+  *t0_min = res[2] ? ord2f(res[0]) : 0.f;
+  *t0_max = res[2] ? ord2f(res[1]) : 0.f;
+  return 0;
+}
+
+// a18 for the resident segments [seg_begin, seg_end) = one batch of the reference's loop (cli/simulate_pixels.py:1120-1153):
+// light_sample_inc [n_det][n_ticks] f4 (+ truth slots) is zero / -1 initialised here and stays in HBM.
+extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, const int32_t* op_channel,
+                                   int32_t n_det, const int64_t* segment_track_id, int32_t max_truth, double start_time,
+                                   int32_t n_ticks) {
+  NEED(ctx && op_channel && n_det > 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
+  NEED_LIGHT_INC(ctx);
+  NEED(ctx->d_lut_t0avg, "light LUT not set");
+  NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
+  for (int i = 0; i < n_det; i++) NEED(op_channel[i] >= 0 && op_channel[i] < ctx->light_n_out, "op_channel outside the incidence array");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = seg_end - seg_begin;
+  const size_t bo = (size_t)n_det * n_ticks;
+  hipStream_t st = ctx->stream;
+  CK(ldsim_ensure_buf(ctx, &ctx->light_out, bo * 4 + 16));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_opc, (size_t)n_det * 4));
+  HIPCHK(hipMemcpyAsync(ctx->light_opc.p, op_channel, (size_t)n_det * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(ctx->evl[2], st));
+  HIPCHK(hipMemsetAsync(ctx->light_out.p, 0, bo * 4, st));
+  if (max_truth) {
+    CK(ldsim_ensure_buf(ctx, &ctx->light_tid, bo * max_truth * 8 + 16));
+    CK(ldsim_ensure_buf(ctx, &ctx->light_tph, bo * max_truth * 8 + 16));
+    CK(ldsim_ensure_buf(ctx, &ctx->light_trk, (size_t)(n > 0 ? n : 1) * 8));
+    HIPCHK(hipMemsetAsync(ctx->light_tid.p, 0xFF, bo * max_truth * 8, st));     // -1
+    HIPCHK(hipMemsetAsync(ctx->light_tph.p, 0, bo * max_truth * 8, st));
+    if (n) {
+      NEED(segment_track_id, "segment_track_id is needed for the truth slots");
+      HIPCHK(hipMemcpyAsync(ctx->light_trk.p, segment_track_id, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+  }
+  CK(light_launch_sum(ctx, seg_begin, n, (const int32_t*)ctx->light_vox.p + seg_begin * 3, (const int64_t*)ctx->light_trk.p,
+                      (const float*)ctx->light_nph.p + (size_t)seg_begin * ctx->light_n_out, ctx->light_n_out,
+                      (const int32_t*)ctx->light_opc.p, n_det, nullptr, start_time, n_ticks, (float*)ctx->light_out.p,
+                      (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p, max_truth));
+  HIPCHK(hipEventRecord(ctx->evl[3], st));
+  HIPCHK(hipStreamSynchronize(st));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->evl[2], ctx->evl[3]));
+  ctx->ms_light_sum = ms;
+  ctx->light_sum_ndet = n_det; ctx->light_sum_nticks = n_ticks; ctx->light_sum_truth = max_truth;
+  return 0;
+}
+
+extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* true_track_id,
+                                        double* true_photons) {
+  NEED(ctx, "null ctx");
+  const size_t bo = (size_t)ctx->light_sum_ndet * ctx->light_sum_nticks;
+  if (bo == 0) return 0;
+  if (light_sample_inc) HIPCHK(hipMemcpyAsync(light_sample_inc, ctx->light_out.p, bo * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->light_sum_truth) {
+    if (true_track_id)
+      HIPCHK(hipMemcpyAsync(true_track_id, ctx->light_tid.p, bo * ctx->light_sum_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (true_photons)
+      HIPCHK(hipMemcpyAsync(true_photons, ctx->light_tph.p, bo * ctx->light_sum_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms) {
+  NEED(ctx, "null ctx");
+  if (incidence_ms) *incidence_ms = ctx->ms_light_inc;
+  if (sum_ms) *sum_ms = ctx->ms_light_sum;
   return 0;
 }
 
@@ -775,12 +962,19 @@ extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg
                                   LdsimChainStats* stats) {
   NEED(ctx, "null ctx");
   NEED(ctx->d_resp, "no response table set (ldsim_set_response)");
+  NEED_RESIDENT(ctx);
   NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
   NEED(ctx->h_consts.reset_noise_charge == 0 && ctx->h_consts.uncorrelated_noise_charge == 0 &&
            ctx->h_consts.discriminator_noise == 0,
        "FEE noise must be 0: the reference's Numba xoroshiro128p stream is not reproduced");
   HIPCHK(hipSetDevice(ctx->device));
-  int rc = chain_run(ctx, seg_begin, seg_end, want_fractions);
+  int rc;
+  try {
+    rc = chain_run(ctx, seg_begin, seg_end, want_fractions);
+  } catch (const std::exception& e) {      // host allocations of the orchestration: nothing may throw across the C ABI
+    ldsim_set_error("chain_run: %s", e.what());
+    rc = LDSIM_EINVAL;
+  }
   if (stats) *stats = ctx->stats;
   return rc;
 }

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <exception>
+#include <vector>
+
 #include "../../include/ldsim.h"
 
 #define LDSIM_WAVE 64
@@ -120,6 +123,17 @@ struct ldsim_ctx {
   DevBuf raw;          // AoS staging (H2D/D2H)
   LdsimTrackLayout seg_layout{};
   DevBuf scratch[32];  // named scratch buffers, grown on demand
+  std::vector<int32_t> h_batch;   // host copy of the resident segments' batch ids (validated non-decreasing at upload)
+  int seg_owner = 0;   // who filled the segment store last: 1 = ldsim_segments_upload (resident chain), 2 = a host-buffer stage call
+  // device-resident light leg (ldsim_dev_light_incidence / ldsim_dev_sum_light)
+  DevBuf light_nph, light_t0, light_vox;       // [n][light_n_out] f32, f32 (trigger mode 0 only), [n][3] i32 over all resident segments
+  int32_t light_n_out = 0;
+  int64_t light_n = -1;                        // resident segment count the incidence was computed for (-1 = not computed)
+  DevBuf light_out, light_tid, light_tph, light_opc, light_trk;   // last photon sum: [n_det][n_ticks] f32, truth ids / photons
+  int32_t light_sum_ndet = 0, light_sum_nticks = 0, light_sum_truth = 0;
+  DevBuf light_tmp[9];
+  double ms_light_inc = 0, ms_light_sum = 0;
+  hipEvent_t evl[4] = {nullptr, nullptr, nullptr, nullptr};
   // chain results
   LdsimChainStats stats{};
   int64_t chain_U = 0, chain_hits = 0;

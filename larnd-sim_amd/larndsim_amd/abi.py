@@ -52,7 +52,7 @@ class LdsimChainStats(C.Structure):
                 ("n_ambiguous", C.c_int32), ("n_dfma", C.c_int64), ("n_fallback", C.c_int64), ("n_samples", C.c_int64), ("n_wbuf", C.c_int64)]
 
 
-ABI_VERSION = 2      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
+ABI_VERSION = 3      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):

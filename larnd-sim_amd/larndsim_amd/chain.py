@@ -121,6 +121,81 @@ class ChargeChain:
                                                   lib.ptr(out['track_pixel_map']), lib.ptr(fr)))
         return out
 
+    # ---- device-resident light leg (cli/simulate_pixels.py:749-797, 1120-1153) ------------------------------------------------
+    def light_incidence(self, lut=None, n_out=None):
+        """``lightLUT.calculate_light_incidence`` over all resident segments (after ``quench_drift``); the arrays stay in
+        HBM.  ``lut``: the structured LUT (uploaded unless already resident); ``n_out``: output channels, default all."""
+        self._check_constants()
+        lib.set_light(lut, self.ctx)
+        n_out = consts.light.N_OP_CHANNEL if n_out is None else n_out
+        lib.check(lib.load().ldsim_dev_light_incidence(self.ctx, C.c_int32(int(n_out))))
+        self._light_n_out = int(n_out)
+
+    def download_light_incidence(self, seg_begin=0, seg_end=None):
+        """(light_sim_dat rows, track_light_voxel rows) of resident segments [seg_begin, seg_end) in the reference's dtypes
+        (cli/simulate_pixels.py:760-763); ``segment_id`` is left 0 -- the driver fills it from its own ids."""
+        seg_end = self.n if seg_end is None else seg_end
+        n = seg_end - seg_begin
+        nph = np.zeros((n, self._light_n_out), dtype=np.float32)
+        t0 = np.zeros((n, self._light_n_out), dtype=np.float32) if consts.light.LIGHT_TRIG_MODE == 0 else None
+        vox = np.zeros((n, 3), dtype=np.int32)
+        lib.check(lib.load().ldsim_dev_light_incidence_download(self.ctx, C.c_int64(seg_begin), C.c_int64(seg_end),
+                                                                lib.ptr(nph), lib.ptr(t0), lib.ptr(vox)))
+        inc = np.zeros((n, self._light_n_out), dtype=[('segment_id', 'u4'), ('n_photons_det', 'f4'), ('t0_det', 'f4')])
+        inc['n_photons_det'] = nph
+        if t0 is not None:
+            inc['t0_det'] = t0
+        return inc, vox
+
+    def light_nticks(self, seg_begin, seg_end):
+        """``light_sim.get_nticks`` (larndsim/light_sim.py:24-41) for the resident rows of one batch: same expressions, with
+        the min / max of ``t0_det`` reduced on the device."""
+        light = consts.light
+        if light.LIGHT_TRIG_MODE == 0:
+            lo, hi, any_ = C.c_float(), C.c_float(), C.c_int32()
+            lib.check(lib.load().ldsim_dev_light_t0_range(self.ctx, C.c_int64(seg_begin), C.c_int64(seg_end), C.byref(lo),
+                                                          C.byref(hi), C.byref(any_)))
+            if any_.value:
+                start_time = np.float32(lo.value) - light.LIGHT_WINDOW[0]
+                end_time = np.float32(hi.value) + light.LIGHT_WINDOW[1]
+                return int(np.ceil((end_time - start_time) / light.LIGHT_TICK_SIZE)), start_time
+        return int((light.LIGHT_WINDOW[1] + light.LIGHT_WINDOW[0]) / light.LIGHT_TICK_SIZE), 0
+
+    def sum_light(self, seg_begin, seg_end, op_channel, segment_track_id=None, max_truth=None, max_ticks=int(5e4)):
+        """``light_sim.sum_light_signals`` for the batch [seg_begin, seg_end) on the resident incidence arrays
+        (cli/simulate_pixels.py:1120-1153).  Returns (n_ticks, start_time); fetch the arrays with ``download_light``."""
+        self._check_constants()
+        n_ticks, t_start = self.light_nticks(seg_begin, seg_end)
+        n_ticks = min(n_ticks, max_ticks)
+        mt = consts.sim.MAX_MC_TRUTH_IDS if max_truth is None else max_truth
+        opc = np.ascontiguousarray(op_channel, dtype=np.int32)
+        tid = None
+        if mt:
+            tid = (np.arange(seg_begin, seg_end, dtype=np.int64) if segment_track_id is None
+                   else np.ascontiguousarray(segment_track_id, dtype=np.int64))
+            if tid.shape[0] != seg_end - seg_begin:
+                raise ValueError("segment_track_id must have one entry per segment of the range")
+        lib.check(lib.load().ldsim_dev_sum_light(self.ctx, C.c_int64(seg_begin), C.c_int64(seg_end), lib.ptr(opc),
+                                                 C.c_int32(opc.shape[0]), lib.ptr(tid), C.c_int32(int(mt)),
+                                                 C.c_double(float(t_start)), C.c_int32(int(n_ticks))))
+        self._light_shape = (opc.shape[0], int(n_ticks), int(mt))
+        return n_ticks, t_start
+
+    def download_light(self, truth=True):
+        """(light_sample_inc f4 [n_det][n_ticks], true_track_id i8 [..][max_truth], true_photons f8 [..][max_truth])."""
+        nd, nt, mt = self._light_shape
+        out = np.zeros((nd, nt), dtype=np.float32)
+        tid = np.full((nd, nt, mt), -1, dtype=np.int64)
+        tph = np.zeros((nd, nt, mt))
+        lib.check(lib.load().ldsim_dev_light_download(self.ctx, lib.ptr(out), lib.ptr(tid) if (mt and truth) else None,
+                                                      lib.ptr(tph) if (mt and truth) else None))
+        return out, tid, tph
+
+    def light_kernel_ms(self):
+        a, b = C.c_double(), C.c_double()
+        lib.check(lib.load().ldsim_light_kernel_ms(self.ctx, C.byref(a), C.byref(b)))
+        return dict(incidence_ms=a.value, sum_ms=b.value)
+
     def compact_hits(self):
         """(device pointer, n_rows, row_bytes) of the compact hit list of the last run()."""
         p, n, rb = C.c_void_p(), C.c_int64(), C.c_int32()

@@ -796,6 +796,120 @@ def test_light_properties_baseline_event():
     assert np.array_equal(one.sum(axis=1) > 0, seen)
 
 
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_resident_light_leg_golden(cfg):
+    """Device-resident light leg (ldsim_dev_light_incidence / ldsim_dev_sum_light: nothing leaves HBM between the stages)
+    against the reference's goldens and against the host-buffer stage calls: voxels and truth ids exact, photons to f4."""
+    H.load_cfg(cfg)
+    g = H.gold(f"light_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    n = len(r)
+    lut = synth.make_lut((14, 26, 8), 48, int(g["n_prof"]), int(g["lut_seed"]))
+    ch = ChargeChain()
+    ch.upload(r, np.zeros(n, dtype=np.int32))
+    ch.light_incidence(lut)
+    inc, vox = ch.download_light_incidence()
+    assert np.array_equal(vox, g["voxel"])
+    np.testing.assert_allclose(inc['n_photons_det'], g["n_photons_det"], rtol=1e-6)
+    if consts.light.LIGHT_TRIG_MODE == 0:
+        np.testing.assert_allclose(inc['t0_det'], g["t0_det"], rtol=1e-6)
+    opc = g["op_channel"]
+    Mt = g["true_id"].shape[-1]
+    n_ticks, t_start = ch.sum_light(0, n, opc, np.arange(n, dtype='i8'), max_truth=Mt, max_ticks=int(g["n_ticks"]))
+    assert n_ticks == int(g["n_ticks"]) and t_start == pytest.approx(float(g["t_start"]))
+    out, tid, tph = ch.download_light()
+    ref = g["light_sample_inc"][:, :n_ticks]
+    assert ref.sum() > 0
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=0)
+    assert np.array_equal(tid, g["true_id"][:, :n_ticks])
+    np.testing.assert_allclose(tph, g["true_photons"][:, :n_ticks], rtol=1e-5)
+    # the host-buffer stage calls on the same records (reference call sites) give the same arrays bit for bit: the same
+    # kernels run, the stage call with the driver's sorted_indices, the resident one with its own descending order
+    inc2 = np.zeros_like(inc); vox2 = np.zeros_like(vox)
+    lightLUT.calculate_light_incidence[1, 256](r, lut, inc2, vox2)
+    assert np.array_equal(inc2['n_photons_det'], inc['n_photons_det']) and np.array_equal(vox2, vox)
+    out2 = np.zeros_like(out); tid2 = np.full_like(tid, -1); tph2 = np.zeros_like(tph)
+    light_sim.sum_light_signals[1, 64](r, vox2, np.arange(n, dtype='i8'), inc2, opc, lut, float(t_start), out2, tid2, tph2,
+                                       g["sorted_indices"], int(g["n_prof"]))
+    assert np.array_equal(out2, out) and np.array_equal(tid2, tid) and np.array_equal(tph2, tph)
+    # without truth slots the scatter kernel runs (f64 tile, one f4 rounding)
+    ch.upload(r, np.zeros(n, dtype=np.int32))       # the stage calls above took the segment store over
+    ch.light_incidence(lut)
+    ch.sum_light(0, n, opc, max_truth=0, max_ticks=int(g["n_ticks"]))
+    out3, _, _ = ch.download_light()
+    assert np.array_equal(out3 != 0, ref != 0)
+    np.testing.assert_allclose(out3, ref, rtol=1e-5, atol=0)
+
+
+def test_stage_call_between_upload_and_run_is_refused():
+    """The host-buffer stage calls upload their records into the store the resident chain uses.  A chain call that finds
+    the store taken over by a stage call must refuse (LDSIM_ESTATE) instead of simulating the stage call's records."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(40, seed=3, segs_per_event=40)
+    batching.swap_coordinates(seg)
+    other = synth.make_segments(64, seed=4, segs_per_event=64)
+    batching.swap_coordinates(other)
+    ch = ChargeChain(H.response_for("survey"))
+    ch.upload(seg, np.zeros(len(seg), dtype=np.int32))
+    ch.quench_drift()
+    good = ch.run(0, len(seg))
+    ref = ch.download()
+    quenching.quench[1, 256](other, consts.physics.BIRKS)           # a stage call in between (the reference loop does this)
+    for call in (lambda: ch.run(0, len(seg)), ch.quench_drift, ch.reset, lambda: ch.download_segments(seg.copy())):
+        with pytest.raises(lib.LdsimError, match="stage call replaced the resident segments"):
+            call()
+    ch.upload(seg, np.zeros(len(seg), dtype=np.int32))
+    ch.quench_drift()
+    again = ch.run(0, len(seg))
+    assert again.n_unique == good.n_unique
+    out = ch.download()
+    for k in ref:
+        assert np.array_equal(ref[k], out[k]), k
+    # batch ids must be non-decreasing over the simulated segments, also across skipped (negative) ones
+    with pytest.raises(lib.LdsimError, match="non-decreasing"):
+        ch.upload(seg, np.array([5, -1, 3] + [6] * (len(seg) - 3), dtype=np.int32))
+
+
+def test_light_properties_baseline_sizes():
+    """BASELINE.json config 5, light leg at full size: ndlar, 1 M segments, synthetic light set-up of SURVEY 8d (48 channels
+    per TPC, 3360 channels), device-resident.  Per event: a segment lights only its own TPC's channels, voxels are inside
+    the LUT, and the photon sum closes -- every channel's waveform integrates to the photons incident on it."""
+    seg, bid = _prepared_set("ndlar", 1_000_000, 5)
+    n_op = synth.set_synthetic_light(48)
+    lut = synth.make_lut((14, 26, 8), 48, 100, synth.SEED_BASE + 5)
+    ch = ChargeChain()
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.light_incidence(lut)
+    got = ch.download_segments(seg.copy())
+    opc = consts.light.TPC_TO_OP_CHANNEL[:].ravel().astype('i4')
+    c2t = np.asarray(consts.light.OP_CHANNEL_TO_TPC)
+    tick = consts.light.LIGHT_TICK_SIZE
+    n_sim = int((bid >= 0).sum())            # unsimulated segments (none in the synthetic set) sit behind the batches
+    assert n_sim > 0.99 * len(seg)
+    ev = got["event_id"][:n_sim]
+    edges = np.flatnonzero(np.r_[True, ev[1:] != ev[:-1], True])
+    assert len(edges) - 1 == 200
+    checked = 0
+    for b, e in zip(edges[:-1], edges[1:]):
+        inc, vox = ch.download_light_incidence(b, e)
+        r = got[b:e]
+        in_tpc = r["pixel_plane"] != consts.detector.DEFAULT_PLANE_INDEX
+        assert ((vox[in_tpc] >= 0) & (vox[in_tpc] < np.array([14, 26, 8]))).all()
+        nph = inc['n_photons_det']
+        own = c2t[None, :] == r["pixel_plane"][:, None]
+        assert (nph[~own] == 0).all()
+        lit = own & in_tpc[:, None] & (r["n_photons"] > 0)[:, None]
+        assert (nph[lit] > 0).all()
+        n_ticks, t_start = ch.sum_light(b, e, opc, max_truth=0)
+        out, _, _ = ch.download_light()
+        assert n_ticks == 11000 and t_start == 0
+        np.testing.assert_allclose(out.sum(axis=1, dtype=np.float64) * tick, nph.sum(axis=0, dtype=np.float64), rtol=2e-5,
+                                   atol=1e-3)
+        checked += e - b
+    assert checked == n_sim
+
+
 def _two_event_set(cfg, seed, n=1200):
     H.load_cfg(cfg)
     seg = synth.make_segments(n, seed=seed, segs_per_event=n // 2, spill=bool(consts.sim.IS_SPILL_SIM))
