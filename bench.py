@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """
-bench.py -- throughput of the charge hot path (quench -> drift -> pixels -> induced current -> ADC).
+bench.py -- throughput of the charge hot path (quench -> drift -> pixels -> induced current -> ADC), plus the light leg
+(light incidence + photon sum) for the ndlar configuration (BASELINE.json configs[4]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; the launcher only
+   starts the processes -- the collective layer is RCCL through the C-ABI, larndsim_amd/comm.py, no torch in this file)
 
-A step = one pass of the whole path over this rank's resident synthetic segment set
-(BASELINE.json configs[1]: module0, 100k segments; the example edep-sim file is absent so the
-SURVEY §8d synthetic straight tracks are used).  Segments are uploaded (H2D) before the timed
-region; a step re-unpacks the resident records, runs quench+drift and the fused chain chunk by
-chunk; per-pixel ADC results stay in HBM.  N > 1 is weak scaling: every rank owns its own
-100k-segment set of events (batches are sharded by (event, TPC group), no data-path collective
-until the final all-gather of the compact hit rows, which is inside the timed region).
-Prints ONE JSON line on rank 0.
+A step = one pass of the whole path over this rank's resident synthetic segment set (BASELINE.json configs[1]: module0,
+100k segments; the example edep-sim file is absent so the SURVEY 8d synthetic straight tracks are used).  Segments are
+uploaded (H2D) before the timed region; a step re-unpacks the resident records, runs quench+drift and the fused chain
+chunk by chunk; per-pixel ADC results stay in HBM.  N > 1 is weak scaling: every rank owns its own 100k-segment set of
+events (batches are sharded by (event, TPC group), no data-path collective until the final all-gather-v of the compact
+hit rows, which is inside the timed region).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -31,11 +31,7 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = 50_000
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
-# weights_kernel<1>, one launch = 50k segments (profiles/r01_split_pmc_*.csv): FETCH_SIZE 196.5 MB (x2 on gfx950 = 393 MB)
-# + WRITE_SIZE 21.80 GB; the writes are the per-pair weight blocks and item lists handed to mac_kernel (intermediates the
-# algorithmic count excludes) plus ~5 GB of register-spill scratch written back (the kernel is built for 4 workgroups
-# per CU: 128 VGPRs, 52 B/lane of scratch).  mac_kernel reads the blocks back: FETCH 8.99 GB x2, WRITE 5.06 GB.
-PROFILED_TRAFFIC_BYTES = 22.19e9
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "r02_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
 def cpu_baseline(response, n_seg=400):
@@ -66,8 +62,20 @@ def cpu_baseline(response, n_seg=400):
     O.digitize(adc)
     dt = time.perf_counter() - t0
     return {"value": n_seg / dt, "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": f"{n_seg} segments of the same synthetic module0 set, full chain, {dt:.1f} s; OpenMP over "
+            "sample": f"{n_seg} segments of the same synthetic set (charge chain), {dt:.1f} s; OpenMP over "
                       f"(segment,pixel) pairs in tracks_current only"}
+
+
+def profiled_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md, HBM), or (None, why) when this workload was not profiled."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            tab = json.load(f)
+        e = tab[config][kernel]
+        return float(e["bytes_per_launch"]), e.get("source", os.path.basename(TRAFFIC_FILE))
+    except Exception:
+        return None, f"no PMC pass for {config}/{kernel} in profiles/{os.path.basename(TRAFFIC_FILE)} (tools/pmc_traffic.py writes it)"
 
 
 def main():
@@ -80,9 +88,13 @@ def main():
     ap.add_argument("--config", default="module0", choices=["module0", "2x2_no_modvar", "ndlar"],
                     help="detector configuration of the synthetic workload (SURVEY 8d seeds); the contract line is the "
                          "default, module0 = BASELINE configs[1]")
+    ap.add_argument("--light", default="auto", choices=["auto", "on", "off"],
+                    help="time the light leg (incidence + per-batch photon sum) with the charge chain; auto = ndlar only "
+                         "(BASELINE configs[4], synthetic light set-up of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense-response and PCIe-inclusive side measurements")
     ap.add_argument("--fractions", type=int, default=1, help="compute backtracking fractions (reference always does)")
-    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed / all-gather path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather path even with one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,33 +103,28 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    from larndsim_amd import batching, consts, dist as ldist, lib, synth
+    from larndsim_amd import batching, comm as lcomm, consts, dist as ldist, lib, synth
     from larndsim_amd.chain import ChargeChain
 
-    tdist = None
-    torch = None
     use_dist = world > 1 or a.force_dist
     result_fd = None
     if use_dist:
-        # RCCL prints a version banner to stdout when the communicator is created (and may print again on teardown).
-        # The result stream must carry exactly one JSON line, so for the whole process fd 1 points at stderr and the line
-        # is written to a saved duplicate of the original stdout.
+        # RCCL may print to stdout when the communicator is created.  The result stream must carry exactly one JSON
+        # line, so fd 1 points at stderr for the whole process and the line is written to a duplicate of the original.
         sys.stdout.flush()
         result_fd = os.dup(1)
         os.dup2(2, 1)
-        import datetime
-        import torch
-        import torch.distributed as tdist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        tdist.init_process_group(backend="nccl", timeout=datetime.timedelta(seconds=300), rank=rank, world_size=world,
-                                 device_id=torch.device("cuda", local_rank))
 
     consts.load_snapshot(a.config)
     for k in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOISE"):
-        setattr(consts.detector, k, 0)     # the reference's RNG stream is third-party/unpinned: noise off
+        setattr(consts.detector, k, 0)     # noise off: the contract workload is the deterministic chain
     seed_index = {"module0": 2, "2x2_no_modvar": 3, "ndlar": 5}[a.config]      # BASELINE config number
+    light_on = a.light == "on" or (a.light == "auto" and a.config == "ndlar")
+    lut = None
+    if light_on:
+        if not consts.light.LIGHT_SIMULATED or consts.light.N_OP_CHANNEL == 0:
+            synth.set_synthetic_light(48)                       # ndlar ships no light configuration
+        lut = synth.make_lut((14, 26, 8), 48, 100, synth.SEED_BASE + seed_index)
 
     # ---- workload: global set of world x 100k segments, this rank's shard of its batches ----------------------------
     n_total = a.segments * world
@@ -135,44 +142,59 @@ def main():
     response = synth.make_response(a.response)
 
     ch = ChargeChain(response, device=local_rank)
+    cm = lcomm.Communicator(ch.ctx, rank, world) if use_dist else None
+    t_up = time.perf_counter()
     ch.upload(seg, bid)                      # H2D happens here, outside the timed region
+    ch.synchronize()
+    t_up = time.perf_counter() - t_up
     ranges = batching.chunk_ranges(bid, CHUNK_SEGMENTS)
+    n_sim = int((bid >= 0).sum())
+    bedges = np.flatnonzero(np.r_[True, bid[1:n_sim] != bid[:n_sim - 1], True]) if n_sim else np.array([0])
+    op_all = consts.light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32) if light_on else None
 
-    acc = {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0, "S": 0, "U": 0, "pairs": 0, "launches": 0,
-           "hits": 0, "ambig": 0, "ovf": 0}
+    def new_acc():
+        return {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0,
+                "S": 0, "U": 0, "pairs": 0, "launches": 0, "hits": 0, "ambig": 0, "ovf": 0, "inc_ms": 0.0, "inc_n": 0,
+                "sum_ms": 0.0, "sum_n": 0, "photons": 0.0}
+    acc = new_acc()
 
-    def step(record):
+    def step(record, download=False):
         ch.reset()
         ch.quench_drift()
-        rows_all = []
-        for (b, e) in ranges:
+        if light_on:
+            ch.light_incidence(lut)
+            if record:
+                acc["inc_ms"] += ch.light_kernel_ms()["incidence_ms"]; acc["inc_n"] += 1
+            for b, e in zip(bedges[:-1], bedges[1:]):          # one photon sum per (event, TPC group) batch, like the driver
+                ch.sum_light(int(b), int(e), op_all)
+                if record:
+                    acc["sum_ms"] += ch.light_kernel_ms()["sum_ms"]; acc["sum_n"] += 1
+                if download:
+                    ch.download_light(truth=False)
+        for i, (b, e) in enumerate(ranges):
             st = ch.run(b, e, want_fractions=bool(a.fractions))
             if record:
                 ms = ch.kernel_ms()
                 acc["cur_ms"] += ms["current_ms"]; acc["adc_ms"] += ms["adc_ms"]
                 acc["w_ms"] += ms["weights_ms"]; acc["m_ms"] += ms["mac_ms"]; acc["f_ms"] += ms["fallback_ms"]
                 acc["samples"] += st.n_samples
-                acc["bytes"] += 184.0 * st.n_segments + 484.0 * st.n_unique     # SURVEY §8d B_alg
+                acc["bytes"] += 184.0 * st.n_segments + 484.0 * st.n_unique     # SURVEY 8d B_alg
                 acc["dfma"] += st.n_dfma; acc["S"] += st.n_segments; acc["U"] += st.n_unique
                 acc["pairs"] += st.n_pairs; acc["launches"] += 1; acc["ambig"] += st.n_ambiguous
                 acc["ovf"] += st.n_overflow
-            if use_dist:
-                p, n, rb = ch.compact_hits()
-                rows_all.append(ldist.device_rows_as_tensor(p, n, rb, torch.device("cuda", local_rank)).clone())
-            if record:
                 acc["hits"] += ch.compact_hits()[1]
-        if use_dist:
-            rows = torch.cat(rows_all, dim=0)
-            gathered, _ = ldist.allgather_rows(rows)
-            torch.cuda.synchronize()
-            return gathered.shape[0]
+            if cm is not None:
+                cm.accumulate_hits(reset=(i == 0))
+            if download:
+                ch.download()
+        if cm is not None:
+            return cm.allgather_hits()[0]
         return 0
 
     def barrier():
         ch.synchronize()
-        if use_dist:
-            torch.cuda.synchronize()
-            tdist.barrier()
+        if cm is not None:
+            cm.barrier()
 
     for _ in range(a.warmup):
         step(False)
@@ -182,27 +204,57 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(len(seg))], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM)
-        n_job = float(tot.item())
-    else:
-        n_job = float(len(seg))
+    n_job = float(len(seg))
+    if cm is not None:
+        elapsed = cm.allreduce(elapsed, "max")
+        n_job = cm.allreduce(n_job, "sum")
+
+    # ---- side measurements (one GPU only; never part of `value`) ------------------------------------------------------------
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras:
+        main_acc, acc = acc, new_acc()
+        # (a) host buffers in, host results out: H2D of the records + the step + D2H of every per-pixel array
+        t1 = time.perf_counter()
+        ch.upload(seg, bid)
+        step(False, download=True)
+        ch.synchronize()
+        t_incl = time.perf_counter() - t1
+        extras["pcie_inclusive"] = {"value": len(seg) / t_incl, "unit": "segments/s", "ms_per_step": 1e3 * t_incl,
+                                    "h2d_ms": 1e3 * t_up,
+                                    "note": "one pass incl. H2D of the 152-byte records and D2H of unique_pix / adc_list / "
+                                            "adc_ticks / adc_digit / track_pixel_map / current_fractions"
+                                            + (" / light_sample_inc" if light_on else "") + " per chunk (pageable host memory)"}
+        # (b) the same workload on a response table without exact zeros (real response files are dense)
+        if a.response != "dense":
+            lib.set_response(synth.make_response("dense"), ch.ctx)
+            step(False)
+            ch.synchronize()
+            t2 = time.perf_counter()
+            nd = max(1, min(3, a.steps))
+            for _ in range(nd):
+                step(True)
+            ch.synchronize()
+            t_dense = (time.perf_counter() - t2) / nd
+            extras["dense_response_value"] = len(seg) / t_dense
+            extras["dense_response"] = {"value": len(seg) / t_dense, "unit": "segments/s", "ms_per_step": 1e3 * t_dense,
+                                        "steps": nd, "mac_kernel_ms_avg": acc["m_ms"] / max(acc["launches"], 1),
+                                        "dfma_per_segment": acc["dfma"] / max(acc["S"], 1),
+                                        "valu_f64_frac": (2.0 * acc["dfma"] / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS)
+                                        if acc["m_ms"] > 0 else None,
+                                        "note": "synthetic 'dense' response (no exact zeros, so trim_response skips nothing)"}
+            lib.set_response(response, ch.ctx)
+        acc = main_acc
 
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         value = n_job * a.steps / elapsed
         split = acc["w_ms"] > 0
         M = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
-        # dominant kernel of the path: the longer of the split path's two kernels (weights_kernel on module0 / 2x2,
-        # mac_kernel on ndlar), or the monolithic current_kernel when the split path is off
+        # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
         elif acc["w_ms"] >= acc["m_ms"]:
-            dom_name, dom_ms = f"weights_kernel<{M}>", acc["w_ms"]
+            dom_name, dom_ms = f"qweights_kernel<{M}>", acc["w_ms"]
         else:
             dom_name, dom_ms = f"mac_kernel<{M}>", acc["m_ms"]
         dom_s = dom_ms * 1e-3
@@ -210,28 +262,32 @@ def main():
         mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
         tflops = 2.0 * acc["dfma"] / mac_s / 1e12 if mac_s > 0 else 0.0
         nl = max(acc["launches"], 1)
+        default_workload = (a.segments == SEGS_PER_GPU and a.response == "survey" and a.fractions and split)
+        traffic, traffic_src = profiled_traffic(a.config, dom_name) if default_workload else (None, "not the profiled workload")
+        what = "charge chain quench->drift->pixels->tracks_current->pixel sum->ADC+digitize"
+        if light_on:
+            what += " + light incidence (all segments) + photon sum per (event, TPC group) batch"
         out = {
             "metric": f"edep segments/s end-to-end (quench->ADC), {a.config} config",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.config}, {a.segments} synthetic straight-track segments per GPU "
-                                   f"(seed {synth.SEED_BASE + seed_index}, 5000/event), full charge chain quench->drift->pixels->"
-                                   f"tracks_current->pixel sum->ADC+digitize, backtracking fractions "
+                                   f"(seed {synth.SEED_BASE + seed_index}, 5000/event), {what}, backtracking fractions "
                                    f"{'on' if a.fractions else 'off'}",
                        "response": f"synthetic '{a.response}' (45,45,1950) f64", "noise": "off",
+                       "light": (f"synthetic LUT (14,26,8) x 48 ch/TPC x 100 bins, {int(consts.light.N_OP_CHANNEL)} channels, "
+                                 f"{len(bedges) - 1} photon sums per step") if light_on else "off",
                        "segments_per_step": int(n_job), "pairs_per_segment": acc["pairs"] / max(acc["S"], 1),
                        "unique_pixels_per_segment": acc["U"] / max(acc["S"], 1),
                        "hits_per_step": acc["hits"] // max(a.steps, 1),
-                       "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}"},
+                       "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}",
+                       "collective": "RCCL all-gather (counts) + all-gather-v (24-byte hit rows), C-ABI ldsim_comm_*"
+                                     if cm is not None else "none (one rank)"},
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_*: FETCH_SIZE x2 per the
-                         # gfx950 correction + WRITE_SIZE) -- only valid for the default workload/chunking
-                         "traffic": PROFILED_TRAFFIC_BYTES if (a.config == "module0" and a.segments == SEGS_PER_GPU
-                                                               and a.response == "survey" and a.fractions and split
-                                                               and dom_name == "weights_kernel<1>") else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms_avg": dom_ms / nl,
                          "launches": acc["launches"],
                          "algorithmic_bytes_per_launch": acc["bytes"] / nl,
@@ -240,12 +296,28 @@ def main():
                          "stage_kernels": {"weights_kernel_ms_avg": acc["w_ms"] / nl, "mac_kernel_ms_avg": acc["m_ms"] / nl,
                                            "current_kernel_ms_avg": acc["f_ms"] / nl,
                                            "pixel_adc_kernel_ms_avg": acc["adc_ms"] / nl,
-                                           "charge_samples_per_launch": acc["samples"] / nl},
+                                           "quadrature_nodes_per_pair": acc["samples"] / max(acc["pairs"], 1)},
                          "valu_f64": {"kernel": f"mac_kernel<{M}>" if split else f"current_kernel<{M}>",
                                       "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                                       "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},
         }
+        if light_on and acc["inc_n"]:
+            n_op = int(consts.light.N_OP_CHANNEL)
+            inc_ms = acc["inc_ms"] / acc["inc_n"]
+            b_alg = len(seg) * (152.0 + 12.0 * n_op)            # S*152 read + S*n_op*12 written
+            written = len(seg) * n_op * (8.0 if consts.light.LIGHT_TRIG_MODE == 0 else 4.0) + len(seg) * 12.0
+            out["roofline_light_incidence"] = {
+                "bound": "hbm", "kernel": "light_incidence_kernel", "achieved": b_alg / (inc_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "launch_ms_avg": inc_ms, "algorithmic_bytes_per_launch": b_alg,
+                "bytes_written_per_launch": written, "written_GBs": written / (inc_ms * 1e-3) / 1e9,
+                "traffic": None, "traffic_source": "no PMC pass",
+                "note": "algorithmic bytes per SURVEY 8d (reference record + {segment_id, n_photons_det, t0_det} per channel); "
+                        "the kernel itself reads 44 B of SoA columns per segment and writes n_photons_det (+ t0_det in "
+                        "trigger mode 0) and the voxel",
+                "photon_sum_ms_avg": acc["sum_ms"] / max(acc["sum_n"], 1), "photon_sums": acc["sum_n"] // max(a.steps, 1)}
+        out.update(extras)
         if world > 1:
             # timed on rank 0 of the single-GPU run only: at N > 1 it would keep the other ranks waiting at the barrier
             out["cpu_baseline"] = {"value": None, "unit": "segments/s", "cores": 0, "kind": "port",
@@ -264,9 +336,9 @@ def main():
             sys.stdout.flush()
         else:
             os.write(result_fd, line.encode())
-    if use_dist:
-        tdist.barrier()
-        tdist.destroy_process_group()
+    if cm is not None:
+        cm.barrier()
+        cm.destroy()
 
 
 if __name__ == "__main__":

@@ -283,6 +283,23 @@ int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* t
 /* HIP-event durations of the last ldsim_dev_light_incidence launch and the last ldsim_dev_sum_light call */
 int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms);
 
+/* ---- multi-GPU: the one exchange step of the batch-sharded path, RCCL over xGMI -------------------------------
+ * One process per GPU; (event, TPC-group) batches are sharded over the ranks and never share a pixel, so the only
+ * collective reassembles the output: row counts (all-gather), then the 24-byte hit rows (all-gather-v). */
+#define LDSIM_COMM_ID_BYTES 128
+/* ncclGetUniqueId on one rank; the host side hands the 128 bytes to every rank (larndsim_amd/comm.py) */
+int ldsim_comm_unique_id(void* id);
+int ldsim_comm_init(ldsim_ctx* ctx, const void* id, int32_t rank, int32_t world);
+int ldsim_comm_destroy(ldsim_ctx* ctx);
+/* *value reduced over the ranks (op 0 = sum, 1 = max); also the barrier of the timed region */
+int ldsim_comm_allreduce_f64(ldsim_ctx* ctx, double* value, int32_t op);
+/* append the last ldsim_charge_chain call's compact hit rows to the pass buffer (reset != 0 empties it first) */
+int ldsim_hits_accumulate(ldsim_ctx* ctx, int32_t reset);
+/* all-gather-v of the pass buffer: *gathered = device pointer (ctx-owned) to the rows of rank 0, 1, .. back to back,
+ * counts[world] (may be NULL) = rows per rank */
+int ldsim_comm_allgather_hits(ldsim_ctx* ctx, void** gathered, int64_t* total_rows, int64_t* counts);
+int ldsim_comm_gathered_download(ldsim_ctx* ctx, void* rows, int64_t n);
+
 /* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
 int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);
 /* split of current_ms over the tracks_current kernels of the last chain call: weights_kernel, mac_kernel and the

@@ -191,6 +191,9 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);
+  (void)ldsim_comm_destroy(ctx);
+  for (DevBuf* b : {&ctx->comm_tmp, &ctx->hits_acc, &ctx->hits_all})
+    if (b->p) (void)hipFree(b->p);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;

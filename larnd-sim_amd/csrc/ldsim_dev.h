@@ -134,6 +134,11 @@ struct ldsim_ctx {
   DevBuf light_tmp[9];
   double ms_light_inc = 0, ms_light_sum = 0;
   hipEvent_t evl[4] = {nullptr, nullptr, nullptr, nullptr};
+  // multi-GPU exchange (comm.hip): RCCL communicator, rows accumulated over the chain calls of a pass, gathered rows
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  DevBuf comm_tmp, hits_acc, hits_all;
+  int64_t hits_acc_rows = 0;
   // chain results
   LdsimChainStats stats{};
   int64_t chain_U = 0, chain_hits = 0;

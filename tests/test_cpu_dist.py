@@ -63,3 +63,28 @@ def test_shard_and_allgather_gloo_world2():
     assert np.array_equal(np.sort(g0[:, 1]), np.sort(np.r_[idx0, idx1]))
     # rank order == batch order: the concatenation is sorted by batch id, like a single-GPU run
     assert (np.diff(g0[:, 0]) >= 0).all()
+
+
+def _id_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(REPO, "larnd-sim_amd"))
+    from larndsim_amd import comm
+    payload = bytes(range(128)) if rank == 0 else b""
+    got = comm.exchange_id(payload, rank, world, addr="127.0.0.1", port=port, timeout=60.0)
+    q.put((rank, got))
+
+
+def test_unique_id_rendezvous_world3():
+    """The ncclUniqueId hand-out of larndsim_amd/comm.py (rank 0 serves the 128 bytes over TCP): every rank ends up with
+    rank 0's bytes, whichever process starts first.  The collectives themselves need GPUs (bench.py --force-dist)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, q)) for r in (2, 1, 0)]   # rank 0 last: the others retry
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == res[2] == bytes(range(128))
