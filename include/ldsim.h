@@ -138,6 +138,15 @@ int ldsim_set_pixel_gains(ldsim_ctx* ctx, const int32_t* keys, const double* val
 int ldsim_clear_pixel_tables(ldsim_ctx* ctx);
 int ldsim_synchronize(ldsim_ctx* ctx);
 
+/* Random streams of the noisy stages: numba.cuda.random.create_xoroshiro128p_states(n, seed) (cli/simulate_pixels.py:
+ * 92-104,396; third-party algorithm restated in csrc/rng.h -- unpinned).  State ip serves pixel row ip of
+ * a get_adc_values call / of a chain launch and is advanced in place like the reference's rng_states[ip]; the table grows
+ * on demand by continuing the 2^64-step jump sequence.  Needed before any call with a non-zero noise charge
+ * (RESET_NOISE_CHARGE, UNCORRELATED_NOISE_CHARGE, DISCRIMINATOR_NOISE): such a call without it returns LDSIM_ESTATE. */
+int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states);
+int ldsim_rng_states_download(ldsim_ctx* ctx, uint64_t* states /* [n][2] = s0, s1 */, int64_t n);
+int ldsim_rng_clear(ldsim_ctx* ctx);
+
 /* ---- (1) stage-by-stage, host buffers ---------------------------------------------------------- */
 /* quenching.quench[bpg,tpb](tracks, mode)            -- reference larndsim/quenching.py:11-44 */
 int ldsim_quench(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout, int32_t mode);
@@ -173,7 +182,8 @@ int ldsim_sum_pixel_signals(ldsim_ctx* ctx, const float* signals, int64_t n, int
                             double* overflow_flag);
 /* fee.get_adc_values[bpg,tpb](pixels_signals, pixels_signals_tracks, time_ticks, adc_list, adc_ticks_list,
  *                             time_padding, rng_states, current_fractions, pixel_thresholds)
- *                                                     -- larndsim/fee.py:517-655 (noise terms must be 0) */
+ *                                                     -- larndsim/fee.py:517-655; with non-zero noise charges rng_states = the
+ *                                                        table of ldsim_rng_seed (state ip for pixel ip) */
 int ldsim_get_adc_values(ldsim_ctx* ctx, const double* pixels_signals, const double* pixels_signals_tracks,
                          int64_t n_unique, int32_t n_ticks, int32_t max_tracks, const double* time_ticks,
                          int32_t n_time_ticks, double time_padding, const double* pixel_thresholds,

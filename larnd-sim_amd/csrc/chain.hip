@@ -315,7 +315,20 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   F.fractions = want_fractions ? (double*)ctx->scratch[SB_FRAC].p : nullptr;
   F.counters = counters;
   F.hit_count = d_hitcnt;
+  // FEE noise (fee.py:557,583-584,616-617,621,649): row u of this launch draws from state u of the numba-style table
+  const bool noisy = h.reset_noise_charge != 0 || h.uncorrelated_noise_charge != 0 || h.discriminator_noise != 0;
+  if (noisy) {
+    CK(rng_ensure_states(ctx, U));
+    const int nd = rng_fee_draws_per_pixel(h, h.n_time_ticks);
+    CK(ldsim_ensure(ctx, SB_NOISE, (size_t)U * nd * 4));
+    CK(ldsim_ensure(ctx, SB_NDRAWS, (size_t)U * 4 + 4));
+    CK(rng_launch_fee_noise(ctx, U, nd, (float*)ctx->scratch[SB_NOISE].p));
+    F.noise_z = (const float*)ctx->scratch[SB_NOISE].p;
+    F.noise_nd = nd;
+    F.n_draws = (int32_t*)ctx->scratch[SB_NDRAWS].p;
+  }
   CK(fee_launch_chain(ctx, F));
+  if (noisy) CK(rng_launch_advance(ctx, U, F.n_draws));
   HIPCHK(hipEventRecord(ctx->ev[3], st));
 
   // ---- compact hit rows (payload of the multi-GPU all-gather) -----------------------------------------------------------------------------

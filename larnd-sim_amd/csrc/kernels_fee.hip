@@ -57,22 +57,30 @@ __device__ __forceinline__ double digitize_one(const LdsimConsts* c, double q, d
 // Runs on wave 0.  S = summed pixel waveform in LDS.  Writes hits into LDS arrays; returns n_hits.
 struct HitRec {
   int lr, b;      // span [lr, b] of ticks whose charge entered the hit
-  double q;       // integrated charge (adc_list) == true_q for zero noise
+  double q;       // adc_list value: integrated charge + the noise terms
+  double tq;      // true_q: integrated charge alone, normalises the backtracking fractions (fee.py:633-635)
   double tick;    // adc_ticks_list value
 };
 
-__device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double thr, double time_padding, int lane,
-                        HitRec* hits /* LDS, [A] */, const double* wtap, int ntap) {
+// z: this pixel's normal draws in stream order (fee_noise_kernel), or NULL when every noise charge is 0.  The reference
+// draws one normal before the loop (reset noise, fee.py:557), two at every pass of the loop (uncorrelated + discriminator
+// noise, :583-584, also on busy ticks), two after an integration (:616-617) and one at every reset (:621,649); *n_draws
+// returns how many were consumed.  t_stop = time_ticks[-1] of linspace(0, t_stop, NT + 1) (cli/simulate_pixels.py:1072).
+__device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_stop, double thr, double time_padding,
+                        int lane, HitRec* hits /* LDS, [A] */, const double* wtap, int ntap, const float* __restrict__ z,
+                        int* n_draws) {
   const double dt = c->time_sampling;
   const bool has_rt = c->buffer_risetime > 0;
   const int A = c->max_adc_values;
   const int interval = (int)py_round((3 * c->clock_cycle + c->adc_hold_delay * c->clock_cycle) / dt);
   const int reset_ticks = (int)py_round(c->reset_cycles * c->clock_cycle / dt);
   const int busy_ticks = (int)py_round(c->adc_busy_delay * c->clock_cycle / dt);
-  const int n_time_ticks = NT + 1;  // time_ticks = linspace(0, n_ev*TIME_INTERVAL[1], N_t+1), cli/simulate_pixels.py:1072
-  const double tstep = (1 * c->time_interval[1]) / (double)NT;
-  int ic = 0, iadc = 0, adc_busy = 0, last_reset = 0;
-  double q_sum = 0;
+  const int n_time_ticks = NT + 1;
+  const double tstep = t_stop / (double)NT;
+  const double s_reset = c->reset_noise_charge, s_unc = c->uncorrelated_noise_charge, s_disc = c->discriminator_noise;
+  int ic = 0, iadc = 0, adc_busy = 0, last_reset = 0, cur = 0;
+  double q_sum = 0, true_q = 0;
+  if (z) q_sum = (double)z[cur++] * s_reset;
   while ((ic < NT || adc_busy > 0) && iadc < A) {
     // one chunk of 64 consecutive ticks
     int my_ic = ic + lane;
@@ -82,19 +90,29 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double th
     unsigned long long live_mask = __ballot(live);
     int n_live = (live_mask == ~0ull) ? 64 : __ffsll((long long)~live_mask) - 1;
     double q = (lane < n_live) ? conv_q(S, NT, my_ic, last_reset, ntap, wtap, dt, has_rt) : 0.0;
-    double qs = q_sum + wave_incl_scan(q, lane);
+    const double incl = wave_incl_scan(q, lane);
+    double qs = q_sum + incl;
+    double q_noise = 0.0, disc_noise = 0.0;
+    if (z && lane < n_live) {
+      q_noise = (double)z[cur + 2 * lane] * s_unc;
+      disc_noise = (double)z[cur + 2 * lane + 1] * s_disc;
+    }
     int busy_after = busy_before > 0 ? busy_before - 1 : 0;
-    bool trig = (lane < n_live) && (qs + 0.0 >= thr + 0.0) && (busy_after == 0);
+    bool trig = (lane < n_live) && (qs + q_noise >= thr + disc_noise) && (busy_after == 0);
     unsigned long long tm = __ballot(trig);
     if (tm == 0) {
+      if (z) cur += 2 * n_live;
       if (n_live < 64) break;
       q_sum = __shfl(qs, 63);
+      true_q += __shfl(incl, 63);
       ic += 64;
       adc_busy = adc_busy > 64 ? adc_busy - 64 : 0;
       continue;
     }
     int f = __ffsll((long long)tm) - 1;
     q_sum = __shfl(qs, f);
+    true_q += __shfl(incl, f);
+    if (z) cur += 2 * (f + 1);
     int ict = ic + f;
     int integrate_end = ict + interval;
     // integrate the next `interval` ticks (fee.py:590-614)
@@ -105,11 +123,18 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double th
       qi += wave_sum(v);
     }
     q_sum += qi;
+    true_q += qi;
     ic = integrate_end + 1;
-    double adc = q_sum + 0.0;
-    if (adc < thr + 0.0) {  // fee.py:619-628
+    double adc = q_sum, disc2 = 0.0;
+    if (z) {
+      adc = q_sum + (double)z[cur] * s_unc;
+      disc2 = (double)z[cur + 1] * s_disc;
+      cur += 2;
+    }
+    if (adc < thr + disc2) {  // fee.py:619-628
       ic += reset_ticks;
-      q_sum = 0;
+      q_sum = z ? (double)z[cur++] * s_reset : 0.0;
+      true_q = 0;
       last_reset = ic;
       adc_busy = 0;
       continue;
@@ -117,18 +142,21 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double th
     if (lane == 0) {
       int crossing = ic < n_time_ticks - 1 ? ic : n_time_ticks - 1;
       int post = ic - crossing > 0 ? ic - crossing : 0;
-      double tt = (crossing == NT) ? (1 * c->time_interval[1]) : crossing * tstep;
+      double tt = (crossing == NT) ? t_stop : crossing * tstep;
       hits[iadc].lr = last_reset;
       hits[iadc].b = integrate_end;
       hits[iadc].q = adc;
+      hits[iadc].tq = true_q;
       hits[iadc].tick = tt + time_padding - 2 + post;
     }
     ic += reset_ticks;
     last_reset = ic;
     adc_busy = busy_ticks;
-    q_sum = 0;
+    q_sum = z ? (double)z[cur++] * s_reset : 0.0;
+    true_q = 0;
     iadc++;
   }
+  *n_draws = cur;
   return iadc;
 }
 
@@ -201,8 +229,13 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   // ---- trigger scan on wave 0 ----------------------------------------------------------------------------------------
   if (wv == 0) {
     const double thr = F.thr_table ? F.thr_table[F.upix[u]] : F.threshold;
-    int nh = adc_scan(c, S, NT, thr, F.time_padding, lane, hits, wtap, ntap);
-    if (lane == 0) s_nh = nh;
+    int nd = 0;
+    int nh = adc_scan(c, S, NT, 1 * c->time_interval[1], thr, F.time_padding, lane, hits, wtap, ntap,
+                      F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd);
+    if (lane == 0) {
+      s_nh = nh;
+      if (F.n_draws) F.n_draws[u] = nd;
+    }
   }
   __syncthreads();
   const int nh = s_nh;
@@ -238,7 +271,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
           }
         }
         acc = wave_sum(acc);
-        if (lane == 0) fr[h * M + k] = hits[h].q > 0 ? acc / hits[h].q : acc;
+        if (lane == 0) fr[h * M + k] = hits[h].tq > 0 ? acc / hits[h].tq : acc;
       }
     }
   }
@@ -312,7 +345,9 @@ __global__ void sum_pixel_signals_kernel(double* pixels_signals, const float* si
 __global__ void __launch_bounds__(FEE_THREADS) adc_dense_kernel(const LdsimConsts* c, const double* pixels_signals,
                                                                 const double* pts, int64_t U, int NT, int M,
                                                                 const double* thresholds, double time_padding,
-                                                                double* adc_list, double* adc_ticks, double* fractions) {
+                                                                double t_stop, const float* noise_z, int noise_nd,
+                                                                int32_t* n_draws, double* adc_list, double* adc_ticks,
+                                                                double* fractions) {
   const int64_t u = blockIdx.x;
   if (u >= U) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -334,8 +369,13 @@ __global__ void __launch_bounds__(FEE_THREADS) adc_dense_kernel(const LdsimConst
     }
   }
   if (wv == 0) {
-    int nh = adc_scan(c, S, NT, thresholds[u], time_padding, lane, hits, wtap, ntap);
-    if (lane == 0) s_nh = nh;
+    int nd = 0;
+    int nh = adc_scan(c, S, NT, t_stop, thresholds[u], time_padding, lane, hits, wtap, ntap,
+                      noise_z ? noise_z + u * (int64_t)noise_nd : nullptr, &nd);
+    if (lane == 0) {
+      s_nh = nh;
+      if (n_draws) n_draws[u] = nd;
+    }
   }
   __syncthreads();
   const int nh = s_nh;
@@ -357,7 +397,7 @@ __global__ void __launch_bounds__(FEE_THREADS) adc_dense_kernel(const LdsimConst
           acc += pts[(u * NT + jc) * M + k] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
         }
         acc = wave_sum(acc);
-        if (lane == 0) fr[h * M + k] = hits[h].q > 0 ? acc / hits[h].q : acc;
+        if (lane == 0) fr[h * M + k] = hits[h].tq > 0 ? acc / hits[h].tq : acc;
       }
   }
 }
@@ -388,7 +428,8 @@ int fee_launch_sum_pixel_signals(ldsim_ctx* ctx, double* ps, const float* signal
   return 0;
 }
 int fee_launch_adc_dense(ldsim_ctx* ctx, const double* ps, const double* pts, int64_t U, int NT, int M,
-                         const double* thr, double time_padding, double* adc, double* ticks, double* frac) {
+                         const double* thr, double time_padding, double t_stop, const float* noise_z, int noise_nd,
+                         int32_t* n_draws, double* adc, double* ticks, double* frac) {
   if (U == 0) return 0;
   const LdsimConsts& h = ctx->h_consts;
   if (NT > NT_MAX || h.max_adc_values > A_MAX || (h.buffer_risetime > 0 && 10 * h.buffer_risetime / h.time_sampling > 62)) {
@@ -396,7 +437,7 @@ int fee_launch_adc_dense(ldsim_ctx* ctx, const double* ps, const double* pts, in
     return LDSIM_EINVAL;
   }
   hipLaunchKernelGGL(adc_dense_kernel, dim3((unsigned)U), dim3(FEE_THREADS), 0, ctx->stream, ctx->d_consts, ps, pts, U,
-                     NT, M, thr, time_padding, adc, ticks, frac);
+                     NT, M, thr, time_padding, t_stop, noise_z, noise_nd, n_draws, adc, ticks, frac);
   HIPCHK(hipGetLastError());
   return 0;
 }

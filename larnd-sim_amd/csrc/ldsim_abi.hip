@@ -24,8 +24,12 @@ int fee_launch_track_pixel_map(ldsim_ctx*, int64_t*, const int32_t*, int64_t, co
                                int, int, int);
 int fee_launch_sum_pixel_signals(ldsim_ctx*, double*, const float*, const double*, const int64_t*, const int64_t*,
                                  double*, double*, int64_t, int, int, int, int);
-int fee_launch_adc_dense(ldsim_ctx*, const double*, const double*, int64_t, int, int, const double*, double, double*,
-                         double*, double*);
+int fee_launch_adc_dense(ldsim_ctx*, const double*, const double*, int64_t, int, int, const double*, double, double,
+                         const float*, int, int32_t*, double*, double*, double*);
+int rng_ensure_states(ldsim_ctx* ctx, int64_t n);
+int rng_fee_draws_per_pixel(const LdsimConsts& h, int NT);
+int rng_launch_fee_noise(ldsim_ctx* ctx, int64_t U, int nd, float* z);
+int rng_launch_advance(ldsim_ctx* ctx, int64_t U, const int32_t* n_draws);
 int fee_launch_digitize(ldsim_ctx*, const double*, const double*, double*, int64_t);
 int light_launch_incidence(ldsim_ctx*, int64_t, int64_t, int, float*, float*, int32_t*, int);
 int light_launch_t0_range(ldsim_ctx*, const float*, const float*, int64_t, int*);
@@ -192,6 +196,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);
   (void)ldsim_comm_destroy(ctx);
+  if (ctx->d_rng.p) (void)hipFree(ctx->d_rng.p);
   for (DevBuf* b : {&ctx->comm_tmp, &ctx->hits_acc, &ctx->hits_all})
     if (b->p) (void)hipFree(b->p);
   (void)hipStreamDestroy(ctx->stream);
@@ -600,37 +605,37 @@ extern "C" int ldsim_get_adc_values(ldsim_ctx* ctx, const double* ps, const doub
                                     int32_t M, const double* time_ticks, int32_t n_time_ticks, double time_padding,
                                     const double* thresholds, double* adc_list, double* adc_ticks, double* fractions) {
   NEED(ctx && ps && thresholds && adc_list && adc_ticks, "null argument");
-  NEED(ctx->h_consts.reset_noise_charge == 0 && ctx->h_consts.uncorrelated_noise_charge == 0 &&
-           ctx->h_consts.discriminator_noise == 0,
-       "FEE noise must be 0: the reference's Numba xoroshiro128p stream is not reproduced");
   NEED(n_time_ticks == NT + 1 && time_ticks, "time_ticks must be linspace(0, stop, N_t+1)");
-  // the kernel regenerates linspace(0, stop, N_t+1); honour the caller's stop value
   HIPCHK(hipSetDevice(ctx->device));
-  LdsimConsts saved = ctx->h_consts;
-  LdsimConsts tmp = saved;
-  tmp.time_interval[1] = time_ticks[NT];
-  tmp.n_time_ticks = NT;
-  CK(ldsim_set_consts(ctx, &tmp));
-  const int A = saved.max_adc_values;
-  Tmp dps, dpts, dthr, dadc, dtk, dfr;
+  const LdsimConsts& h = ctx->h_consts;
+  const bool noisy = h.reset_noise_charge != 0 || h.uncorrelated_noise_charge != 0 || h.discriminator_noise != 0;
+  const int A = h.max_adc_values;
+  Tmp dps, dpts, dthr, dadc, dtk, dfr, dz, dnd;
   CK(dps.alloc((size_t)U * NT * 8)); CK(dthr.alloc(U * 8)); CK(dadc.alloc((size_t)U * A * 8)); CK(dtk.alloc((size_t)U * A * 8));
   if (pts) CK(dpts.alloc((size_t)U * NT * M * 8));
   if (fractions) CK(dfr.alloc((size_t)U * A * M * 8));
+  int nd = 0;
+  if (noisy) {      // rng_states[ip] of the reference's call (fee.py:557): state ip of the table, advanced in place
+    CK(rng_ensure_states(ctx, U));
+    nd = rng_fee_draws_per_pixel(h, NT);
+    CK(dz.alloc((size_t)U * nd * 4)); CK(dnd.alloc((size_t)U * 4 + 4));
+    CK(rng_launch_fee_noise(ctx, U, nd, dz.as<float>()));
+  }
   HIPCHK(hipMemcpyAsync(dps.p, ps, (size_t)U * NT * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(dthr.p, thresholds, U * 8, hipMemcpyHostToDevice, ctx->stream));
   if (pts) HIPCHK(hipMemcpyAsync(dpts.p, pts, (size_t)U * NT * M * 8, hipMemcpyHostToDevice, ctx->stream));
   if (fractions) HIPCHK(hipMemsetAsync(dfr.p, 0, (size_t)U * A * M * 8, ctx->stream));
-  int rc = fee_launch_adc_dense(ctx, dps.as<double>(), pts ? dpts.as<double>() : nullptr, U, NT, M, dthr.as<double>(),
-                                time_padding, dadc.as<double>(), dtk.as<double>(),
-                                (fractions && pts) ? dfr.as<double>() : nullptr);
-  if (!rc) {
-    HIPCHK(hipMemcpyAsync(adc_list, dadc.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(adc_ticks, dtk.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (fractions) HIPCHK(hipMemcpyAsync(fractions, dfr.p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
-  int rc2 = ldsim_set_consts(ctx, &saved);
-  return rc ? rc : rc2;
+  // the kernel regenerates linspace(0, stop, N_t+1) from the caller's stop value (cli/simulate_pixels.py:1072)
+  CK(fee_launch_adc_dense(ctx, dps.as<double>(), pts ? dpts.as<double>() : nullptr, U, NT, M, dthr.as<double>(),
+                          time_padding, time_ticks[NT], noisy ? dz.as<float>() : nullptr, nd,
+                          noisy ? dnd.as<int32_t>() : nullptr, dadc.as<double>(), dtk.as<double>(),
+                          (fractions && pts) ? dfr.as<double>() : nullptr));
+  if (noisy) CK(rng_launch_advance(ctx, U, dnd.as<int32_t>()));
+  HIPCHK(hipMemcpyAsync(adc_list, dadc.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(adc_ticks, dtk.p, (size_t)U * A * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (fractions) HIPCHK(hipMemcpyAsync(fractions, dfr.p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 extern "C" int ldsim_digitize(ldsim_ctx* ctx, const double* integral, int64_t n, const double* gain, double* adcs) {
@@ -967,9 +972,6 @@ extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg
   NEED(ctx->d_resp, "no response table set (ldsim_set_response)");
   NEED_RESIDENT(ctx);
   NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
-  NEED(ctx->h_consts.reset_noise_charge == 0 && ctx->h_consts.uncorrelated_noise_charge == 0 &&
-           ctx->h_consts.discriminator_noise == 0,
-       "FEE noise must be 0: the reference's Numba xoroshiro128p stream is not reproduced");
   HIPCHK(hipSetDevice(ctx->device));
   int rc;
   try {

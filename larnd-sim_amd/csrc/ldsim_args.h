@@ -56,9 +56,17 @@ struct FeeArgs {
   double* fractions;          // [U][A][M] or NULL
   unsigned long long* counters;  // [2] overflow pixels, [3] hits
   int32_t* hit_count;         // [U]
+  // FEE noise (fee.py:557,583-584,616-617,621,649): normals drawn ahead by fee_noise_kernel, or NULL = all noise charges 0
+  const float* noise_z;       // [U][noise_nd]
+  int32_t noise_nd;
+  int32_t* n_draws;           // [U] normals the scan consumed
 };
 
 int current_launch(ldsim_ctx* ctx, const CurArgs& args);
+int rng_ensure_states(ldsim_ctx* ctx, int64_t n);
+int rng_fee_draws_per_pixel(const LdsimConsts& h, int NT);
+int rng_launch_fee_noise(ldsim_ctx* ctx, int64_t U, int nd, float* z);
+int rng_launch_advance(ldsim_ctx* ctx, int64_t U, const int32_t* n_draws);
 int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F);
 int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
                          unsigned long long wbuf_cap, unsigned long long* cursor);

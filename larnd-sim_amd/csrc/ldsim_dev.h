@@ -134,6 +134,11 @@ struct ldsim_ctx {
   DevBuf light_tmp[9];
   double ms_light_inc = 0, ms_light_sum = 0;
   hipEvent_t evl[4] = {nullptr, nullptr, nullptr, nullptr};
+  // random streams (kernels_rng.hip): numba-style table of xoroshiro128p states, grown on demand
+  DevBuf d_rng;
+  int64_t rng_n = 0;
+  uint64_t rng_seed = 0, rng_last_init[2] = {0, 0};
+  int rng_seeded = 0;
   // multi-GPU exchange (comm.hip): RCCL communicator, rows accumulated over the chain calls of a pass, gathered rows
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 0;
@@ -152,7 +157,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS
 };
 
 void ldsim_set_error(const char* fmt, ...);

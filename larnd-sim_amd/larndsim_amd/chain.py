@@ -22,6 +22,13 @@ class ChargeChain:
         if response is not None:
             lib.set_response(response, self.ctx)
 
+    def seed_rng(self, seed, n_states=1024 * 256):
+        """``create_xoroshiro128p_states(1024*256, seed=rand_seed)`` of the driver (cli/simulate_pixels.py:396): needed before
+        ``run`` when a FEE noise charge is non-zero.  Row u of a launch draws from state u of the table."""
+        from . import rng
+        self.rng_states = rng.create_xoroshiro128p_states(n_states, seed, self.ctx)
+        return self.rng_states
+
     def _check_constants(self):
         """The ctx is process-wide and this object froze its constants at construction: refuse to compute once anything
         (another ChargeChain, a stage call after ``consts`` was reloaded) has frozen different ones."""

@@ -34,9 +34,10 @@ def load_pixel_table(filename):
 @kernel
 def get_adc_values(pixels_signals, pixels_signals_tracks, time_ticks, adc_list, adc_ticks_list, time_padding,
                    rng_states, current_fractions, pixel_thresholds):
-    """``get_adc_values[bpg, tpb](...)`` with the reference's argument order.  ``rng_states`` is ignored: the
-    FEE noise constants must be 0 (the Numba xoroshiro128p stream is not reproduced); a non-zero noise
-    constant raises."""
+    """``get_adc_values[bpg, tpb](...)`` with the reference's argument order.  With non-zero noise charges
+    (RESET_NOISE_CHARGE, UNCORRELATED_NOISE_CHARGE, DISCRIMINATOR_NOISE) the normals come from the state table of
+    ``rng.create_xoroshiro128p_states`` (``rng_states``: its handle, or None to use the table as it stands): state ``ip``
+    for pixel ``ip``, advanced in place like the reference's ``rng_states[ip]`` (fee.py:557,583-584,616-617,621,649)."""
     ps = np.ascontiguousarray(pixels_signals, dtype=np.float64)
     U, NT = ps.shape
     pts = None if pixels_signals_tracks is None else np.ascontiguousarray(pixels_signals_tracks, dtype=np.float64)

@@ -36,6 +36,7 @@ EXPORTS = [
     "ldsim_chain_download", "ldsim_chain_compact_hits", "ldsim_chain_kernel_ms", "ldsim_chain_kernel_ms_detail",
     "ldsim_dev_light_incidence", "ldsim_dev_light_incidence_download", "ldsim_dev_light_t0_range", "ldsim_dev_sum_light",
     "ldsim_dev_light_download", "ldsim_light_kernel_ms",
+    "ldsim_rng_seed", "ldsim_rng_states_download", "ldsim_rng_clear",
     "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
     "ldsim_comm_allgather_hits", "ldsim_comm_gathered_download",
 ]

@@ -488,11 +488,74 @@ int o_sum_pixel_signals(double* pixels_signals, const float* signals, const doub
   return 0;
 }
 
-/* ---- a15: fee.get_adc_values  (fee.py:517-655), noise terms = 0 -------------------------------- */
+/* ---- a15: fee.get_adc_values  (fee.py:517-655) ---------------------------------------------------------------
+ * rng = NULL: noise terms 0 (the deterministic path every golden pins).  rng != NULL: rng[ip] is pixel ip's
+ * xoroshiro128p state, advanced in place like the reference's rng_states[ip] (restatement above: unpinned). */
+/* ---- numba.cuda.random (third-party, module `numba`, setup.py:5 `numba>=0.52`, unpinned; NOT present under /root/reference)
+ * Restated from the published algorithm of numba/cuda/random.py: xoroshiro128+ ("xoroshiro128p"), state {s0, s1} u64;
+ *   init_xoroshiro128p_state: SplitMix64 of the seed into BOTH words;  next: result = s0 + s1; s1 ^= s0;
+ *   s0 = rotl(s0, 55) ^ s1 ^ (s1 << 14); s1 = rotl(s1, 36);  jump: the 2^64-step polynomial {0xbeac0467eba5facb,
+ *   0xd86b048b86aa9922};  create_xoroshiro128p_states(n, seed): state 0 = init(seed), state i = state i-1 jumped once;
+ *   uniform_float32 = float32((x >> 11) * 2^-53);  normal_float32 = Box-Muller in float32 from two uniforms, second value
+ *   discarded:  sqrt(-2 log u1) * cos(2 pi u2).
+ * Call sites: fee.py:557,583-584,616-617,621,649; detsim.py:331,336-337; seeding cli/simulate_pixels.py:92-104,396.
+ * No reference test pins any RNG-dependent value and Numba cannot run here: PARITY UNPINNED for every noisy output -- the HIP
+ * path is tested bit-identical to THIS restatement plus statistical closure. */
+typedef struct { uint64_t s0, s1; } ORng;
+static uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t o_rng_next(ORng* st) {
+  uint64_t s0 = st->s0, s1 = st->s1, result = s0 + s1;
+  s1 ^= s0;
+  st->s0 = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
+  st->s1 = rotl64(s1, 36);
+  return result;
+}
+static void rng_jump(ORng* st) {
+  static const uint64_t JUMP[2] = {0xbeac0467eba5facbULL, 0xd86b048b86aa9922ULL};
+  uint64_t s0 = 0, s1 = 0;
+  for (int i = 0; i < 2; i++)
+    for (int b = 0; b < 64; b++) {
+      if (JUMP[i] & (1ULL << b)) { s0 ^= st->s0; s1 ^= st->s1; }
+      o_rng_next(st);
+    }
+  st->s0 = s0;
+  st->s1 = s1;
+}
+void o_rng_create_states(ORng* states, int64_t n, uint64_t seed) {
+  if (n < 1) return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  states[0].s0 = z;
+  states[0].s1 = z;
+  for (int64_t i = 1; i < n; i++) {
+    states[i] = states[i - 1];
+    rng_jump(&states[i]);
+  }
+}
+float o_rng_uniform_f32(ORng* st) { return (float)((double)(o_rng_next(st) >> 11) * (1.0 / 9007199254740992.0)); }
+float o_rng_normal_f32(ORng* st) {
+  float u1 = o_rng_uniform_f32(st), u2 = o_rng_uniform_f32(st);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+int o_get_adc_values_rng(const double* pixels_signals, const double* pixels_signals_tracks, const double* time_ticks,
+                         int64_t n_time_ticks, double* adc_list, double* adc_ticks_list, double time_padding,
+                         double* current_fractions, const double* thresholds, int64_t U, int64_t NT, int64_t M,
+                         const LdsimConsts* c, ORng* rng);
 int o_get_adc_values(const double* pixels_signals, const double* pixels_signals_tracks /* [U][NT][M] or NULL */,
                      const double* time_ticks, int64_t n_time_ticks, double* adc_list, double* adc_ticks_list,
                      double time_padding, double* current_fractions /* [U][A][M] or NULL */,
                      const double* thresholds, int64_t U, int64_t NT, int64_t M, const LdsimConsts* c) {
+  return o_get_adc_values_rng(pixels_signals, pixels_signals_tracks, time_ticks, n_time_ticks, adc_list, adc_ticks_list,
+                              time_padding, current_fractions, thresholds, U, NT, M, c, NULL);
+}
+#define NORMAL(ip) (rng ? (double)o_rng_normal_f32(&rng[ip]) : 0.0)
+int o_get_adc_values_rng(const double* pixels_signals, const double* pixels_signals_tracks, const double* time_ticks,
+                         int64_t n_time_ticks, double* adc_list, double* adc_ticks_list, double time_padding,
+                         double* current_fractions, const double* thresholds, int64_t U, int64_t NT, int64_t M,
+                         const LdsimConsts* c, ORng* rng) {
   const int64_t A = c->max_adc_values;
   const double dt = c->time_sampling, rt = c->buffer_risetime;
   for (int64_t ip = 0; ip < U; ip++) {
@@ -500,7 +563,7 @@ int o_get_adc_values(const double* pixels_signals, const double* pixels_signals_
     const double* trk = pixels_signals_tracks ? pixels_signals_tracks + ip * NT * M : NULL;
     double* frac = current_fractions ? current_fractions + ip * A * M : NULL;
     int64_t ic = 0, iadc = 0, adc_busy = 0, last_reset = 0;
-    double true_q = 0, q_sum = 0.0 * c->reset_noise_charge;
+    double true_q = 0, q_sum = NORMAL(ip) * c->reset_noise_charge;
     while (ic < NT || adc_busy > 0) {
       if (iadc >= A) break;
       double q = 0;
@@ -521,8 +584,10 @@ int o_get_adc_values(const double* pixels_signals, const double* pixels_signals_
       }
       q_sum += q;
       true_q += q;
+      double q_noise = NORMAL(ip) * c->uncorrelated_noise_charge;
+      double disc_noise = NORMAL(ip) * c->discriminator_noise;
       if (adc_busy > 0) adc_busy--;
-      if (q_sum + 0.0 >= thresholds[ip] + 0.0 && adc_busy == 0) {
+      if (q_sum + q_noise >= thresholds[ip] + disc_noise && adc_busy == 0) {
         int64_t interval = (int64_t)py_round((3 * c->clock_cycle + c->adc_hold_delay * c->clock_cycle) / dt);
         int64_t integrate_end = ic + interval;
         ic++;
@@ -547,10 +612,11 @@ int o_get_adc_values(const double* pixels_signals, const double* pixels_signals_
           true_q += q;
           ic++;
         }
-        double adc = q_sum + 0.0;
-        if (adc < thresholds[ip] + 0.0) {
+        double adc = q_sum + NORMAL(ip) * c->uncorrelated_noise_charge;
+        disc_noise = NORMAL(ip) * c->discriminator_noise;
+        if (adc < thresholds[ip] + disc_noise) {
           ic += (int64_t)py_round(c->reset_cycles * c->clock_cycle / dt);
-          q_sum = 0.0;
+          q_sum = NORMAL(ip) * c->reset_noise_charge;
           true_q = 0;
           if (frac)
             for (int64_t k = 0; k < M; k++) frac[iadc * M + k] = 0;
@@ -566,7 +632,7 @@ int o_get_adc_values(const double* pixels_signals, const double* pixels_signals_
         ic += (int64_t)py_round(c->reset_cycles * c->clock_cycle / dt);
         last_reset = ic;
         adc_busy = (int64_t)py_round(c->adc_busy_delay * c->clock_cycle / dt);
-        q_sum = 0.0;
+        q_sum = NORMAL(ip) * c->reset_noise_charge;
         true_q = 0;
         iadc++;
         continue;

@@ -182,9 +182,46 @@ def sum_pixel_signals(signals, track_starts, pim, tpm, U, want_tracks=True):
     return ps, pts, ovf
 
 
+RNG_DTYPE = np.dtype([("s0", "<u8"), ("s1", "<u8")])     # numba.cuda.random.xoroshiro128p_dtype
+
+
+def rng_create_states(n, seed):
+    """numba.cuda.random.create_xoroshiro128p_states(n, seed) restated (oracle/ldsim_oracle.c: unpinned)."""
+    st = np.zeros(n, dtype=RNG_DTYPE)
+    lib().o_rng_create_states(_p(st), C.c_int64(n), C.c_uint64(int(seed) & (2 ** 64 - 1)))
+    return st
+
+
+def rng_normals(states, index, count):
+    """`count` successive xoroshiro128p_normal_float32(states, index) draws (advances states[index])."""
+    l = lib()
+    l.o_rng_normal_f32.restype = C.c_float
+    out = np.zeros(count, dtype=np.float32)
+    ptr = C.c_void_p(states.ctypes.data + int(index) * RNG_DTYPE.itemsize)
+    for i in range(count):
+        out[i] = l.o_rng_normal_f32(ptr)
+    return out
+
+
 def get_adc_values(pixels_signals, pixels_tracks_signals, time_ticks, thresholds, time_padding=0.0,
-                   want_fractions=True):
+                   want_fractions=True, rng_states=None):
+    """rng_states = None: noise terms 0.  Else the xoroshiro128p states (RNG_DTYPE, one per pixel, advanced in place) and the
+    noise charges of ``consts.detector`` as they stand."""
     c = _consts()
+    if rng_states is not None:
+        c = _consts(noise_zero=False)
+        U, NT = pixels_signals.shape
+        A = c.max_adc_values
+        M = pixels_tracks_signals.shape[2] if pixels_tracks_signals is not None else c.max_tracks_per_pixel
+        adc = np.zeros((U, A)); ticks = np.zeros((U, A))
+        frac = np.zeros((U, A, M)) if (want_fractions and pixels_tracks_signals is not None) else None
+        assert rng_states.dtype == RNG_DTYPE and len(rng_states) >= U
+        lib().o_get_adc_values_rng(_p(np.ascontiguousarray(pixels_signals)), _p(pixels_tracks_signals),
+                                   _p(np.ascontiguousarray(time_ticks)), C.c_int64(len(time_ticks)), _p(adc), _p(ticks),
+                                   C.c_double(time_padding), _p(frac),
+                                   _p(np.ascontiguousarray(thresholds, dtype=np.float64)), C.c_int64(U), C.c_int64(NT),
+                                   C.c_int64(M), C.byref(c), _p(rng_states))
+        return adc, ticks, frac
     U, NT = pixels_signals.shape
     A = c.max_adc_values
     M = pixels_tracks_signals.shape[2] if pixels_tracks_signals is not None else c.max_tracks_per_pixel

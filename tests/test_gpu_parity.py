@@ -10,7 +10,7 @@ import pytest
 
 import helpers as H
 from larndsim_amd import (batching, consts, detsim, drifting, fee, lib, light_sim, lightLUT, pixels_from_track,
-                          quenching, synth)
+                          quenching, rng as lrng, synth)
 from larndsim_amd.chain import ChargeChain
 from larndsim_amd.layout import segments_dtype
 from oracle import oracle as O
@@ -249,7 +249,7 @@ def test_fused_chain_golden():
         assert st.n_unique == len(g["unique_pix"]) and st.max_length == int(g["max_length"])
 
 
-def _oracle_chain(seg, response, thr_of_pixel=None, gain_of_pixel=None):
+def _oracle_chain(seg, response, thr_of_pixel=None, gain_of_pixel=None, rng_states=None):
     """Reference dataflow on the oracle; `thr_of_pixel` / `gain_of_pixel` are dense arrays over pixel ids standing for
     the driver's pixel_thresholds_lut[unique_pix] / pixel_gains_lut[unique_pix] (cli/simulate_pixels.py:1079-1100)."""
     ref = seg.copy()
@@ -268,7 +268,7 @@ def _oracle_chain(seg, response, thr_of_pixel=None, gain_of_pixel=None):
     tt = np.linspace(0, consts.detector.TIME_INTERVAL[1], ps.shape[1] + 1)
     thr = (np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD) if thr_of_pixel is None
            else np.ascontiguousarray(thr_of_pixel[upix]))
-    adc, ticks, frac = O.get_adc_values(ps, pts, tt, thr)
+    adc, ticks, frac = O.get_adc_values(ps, pts, tt, thr, rng_states=rng_states)
     gain = None if gain_of_pixel is None else gain_of_pixel[upix][:, None] * np.ones((1, adc.shape[1]))
     return dict(unique_pix=upix, tpm=tpm, adc=adc, ticks=ticks, frac=frac, digit=O.digitize(adc, gain), ref=ref)
 
@@ -553,12 +553,17 @@ def test_boundary_refuses_misuse_and_stays_usable():
         lib.set_option("no_such_option", 1)
     with pytest.raises(ValueError, match="differ in length"):
         ch.set_pixel_thresholds(np.arange(3), np.ones(2), 1.0)
-    # FEE noise is refused (the reference's RNG stream is not reproduced), not silently dropped
+    # FEE noise needs a seeded state table (ldsim_rng_seed): without one the call is refused, not run noise-free
     consts.detector.RESET_NOISE_CHARGE = 900.0
     try:
         noisy = ChargeChain(resp)
-        with pytest.raises(lib.LdsimError, match="FEE noise must be 0"):
+        lib.check(lib.load().ldsim_rng_clear(noisy.ctx))
+        noisy.upload(seg, bid)
+        noisy.quench_drift()
+        with pytest.raises(lib.LdsimError, match="ldsim_rng_seed first"):
             noisy.run(0, len(seg))
+        noisy.seed_rng(3)
+        noisy.run(0, len(seg))
     finally:
         consts.detector.RESET_NOISE_CHARGE = 0
     # decreasing batch ids are refused at upload; the previous upload is what stays resident is not promised, so upload again
@@ -908,6 +913,108 @@ def test_light_properties_baseline_sizes():
                                    atol=1e-3)
         checked += e - b
     assert checked == n_sim
+
+
+def test_fee_noise_stream_vs_oracle():
+    """FEE noise (fee.py:557,583-584,616-617,621,649) with the xoroshiro128p + Box-Muller generator Numba documents
+    (csrc/rng.h; oracle/ldsim_oracle.c holds the same restatement -- the stream is third-party and unpinned).  On the
+    golden chain's pixel waveforms: the states after the call are bit-identical to the oracle's, i.e. every pixel drew
+    exactly as many numbers as the oracle did (same triggers, failed triggers and resets); hit slots and tick stamps
+    agree; charges agree to the float32 normals' last bit (device vs host logf / cosf)."""
+    H.load_cfg("module0", noise_zero=False)
+    d = consts.detector
+    assert d.RESET_NOISE_CHARGE > 0 and d.UNCORRELATED_NOISE_CHARGE > 0 and d.DISCRIMINATOR_NOISE > 0
+    g = H.gold("chain_module0.npz")
+    ps = np.ascontiguousarray(g["pixels_signals"], dtype=np.float64)
+    U, NT = ps.shape
+    # more pixels, with charges around the threshold so that the noise decides: scaled copies of the golden waveforms
+    scale = np.r_[np.ones(U), np.linspace(0.05, 1.5, 40 * U)]
+    ps = np.concatenate([ps] + [ps] * 40) * scale[:, None]
+    pts = None
+    U = ps.shape[0]
+    tt = np.linspace(0, d.TIME_INTERVAL[1], NT + 1)
+    thr = np.full(U, d.DISCRIMINATION_THRESHOLD * 1.0)
+    st = O.rng_create_states(U, 20241016)
+    adc_o, ticks_o, _ = O.get_adc_values(ps, pts, tt, thr, rng_states=st)
+    A = consts.sim.MAX_ADC_VALUES
+    adc = np.zeros((U, A)); ticks = np.zeros((U, A))
+    states = lrng.create_xoroshiro128p_states(U, 20241016)
+    assert np.array_equal(states.copy_to_host().view(np.uint64), O.rng_create_states(U, 20241016).view(np.uint64))
+    fee.get_adc_values[1, 128](ps, pts, tt, adc, ticks, 0, states, None, thr)
+    after = states.copy_to_host()
+    assert np.array_equal(after.view(np.uint64).ravel(), st.view(np.uint64).ravel()), "draw counts differ from the oracle"
+    assert np.array_equal(adc != 0, adc_o != 0) and (adc_o != 0).sum() > 100
+    assert np.array_equal(ticks, ticks_o)
+    np.testing.assert_allclose(adc, adc_o, rtol=1e-6, atol=1e-2)
+    # the noise really acted: against the noise-free scan some hits appear / vanish and the charges differ
+    H.load_cfg("module0", noise_zero=True)
+    adc0 = np.zeros((U, A)); ticks0 = np.zeros((U, A))
+    fee.get_adc_values[1, 128](ps, pts, tt, adc0, ticks0, 0, None, None, thr)
+    assert not np.array_equal(adc != 0, adc0 != 0)
+    both = (adc != 0) & (adc0 != 0)
+    assert np.abs(adc[both] - adc0[both]).mean() > 300          # ~ sqrt(900^2 + 500^2) electrons of reset + uncorrelated noise
+
+
+def test_fee_noise_statistical_closure():
+    """Noise closure on 40 000 identical pixels carrying one 20 ke- pulse: every pixel triggers once at the pulse, the
+    reported charge is the pulse plus reset noise (drawn at the previous reset) plus uncorrelated noise, i.e. spread
+    sqrt(RESET^2 + UNCORRELATED^2) = 1030 e-; pixels without signal do not trigger (threshold at 5.8 sigma)."""
+    H.load_cfg("module0", noise_zero=False)
+    d = consts.detector
+    NT = len(d.TIME_TICKS)
+    U = 40_000
+    q_pulse = 20_000.0
+    ps = np.zeros((U, NT))
+    ps[: U // 2, 700] = q_pulse / d.TIME_SAMPLING
+    tt = np.linspace(0, d.TIME_INTERVAL[1], NT + 1)
+    thr = np.full(U, d.DISCRIMINATION_THRESHOLD * 1.0)
+    A = consts.sim.MAX_ADC_VALUES
+    adc = np.zeros((U, A)); ticks = np.zeros((U, A))
+    states = lrng.create_xoroshiro128p_states(U, 11)
+    fee.get_adc_values[1, 128](ps, None, tt, adc, ticks, 0, states, None, thr)
+    sig, empty = adc[: U // 2], adc[U // 2:]
+    assert (empty != 0).sum() <= 2
+    first = sig[:, 0]
+    assert (first != 0).all()
+    assert ((sig[:, 1:] != 0).sum(axis=1) == 0).mean() > 0.995       # no second hit (the tail after the reset is ~1 % of the pulse)
+    sigma = np.hypot(d.RESET_NOISE_CHARGE, d.UNCORRELATED_NOISE_CHARGE)
+    assert abs(first.std() - sigma) < 0.03 * sigma
+    assert abs(first.mean() - q_pulse) < 0.01 * q_pulse + 4 * sigma / np.sqrt(U // 2)
+
+
+def test_fused_chain_with_fee_noise_vs_oracle():
+    """The fused chain with the shipped noise charges: row u of the launch draws from state u of the table, so the oracle
+    run per batch with the matching slice of states reproduces the launch: same hits, ticks and codes, charges to the
+    float32 normals' last bit, and the table ends in the same states."""
+    H.load_cfg("module0", noise_zero=False)
+    seg = synth.make_segments(16, seed=21, segs_per_event=8)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    resp = H.response_for("survey")
+    ch = ChargeChain(resp)
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.seed_rng(5)
+    st = ch.run(0, len(seg), want_fractions=True)
+    out = ch.download()
+    states = O.rng_create_states(int(st.n_unique), 5)
+    u0 = 0
+    assert len(table) >= 2
+    for b in range(len(table)):
+        m = out["batch"] == b
+        nb = int(m.sum())
+        sl = states[u0:u0 + nb]
+        o = _oracle_chain(seg[bid == b], resp, rng_states=sl)
+        states[u0:u0 + nb] = sl
+        u0 += nb
+        assert np.array_equal(out["unique_pix"][m], o["unique_pix"])
+        assert np.array_equal(out["adc_list"][m] != 0, o["adc"] != 0)
+        np.testing.assert_allclose(out["adc_list"][m], o["adc"], rtol=1e-5, atol=1e-2)
+        assert np.array_equal(out["adc_ticks_list"][m], o["ticks"])
+        hit = o["adc"] != 0
+        np.testing.assert_allclose(out["current_fractions"][m][hit], o["frac"][hit], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(ch.rng_states.copy_to_host(u0).view(np.uint64).ravel(), states.view(np.uint64).ravel())
 
 
 def _two_event_set(cfg, seed, n=1200):
