@@ -92,7 +92,8 @@ typedef struct {
   double singlet_fraction, tau_s, tau_t;
   double light_response_time, light_oscillation_period, impulse_tick_size;
   int32_t sipm_response_model;             /* 0 = RLC model, 1 = measured impulse (IMPULSE_MODEL passed as an array) */
-  int32_t reserved_;
+  int32_t mc_sample_multiplier;            /* sim.MC_SAMPLE_MULTIPLIER (ABI 3, tracks_current_mc, detsim.py:318-323) */
+  double min_step_size;                    /* sim.MIN_STEP_SIZE [cm] */
 } LdsimConsts;
 
 typedef struct ldsim_ctx ldsim_ctx;
@@ -121,6 +122,13 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * demand and the launch is repeated when it was exhausted, so this only affects the first launches; setting it forgets
  * the size learned so far), "split_max_items" (validation: pairs with more weight items than this are recomputed by
  * the monolithic kernel; 0 = the built-in capacity: 512 items at TIME_SAMPLING/RESPONSE_SAMPLING = 1, 2048 at 2),
+ * "weights_mode" (split path, weights stage: 1 = qweights_kernel, Gauss-Legendre quadrature along the segment (default);
+ * 0 = weights_kernel, the closed form per charge sample), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
+ * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
+ * "numba_f32" (1 = the sub-expressions Numba types float32 for f4 record fields are evaluated in float, detsim.py:74-79,
+ * 116-118,141,387; 0 = all-f64, what the reference computes for f8 records and what the goldens pin; default 0),
+ * "mc_current" (1 = the fused chain takes its induced currents from tracks_current_mc like the reference driver does;
+ * default 0 = tracks_current),
  * "debug_phases" (timing tools only, tools/phase_timing3.py: bit mask that drops phases of the tracks_current kernels;
  * results are wrong unless it is 15, the default).  An unknown name returns LDSIM_EINVAL. */
 int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value);
@@ -168,6 +176,13 @@ int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const Ld
  *                                                     -- larndsim/detsim.py:351-453 */
 int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                          const int32_t* pixels, int32_t max_neigh, float* signals, int32_t n_ticks);
+/* detsim.tracks_current_mc[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response, rng_states) -- larndsim/detsim.py:258-348,
+ * what the reference driver calls (cli/simulate_pixels.py:1016).  The reference lets all tick threads of a (segment, pixel)
+ * race on rng_states[itrk + ntrk*ipix]; here every (segment, pixel, tick) draws from its own stream derived from that state
+ * (SplitMix64 of its words and the tick index), so the result is reproducible and statistically equivalent, not equal.
+ * Needs ldsim_rng_seed; the table is grown to n * max_neigh states and each used state is stepped once afterwards. */
+int ldsim_tracks_current_mc(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                            const int32_t* pixels, int32_t max_neigh, float* signals, int32_t n_ticks);
 /* detsim.get_track_pixel_map2[bpg,tpb](track_pixel_map, unique_pix, pixels, distances, max_distance)
  *                                                     -- larndsim/detsim.py:564-607 */
 int ldsim_track_pixel_map(ldsim_ctx* ctx, const int32_t* unique_pix, int64_t n_unique,

@@ -49,7 +49,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
 }
 
 // materialising tracks_current: dense [S][P] pixel array, signals [S][P][T]
-int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T) {
+int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc) {
   CK(ldsim_ensure(ctx, SB_MISC, 4096));
   unsigned long long* counters = (unsigned long long*)((char*)ctx->scratch[SB_MISC].p + 256);
   HIPCHK(hipMemsetAsync(counters, 0, 64, ctx->stream));
@@ -65,7 +65,7 @@ int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* 
   a.tmax_batch = nullptr;
   a.batch0 = 0;
   a.counters = counters;
-  return current_launch(ctx, a);
+  return mc ? current_mc_launch(ctx, a, ctx->seg.n) : current_launch(ctx, a);
 }
 
 int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions) {
@@ -238,7 +238,10 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   bool split_done = false, split_timed = false;
   size_t ib = 0, hb = 0, cb = 0;
-  if (ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0) {
+  if (ctx->mc_current) {     // the driver's call site (cli/simulate_pixels.py:1016): Monte-Carlo currents, seeded table needed
+    CK(current_mc_launch(ctx, a, n));
+    split_done = true;
+  } else if (ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0) {
     CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
     CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));
     CK(ldsim_ensure(ctx, SB_CORR, (size_t)n_valid * cb));

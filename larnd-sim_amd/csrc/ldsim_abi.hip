@@ -48,7 +48,7 @@ int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*
                       const double*, int, int64_t, int32_t*);
 // chain glue implemented in chain.hip (needs the kernel argument structs)
 int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions);
-int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T);
+int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc);
 
 // ---- errors ---------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -221,6 +221,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
   else if (!strcmp(name, "weights_mode")) { ctx->weights_mode = value != 0; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "numba_f32")) ctx->numba_f32 = value != 0;
+  else if (!strcmp(name, "mc_current")) ctx->mc_current = value != 0;
   else if (!strcmp(name, "quad_max_nodes")) {
     if (!(value >= 8 && value <= 256)) { ldsim_set_error("quad_max_nodes must be in [8, 256]"); return LDSIM_EINVAL; }
     ctx->gl_nmax = (int)value;
@@ -547,7 +548,23 @@ extern "C" int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t 
   CK(ldsim_ensure(ctx, SB_NEIGH, bp));
   CK(ldsim_ensure(ctx, SB_WAVES, bs));
   HIPCHK(hipMemcpyAsync(ctx->scratch[SB_NEIGH].p, pixels, bp, hipMemcpyHostToDevice, ctx->stream));
-  CK(chain_tracks_current(ctx, (const int32_t*)ctx->scratch[SB_NEIGH].p, P, (float*)ctx->scratch[SB_WAVES].p, T));
+  CK(chain_tracks_current(ctx, (const int32_t*)ctx->scratch[SB_NEIGH].p, P, (float*)ctx->scratch[SB_WAVES].p, T, 0));
+  HIPCHK(hipMemcpyAsync(signals, ctx->scratch[SB_WAVES].p, bs, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int ldsim_tracks_current_mc(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
+                                       const int32_t* pixels, int32_t P, float* signals, int32_t T) {
+  NEED(pixels && signals && P >= 0 && T >= 0, "bad tracks_current_mc arguments");
+  NEED(ctx && ctx->d_resp, "no response table set (ldsim_set_response)");
+  CK(upload_tracks(ctx, tracks, n, layout, nullptr));
+  size_t bp = (size_t)n * P * 4, bs = (size_t)n * P * T * 4;
+  if (bs == 0) return 0;
+  CK(ldsim_ensure(ctx, SB_NEIGH, bp));
+  CK(ldsim_ensure(ctx, SB_WAVES, bs));
+  HIPCHK(hipMemcpyAsync(ctx->scratch[SB_NEIGH].p, pixels, bp, hipMemcpyHostToDevice, ctx->stream));
+  CK(chain_tracks_current(ctx, (const int32_t*)ctx->scratch[SB_NEIGH].p, P, (float*)ctx->scratch[SB_WAVES].p, T, 1));
   HIPCHK(hipMemcpyAsync(signals, ctx->scratch[SB_WAVES].p, bs, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;

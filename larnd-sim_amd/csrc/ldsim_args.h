@@ -63,6 +63,7 @@ struct FeeArgs {
 };
 
 int current_launch(ldsim_ctx* ctx, const CurArgs& args);
+int current_mc_launch(ldsim_ctx* ctx, const CurArgs& args, int64_t n_seg);
 int rng_ensure_states(ldsim_ctx* ctx, int64_t n);
 int rng_fee_draws_per_pixel(const LdsimConsts& h, int NT);
 int rng_launch_fee_noise(ldsim_ctx* ctx, int64_t U, int nd, float* z);

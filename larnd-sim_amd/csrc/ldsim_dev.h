@@ -111,6 +111,7 @@ struct ldsim_ctx {
   int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
   int split_max_items = 0;          // validation knob, see CurArgs
   int weights_mode = 1;             // split path, weights stage: 1 = qweights_kernel (Gauss-Legendre along the segment), 0 = weights_kernel (per-sample closed form)
+  int mc_current = 0;               // 1: the chain's induced currents come from current_mc_kernel (tracks_current_mc) instead of tracks_current
   int numba_f32 = 0;                // 1: evaluate the sub-expressions Numba types f32 for f4 record fields in float
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2
   double* d_glw = nullptr;

@@ -41,7 +41,8 @@ class LdsimConsts(C.Structure):
         ("light_tick_size", C.c_double), ("mc_truth_threshold", C.c_double),
         ("light_window", C.c_double * 2), ("singlet_fraction", C.c_double), ("tau_s", C.c_double), ("tau_t", C.c_double),
         ("light_response_time", C.c_double), ("light_oscillation_period", C.c_double),
-        ("impulse_tick_size", C.c_double), ("sipm_response_model", C.c_int32), ("reserved_", C.c_int32),
+        ("impulse_tick_size", C.c_double), ("sipm_response_model", C.c_int32), ("mc_sample_multiplier", C.c_int32),
+        ("min_step_size", C.c_double),
     ]
 
 
@@ -95,4 +96,5 @@ def pack_consts(noise_zero=False):
     c.singlet_fraction, c.tau_s, c.tau_t = l.SINGLET_FRACTION, l.TAU_S, l.TAU_T
     c.light_response_time, c.light_oscillation_period = l.LIGHT_RESPONSE_TIME, l.LIGHT_OSCILLATION_PERIOD
     c.impulse_tick_size, c.sipm_response_model = l.IMPULSE_TICK_SIZE, int(l.SIPM_RESPONSE_MODEL)
+    c.mc_sample_multiplier, c.min_step_size = int(s.MC_SAMPLE_MULTIPLIER), float(s.MIN_STEP_SIZE)
     return c

@@ -44,14 +44,21 @@ def tracks_current(signals, pixels, tracks, response):
 
 @kernel
 def tracks_current_mc(signals, pixels, tracks, response, rng_states):
-    """The reference driver's call site (cli/simulate_pixels.py:1016) uses this Monte-Carlo estimate of the same
-    integral (detsim.py:258-348).  It draws from a Numba RNG state that all tick threads of a (segment, pixel) share, so
-    it is not reproducible even in the reference and only statistically comparable; it is not built here.  Nothing is
-    substituted silently: call ``tracks_current`` (the closed-form integral, detsim.py:351-453) at that line instead."""
-    raise NotImplementedError(
-        "detsim.tracks_current_mc is not provided: replace the call by "
-        "detsim.tracks_current[BPG, TPB](signals, neighboring_pixels, selected_tracks, response) "
-        "(deterministic integral of the same current; see INTEGRATION.md)")
+    """``tracks_current_mc[bpg, tpb](signals, pixels, tracks, response, rng_states)`` -- the reference driver's call site
+    (cli/simulate_pixels.py:1016; detsim.py:258-348).  ``rng_states``: handle of ``rng.create_xoroshiro128p_states`` (or None
+    to use the table as it stands).  The reference's tick threads race on one state per (segment, pixel); here every
+    (segment, pixel, tick) has its own stream derived from that state, so runs are reproducible and statistically, not
+    bitwise, comparable with the reference's."""
+    S, P = pixels.shape
+    T = signals.shape[2]
+    lay = make_layout(tracks.dtype)
+    lib.context()
+    lib.set_response(response)
+    pix = np.ascontiguousarray(pixels, dtype=np.int32)
+    out = np.zeros((S, P, T), dtype=np.float32)
+    lib.check(lib.load().ldsim_tracks_current_mc(lib.context(refresh_consts=False), lib.ptr(tracks), C.c_int64(S),
+                                                 C.byref(lay), lib.ptr(pix), C.c_int32(P), lib.ptr(out), C.c_int32(T)))
+    signals[:] = out
 
 
 @kernel

@@ -540,6 +540,100 @@ float o_rng_normal_f32(ORng* st) {
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+/* ---- 8f row 1: tracks_current_mc (detsim.py:258-348), overlapping_segment (:220-256) ------------------------------------------
+ * The reference's 64 tick threads race on rng_states[itrk + ntrk*ipix]; like the HIP kernel this restatement gives every
+ * (segment, pixel, tick) its own stream derived from that state (SplitMix64 finaliser of the words offset by the tick):
+ * reproducible, statistically equivalent, unpinned.  `states` has S*P entries; each is stepped once at the end. */
+static void mc_stream(const ORng* b, uint32_t it, ORng* o) {
+  uint64_t z0 = b->s0 + 0x9E3779B97F4A7C15ULL * (uint64_t)(it + 1u);
+  uint64_t z1 = b->s1 ^ (0xD1B54A32D192ED03ULL * (uint64_t)(it + 1u));
+  z0 = (z0 ^ (z0 >> 30)) * 0xBF58476D1CE4E5B9ULL; z0 = (z0 ^ (z0 >> 27)) * 0x94D049BB133111EBULL; z0 ^= z0 >> 31;
+  z1 = (z1 ^ (z1 >> 30)) * 0xBF58476D1CE4E5B9ULL; z1 = (z1 ^ (z1 >> 27)) * 0x94D049BB133111EBULL; z1 ^= z1 >> 31;
+  if ((z0 | z1) == 0) z0 = 1;
+  o->s0 = z0;
+  o->s1 = z1;
+}
+int o_tracks_current_mc(float* signals, const int32_t* pixels, const OTrack* tr, int64_t S, int64_t P, int64_t T,
+                        const double* response, int64_t ni, int64_t nj, int64_t nk, const LdsimConsts* c, ORng* states) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t pr = 0; pr < S * P; pr++) {
+    const int64_t itrk = pr / P, ipix = pr % P;
+    const OTrack* t = &tr[itrk];
+    float* out = signals + pr * T;
+    int64_t pID = pixels[pr], px, py, pplane;
+    id2pixel(c, pID, &px, &py, &pplane);
+    if (!(px >= 0 && py >= 0)) continue;
+    int64_t bplane = pplane < 0 ? pplane + c->n_tpc : pplane;
+    if (bplane < 0 || bplane >= c->n_tpc || t->pixel_plane < 0 || t->pixel_plane >= c->n_tpc) continue;
+    const double(*pb)[2] = c->tpc_borders[bplane];
+    double x_p = px * c->pixel_pitch + pb[0][0] + c->pixel_pitch / 2, y_p = py * c->pixel_pitch + pb[1][0] + c->pixel_pitch / 2;
+    double st[3], en[3];
+    if (t->z_start < t->z_end) {
+      st[0] = t->x_start; st[1] = t->y_start; st[2] = t->z_start; en[0] = t->x_end; en[1] = t->y_end; en[2] = t->z_end;
+    } else {
+      en[0] = t->x_start; en[1] = t->y_start; en[2] = t->z_start; st[0] = t->x_end; st[1] = t->y_end; st[2] = t->z_end;
+    }
+    double t_start = py_round((t->t_start - t->t0_start - c->time_padding) / c->time_sampling) * c->time_sampling;
+    double sx = en[0] - st[0], sy = en[1] - st[1], sz = en[2] - st[2];
+    double length = sqrt(sx * sx + sy * sy + sz * sz);
+    double dir[3] = {sx / length, sy / length, sz / length};
+    double impact = sqrt((double)ni * ni + (double)nj * nj) * c->response_bin_size;
+    double dx = x_p - st[0], dy = y_p - st[1], vx = en[0] - st[0], vy = en[1] - st[1];
+    double l = sqrt(vx * vx + vy * vy);
+    vx /= l; vy /= l;
+    double sp = (dx * vx + dy * vy) / l;
+    double rx = dx - vx * sp * l, ry = dy - vy * sp * l, rr = sqrt(rx * rx + ry * ry);
+    double ns[3], ne[3];
+    if (rr > impact) {
+      for (int k = 0; k < 3; k++) { ns[k] = st[k]; ne[k] = st[k]; }
+    } else {
+      double s_plus = sp + sqrt(impact * impact - rr * rr) / l, s_minus = sp - sqrt(impact * impact - rr * rr) / l;
+      if (s_plus > 1) s_plus = 1; else if (s_plus < 0) s_plus = 0;
+      if (s_minus > 1) s_minus = 1; else if (s_minus < 0) s_minus = 0;
+      for (int k = 0; k < 3; k++) {
+        ns[k] = st[k] * (1 - s_minus) + en[k] * s_minus;
+        ne[k] = st[k] * (1 - s_plus) + en[k] * s_plus;
+      }
+    }
+    double ux = ne[0] - ns[0], uy = ne[1] - ns[1], uz = ne[2] - ns[2];
+    double sublen = sqrt(ux * ux + uy * uy + uz * uz);
+    if (!(sublen > 0 && length > 0 && sublen < 1e6)) continue;
+    double nstep_f = fmax(py_round(sublen / c->min_step_size), 1.0);
+    if (!(nstep_f < 2.0e9)) continue;
+    int64_t nstep = (int64_t)nstep_f;
+    double step = sublen / nstep;
+    double charge = t->n_electrons * (sublen / length) / ((double)nstep * c->mc_sample_multiplier);
+    double z_anode = c->tpc_borders[t->pixel_plane][2][0];
+    const ORng* base = &states[itrk + S * ipix];
+    for (int64_t it = 0; it < T; it++) {
+      double time_tick = t_start + it * c->time_sampling;
+      if (time_tick < 0) continue;
+      ORng rs;
+      mc_stream(base, (uint32_t)it, &rs);
+      double total = 0;
+      for (int64_t istep = 0; istep < nstep; istep++)
+        for (int m = 0; m < c->mc_sample_multiplier; m++) {
+          double x = ns[0] + step * (istep + 0.5) * dir[0], y = ns[1] + step * (istep + 0.5) * dir[1];
+          double z = ns[2] + step * (istep + 0.5) * dir[2];
+          z += (double)o_rng_normal_f32(&rs) * t->long_diff;
+          double t0 = fabs(z - z_anode) / c->v_drift - c->time_window;
+          if (!(t0 < time_tick && time_tick < t0 + c->time_window)) continue;
+          x += (double)o_rng_normal_f32(&rs) * t->tran_diff;
+          y += (double)o_rng_normal_f32(&rs) * t->tran_diff;
+          double xd = fabs(x_p - x), yd = fabs(y_p - y);
+          if (xd > c->response_bin_size * ni) continue;
+          if (yd > c->response_bin_size * nj) continue;
+          int64_t i = (int64_t)py_round(xd / c->response_bin_size - 0.5), j = (int64_t)py_round(yd / c->response_bin_size - 0.5);
+          int64_t k = (int64_t)py_round((time_tick - t0) / c->response_sampling);
+          if (i >= 0 && i < ni && j >= 0 && j < nj && k >= 0 && k < nk) total += charge * response[(i * nj + j) * nk + k];
+        }
+      out[it] = (float)total;
+    }
+  }
+  for (int64_t i = 0; i < S * P; i++) o_rng_next(&states[i]);
+  return 0;
+}
+
 int o_get_adc_values_rng(const double* pixels_signals, const double* pixels_signals_tracks, const double* time_ticks,
                          int64_t n_time_ticks, double* adc_list, double* adc_ticks_list, double time_padding,
                          double* current_fractions, const double* thresholds, int64_t U, int64_t NT, int64_t M,

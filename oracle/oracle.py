@@ -182,6 +182,21 @@ def sum_pixel_signals(signals, track_starts, pim, tpm, U, want_tracks=True):
     return ps, pts, ovf
 
 
+def tracks_current_mc(tracks, pixels, T, response, rng_states):
+    """o_tracks_current_mc: signals f32 [S][P][T]; rng_states (RNG_DTYPE, S*P entries) are stepped once."""
+    o = to_oracle(tracks)
+    c = _consts(noise_zero=False)
+    S, P = pixels.shape
+    sig = np.zeros((S, P, T), dtype=np.float32)
+    resp = np.ascontiguousarray(response, dtype=np.float64)
+    pix = np.ascontiguousarray(pixels, dtype=np.int32)
+    assert rng_states.dtype == RNG_DTYPE and len(rng_states) >= S * P
+    lib().o_tracks_current_mc(_p(sig), _p(pix), _p(o), C.c_int64(S), C.c_int64(P), C.c_int64(T), _p(resp),
+                              C.c_int64(resp.shape[0]), C.c_int64(resp.shape[1]), C.c_int64(resp.shape[2]), C.byref(c),
+                              _p(rng_states))
+    return sig
+
+
 RNG_DTYPE = np.dtype([("s0", "<u8"), ("s1", "<u8")])     # numba.cuda.random.xoroshiro128p_dtype
 
 

@@ -159,11 +159,35 @@ def test_load_pixel_table_reads_the_reference_format(tmp_path):
         fee.load_pixel_table(str(tmp_path / "len.npz"))
 
 
-def test_tracks_current_mc_is_refused_with_instructions():
-    """The driver's MC call site is not substituted silently: the stub says what to call instead."""
-    from larndsim_amd import detsim
-    with pytest.raises(NotImplementedError, match=r"detsim\.tracks_current\[BPG, TPB\]"):
-        detsim.tracks_current_mc[1, 64](None, None, None, None, None)
+def test_oracle_rng_restatement_properties():
+    """The oracle's restatement of numba.cuda.random (xoroshiro128p, SplitMix64 seeding, 2^64 jump, float32 Box-Muller):
+    state 0 has both words equal to SplitMix64(seed); the jump is linear over GF(2) (jump(a ^ b) == jump(a) ^ jump(b));
+    uniforms lie in [0, 1]; 2e5 normals have mean 0 and unit variance within 4 standard errors."""
+    from oracle import oracle as O
+    st = O.rng_create_states(4, 12345)
+    z = (12345 + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    z ^= z >> 31
+    assert int(st["s0"][0]) == int(st["s1"][0]) == z
+    assert len({(int(a), int(b)) for a, b in zip(st["s0"], st["s1"])}) == 4
+    a, b = O.rng_create_states(2, 1), O.rng_create_states(2, 2)
+    x = np.zeros(2, dtype=O.RNG_DTYPE)
+    x["s0"][0] = a["s0"][0] ^ b["s0"][0]; x["s1"][0] = a["s1"][0] ^ b["s1"][0]
+    # one jump of the xor-ed state via the library: create_states jumps state 0 into state 1, reuse it through a manual copy
+    lib = O.lib()
+    import ctypes as C
+    class R(C.Structure):
+        _fields_ = [("s0", C.c_uint64), ("s1", C.c_uint64)]
+    nxt = lib.o_rng_next
+    nxt.restype = C.c_uint64
+    r1 = R(int(a["s0"][0]), int(a["s1"][0])); r2 = R(int(b["s0"][0]), int(b["s1"][0])); r3 = R(int(x["s0"][0]), int(x["s1"][0]))
+    for _ in range(50):      # the state update is linear: the xor of two streams' states is the state of the xor-ed seed state
+        nxt(C.byref(r1)); nxt(C.byref(r2)); nxt(C.byref(r3))
+        assert r3.s0 == r1.s0 ^ r2.s0 and r3.s1 == r1.s1 ^ r2.s1
+    n = O.rng_normals(O.rng_create_states(1, 7), 0, 200_000).astype(np.float64)
+    assert abs(n.mean()) < 4 / np.sqrt(len(n)) and abs(n.var() - 1) < 4 * np.sqrt(2 / len(n))
+    assert np.isfinite(n).all() and np.abs(n).max() < 7
 
 
 def test_synthetic_inputs_are_deterministic_and_in_schema():

@@ -1017,6 +1017,78 @@ def test_fused_chain_with_fee_noise_vs_oracle():
     assert np.array_equal(ch.rng_states.copy_to_host(u0).view(np.uint64).ravel(), states.view(np.uint64).ravel())
 
 
+def test_tracks_current_mc_vs_oracle_and_closure():
+    """detsim.tracks_current_mc (what the reference driver calls, cli/simulate_pixels.py:1016).  Every (segment, pixel, tick)
+    has its own stream here (the reference's tick threads race on one state), so parity is (a) with the oracle's
+    restatement of the same rule: the table states end bit-identical and the currents agree except where a float32 normal's
+    last bit moves a sample across a response-cell edge; (b) statistical closure with the deterministic integral
+    tracks_current: the same charge is induced."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(4, seed=17, segs_per_event=4)
+    batching.swap_coordinates(seg)
+    r = H.quench_drift(O, seg)
+    nmax = O.max_pixels(r)
+    P = 3 * nmax + 6
+    _, neigh, nrad, _ = O.get_pixels(r, nmax, P, 1)
+    _, T = O.time_intervals(r)
+    resp = synth.make_response("golden")
+    S = len(r)
+    st = O.rng_create_states(S * P, 99)
+    ref = O.tracks_current_mc(r, neigh, T, resp, st)
+    states = lrng.create_xoroshiro128p_states(S * P, 99)
+    sig = np.zeros((S, P, T), dtype=np.float32)
+    detsim.tracks_current_mc[(S, P, 1), (1, 1, 64)](sig, neigh, r, resp, states)
+    assert np.array_equal(states.copy_to_host().view(np.uint64).ravel(), st.view(np.uint64).ravel())
+    assert np.array_equal(sig != 0, ref != 0) and (ref != 0).sum() > 5000
+    peak = np.abs(ref).max(axis=-1, keepdims=True) + 1e-30
+    close = np.abs(sig - ref) <= 1e-4 * np.abs(ref) + 1e-6 * peak
+    assert close.mean() > 0.999
+    # a second call continues the streams: different samples, same physics
+    sig2 = np.zeros_like(sig)
+    detsim.tracks_current_mc[(S, P, 1), (1, 1, 64)](sig2, neigh, r, resp, None)
+    assert not np.array_equal(sig2, sig)
+    det = O.tracks_current(r, neigh, T, resp)
+    q_mc, q_mc2, q_det = sig.sum(dtype=np.float64), sig2.sum(dtype=np.float64), det.sum(dtype=np.float64)
+    assert abs(q_mc / q_det - 1) < 0.03 and abs(q_mc2 / q_det - 1) < 0.03
+    # per pair with a sizeable signal the two estimates of the induced charge agree within the sampling error
+    big = np.abs(det).sum(axis=-1) > 0.05 * np.abs(det).sum(axis=-1).max()
+    ratio = sig.sum(axis=-1, dtype=np.float64)[big] / det.sum(axis=-1, dtype=np.float64)[big]
+    assert np.abs(ratio - 1).max() < 0.15
+
+
+def test_fused_chain_with_mc_currents():
+    """Option "mc_current": the fused chain takes its induced currents from tracks_current_mc (the reference driver's
+    configuration) -- same pixels as the deterministic chain, charges equal within the Monte-Carlo error."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(24, seed=27, segs_per_event=12)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    ch = ChargeChain(H.response_for("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.run(0, len(seg))
+    det = ch.download()
+    try:
+        lib.set_option("mc_current", 1)
+        ch.seed_rng(123)
+        ch.run(0, len(seg))
+        mc = ch.download()
+        ch.seed_rng(123)
+        ch.run(0, len(seg))
+        again = ch.download()
+    finally:
+        lib.set_option("mc_current", 0)
+    for k in mc:
+        assert np.array_equal(mc[k], again[k]), f"{k}: not reproducible with the same seed"
+    assert np.array_equal(mc["unique_pix"], det["unique_pix"]) and np.array_equal(mc["track_pixel_map"], det["track_pixel_map"])
+    q_det, q_mc = det["adc_list"].sum(), mc["adc_list"].sum()
+    assert q_det > 0 and abs(q_mc / q_det - 1) < 0.03
+    both = (det["adc_list"][:, 0] > 2e4) & (mc["adc_list"][:, 0] != 0)
+    assert both.sum() >= 5
+    assert np.abs(mc["adc_list"][both, 0] / det["adc_list"][both, 0] - 1).max() < 0.2
+
+
 def _two_event_set(cfg, seed, n=1200):
     H.load_cfg(cfg)
     seg = synth.make_segments(n, seed=seed, segs_per_event=n // 2, spill=bool(consts.sim.IS_SPILL_SIM))
