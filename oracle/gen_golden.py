@@ -588,6 +588,138 @@ def gen_light_response():
               "truth slots used", int((s_tid >= 0).sum()), int((r_tid >= 0).sum()))
 
 
+def gen_packets():
+    """fee.export_to_hdf5 (fee.py:84-356) on the golden chain's ADC arrays, replicated over events.  larpix-control is a
+    third-party package that is not installed: its packet classes are replaced by attribute bags that record what the
+    reference assigns (no logic of their own; assign_parity is a no-op), hdf5format.to_file and h5py.File by sinks.  The
+    fixture therefore pins the reference's own logic -- which slots become packets, time ticks and rollover, the pixel ->
+    io_group / io_channel / chip / channel mapping, the inserted timestamp / sync / trigger packets, the association rows --
+    and nothing of larpix-control's byte format."""
+    class _Bag:
+        def __init__(self, kind, **kw):
+            self.kind = kind
+            self.__dict__.update(kw)
+
+    class Packet_v2(_Bag):
+        def __init__(self):
+            super().__init__("data")
+
+        def assign_parity(self):
+            pass
+
+    class TimestampPacket(_Bag):
+        def __init__(self, timestamp=None):
+            super().__init__("timestamp", timestamp=timestamp)
+
+    class SyncPacket(_Bag):
+        def __init__(self, sync_type=None, timestamp=None, io_group=None):
+            super().__init__("sync", sync_type=sync_type, timestamp=timestamp, io_group=io_group)
+
+    class TriggerPacket(_Bag):
+        def __init__(self, io_group=None, trigger_type=None, timestamp=None):
+            super().__init__("trigger", io_group=io_group, trigger_type=trigger_type, timestamp=timestamp)
+
+    class Key:
+        def __init__(self, io_group, io_channel, chip_id):
+            self.io_group, self.io_channel, self.chip_id = io_group, io_channel, chip_id
+
+    class _Attrs(dict):
+        pass
+
+    class _Node:
+        def __init__(self):
+            self.attrs = _Attrs()
+
+    class _File:
+        store = {}
+
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def keys(self):
+            return self.store.keys()
+
+        def create_dataset(self, name, data=None, **k):
+            self.store[name] = data
+
+        def __getitem__(self, name):
+            return self.store.setdefault(name, _Node())
+
+    chain = np.load(os.path.join(GOLD, "chain_module0.npz"))
+    for cfg, case, t_events in (("module0", "a", (1000.0, 250000.0, 1.2e6)), ("2x2_no_modvar", "b", (0.0, 1.2e6, 2.4e6))):
+        ref = Ref(cfg)
+        fee = ref.fee
+        fee.Packet_v2, fee.TimestampPacket, fee.SyncPacket, fee.TriggerPacket, fee.Key = (
+            Packet_v2, TimestampPacket, SyncPacket, TriggerPacket, Key)
+        fee.PacketCollection = lambda packets, read_id=0, message='': packets
+        fee.hdf5format = types.SimpleNamespace(to_file=lambda *a, **k: None)
+        _File.store = {}
+        fee.h5py = types.SimpleNamespace(File=_File)
+        U0 = chain["unique_pix"].shape[0]
+        n_ev = len(t_events)
+        rng = np.random.default_rng(71)
+        adc = np.concatenate([chain["adc_digit_low"]] * n_ev)
+        ticks = np.concatenate([chain["adc_ticks_low"]] * n_ev)
+        frac = np.concatenate([chain["adc_fractions_low"]] * n_ev)
+        upix = np.concatenate([chain["unique_pix"]] * n_ev)
+        tpm = np.concatenate([chain["track_pixel_map"]] * n_ev)
+        # segment ids / trajectory ids of the slots (the driver maps track_pixel_map through them, cli :1107-1113)
+        seg_ids = np.where(tpm >= 0, 1000 + tpm, -1)
+        traj_ids = np.where(tpm >= 0, 7 + tpm // 2, -1)
+        ev = np.repeat(np.arange(n_ev), U0)
+        event_id_list = np.repeat(ev[:, None], adc.shape[1], axis=1)
+        event_times = np.array(t_events)
+        bad = None
+        if case == "a":      # one live channel of the golden set disabled through a bad-channels file
+            import tempfile, yaml
+            pk, _ = fee.export_to_hdf5(event_id_list, adc, ticks, upix, frac, seg_ids, traj_ids, "x.h5", event_times,
+                                       light_trigger_times=np.zeros(n_ev), light_trigger_event_id=np.arange(n_ev),
+                                       light_trigger_modules=np.ones(n_ev))
+            first = [p for p in pk if p.kind == "data"][3]
+            bad_dict = {first.chip_key: [int(first.channel_id)]}
+            fd, bad = tempfile.mkstemp(suffix=".yaml")
+            with os.fdopen(fd, "w") as fh:
+                yaml.safe_dump(bad_dict, fh)
+            _File.store = {}
+        pk, assn = fee.export_to_hdf5(event_id_list, adc, ticks, upix, frac, seg_ids, traj_ids, "x.h5", event_times,
+                                      light_trigger_times=np.zeros(n_ev) + 3.0, light_trigger_event_id=np.arange(n_ev),
+                                      light_trigger_modules=np.ones(n_ev), bad_channels=bad)
+        rows = np.zeros(len(pk), dtype=[("kind", "i4"), ("io_group", "i8"), ("io_channel", "i8"), ("chip_id", "i8"),
+                                        ("channel_id", "i8"), ("timestamp", "f8"), ("dataword", "i8"),
+                                        ("trigger_type", "i8"), ("receipt_timestamp", "i8"), ("first_packet", "i8")])
+        for i, p in enumerate(pk):
+            r = rows[i]
+            if p.kind == "data":
+                g, c, chip = (int(x) for x in p.chip_key.split("-"))
+                r["kind"] = 0; r["io_group"] = g; r["io_channel"] = c; r["chip_id"] = chip
+                r["channel_id"] = p.channel_id; r["timestamp"] = p.timestamp; r["dataword"] = p.dataword
+                r["receipt_timestamp"] = p.receipt_timestamp; r["first_packet"] = p.first_packet
+            elif p.kind == "timestamp":
+                r["kind"] = 4; r["timestamp"] = float(p.timestamp); r["io_group"] = p.chip_key.io_group
+            elif p.kind == "sync":
+                r["kind"] = 6; r["timestamp"] = p.timestamp; r["io_group"] = p.io_group; r["trigger_type"] = p.sync_type[0]
+            else:
+                r["kind"] = 7; r["timestamp"] = p.timestamp; r["io_group"] = p.io_group; r["trigger_type"] = p.trigger_type[0]
+        np.savez_compressed(os.path.join(GOLD, f"packets_{cfg}.npz"), event_id_list=event_id_list.astype("i4"),
+                            adc=adc, ticks=ticks, fractions=frac, unique_pix=upix, segment_ids=seg_ids, traj_ids=traj_ids,
+                            event_times=event_times, trig_times=np.zeros(n_ev) + 3.0,
+                            bad_key=np.array(list(bad_dict.keys())[0] if bad else ""),
+                            bad_channel=np.array(list(bad_dict.values())[0][0] if bad else -1),
+                            rows=rows, assn_event_ids=assn["event_ids"], assn_segment_ids=assn["segment_ids"],
+                            assn_fraction=assn["fraction"], assn_file_traj_ids=assn["file_traj_ids"],
+                            assn_fraction_traj=assn["fraction_traj"],
+                            config_attrs=np.array([_File.store["configs"].attrs[k] for k in
+                                                   ("vdrift", "long_diff", "tran_diff", "lifetime", "drift_length")]))
+        kinds = {k: int((rows["kind"] == k).sum()) for k in (0, 4, 6, 7)}
+        print("packets", cfg, "trig mode", ref.light.LIGHT_TRIG_MODE, "packets", len(pk), kinds)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sets", default="consts,qd,pixels,light,sampled,chain")
@@ -599,7 +731,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for s in a.sets.split(","):
         {"consts": gen_consts, "qd": gen_qd, "pixels": gen_pixels, "light": gen_light, "light_response": gen_light_response,
-         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs)}[s]()
+         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs), "packets": gen_packets}[s]()
     return 0
 
 

@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
     from larndsim_amd import batching, consts, dist as ldist, synth
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    consts.load_snapshot("2x2")
+    consts.load_snapshot("2x2_no_modvar")
     seg = synth.make_segments(9000, seed=5, segs_per_event=1500, spill=True)
     batching.swap_coordinates(seg)
     bid, order, table = batching.assign_batches(seg)

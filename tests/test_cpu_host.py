@@ -97,7 +97,7 @@ def test_snapshot_values_appendix_b():
 
 
 def test_batching_matches_tpcbatcher_iteration():
-    consts.load_snapshot("2x2")
+    consts.load_snapshot("2x2_no_modvar")
     seg = synth.make_segments(6000, seed=4, segs_per_event=1500, spill=True)
     # a few segments outside every TPC and one straddling two TPC groups
     seg["x_start"][:5] += 1000; seg["x_end"][:5] += 1000
@@ -227,3 +227,48 @@ def test_cli_input_checks_like_the_reference(tmp_path):
     for f in ("t0", "t0_start", "t0_end", "n_photons", "segment_id"):
         assert f in new.dtype.names
     assert np.array_equal(new["t0"], [1, 2, 3]) and (new["t"] == 0).all() and (new["x"] == 7).all() and (new["z"] == 5).all()
+
+
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_packets_writer_golden(cfg):
+    """packets.build_packets (larpix-control-free writer of the `packets` / `mc_packets_assn` datasets) against
+    fee.export_to_hdf5 of the reference run under attribute-bag packet classes (oracle/gen_golden.py gen_packets): every
+    packet in order with its io_group / io_channel / chip / channel / timestamp / dataword, the inserted timestamp, sync
+    and trigger packets (module0: threshold trigger mode; 2x2: beam mode inserts none), rollover of the third event, a
+    disabled channel, and the association rows."""
+    from larndsim_amd import packets
+    H.load_cfg(cfg, noise_zero=False)
+    g = H.gold(f"packets_{cfg}.npz")
+    bad = {str(g["bad_key"]): [int(g["bad_channel"])]} if str(g["bad_key"]) else None
+    n_ev = len(g["event_times"])
+    pk, assn = packets.build_packets(g["event_id_list"], g["adc"], g["ticks"], g["unique_pix"], g["fractions"],
+                                     g["segment_ids"], g["traj_ids"], g["event_times"], light_trigger_times=g["trig_times"],
+                                     light_trigger_event_id=np.arange(n_ev), light_trigger_modules=np.ones(n_ev),
+                                     bad_channels=bad)
+    rows = g["rows"]
+    assert len(pk) == len(rows) and (rows["kind"] == 0).sum() > 40
+    assert np.array_equal(pk["packet_type"], rows["kind"])
+    assert np.array_equal(pk["io_group"], rows["io_group"])
+    data = rows["kind"] == 0
+    for f in ("io_channel", "chip_id", "channel_id", "dataword", "first_packet", "receipt_timestamp"):
+        assert np.array_equal(pk[f][data].astype(np.int64), rows[f][data]), f
+    assert np.array_equal(pk["timestamp"], rows["timestamp"].astype(np.uint64))        # floats truncate like the u8 dataset does
+    sync_trig = (rows["kind"] == 6) | (rows["kind"] == 7)
+    assert np.array_equal(pk["trigger_type"][sync_trig].astype(np.int64), rows["trigger_type"][sync_trig])
+    if bad:
+        k = tuple(int(x) for x in str(g["bad_key"]).split("-"))
+        hit = (pk["io_group"] == k[0]) & (pk["io_channel"] == k[1]) & (pk["chip_id"] == k[2]) & \
+              (pk["channel_id"] == int(g["bad_channel"])) & (pk["packet_type"] == 0)
+        assert not hit.any()
+    # data packets carry odd parity over their 64 bits
+    w = (pk["chip_id"].astype(np.uint64) << 2) | (pk["channel_id"].astype(np.uint64) << 10) | \
+        ((pk["timestamp"] & 0x7FFFFFFF) << 16) | (pk["first_packet"].astype(np.uint64) << 47) | \
+        (pk["dataword"].astype(np.uint64) << 48) | (pk["parity"].astype(np.uint64) << 63)
+    ones = np.array([bin(int(x)).count("1") for x in w[data]])
+    assert (ones % 2 == 1).all()
+    assert np.array_equal(assn["event_ids"], g["assn_event_ids"])
+    assert np.array_equal(assn["segment_ids"], g["assn_segment_ids"])
+    assert np.array_equal(assn["fraction"], g["assn_fraction"])
+    assert np.array_equal(assn["file_traj_ids"], g["assn_file_traj_ids"])
+    assert np.array_equal(assn["fraction_traj"], g["assn_fraction_traj"])
+    assert packets.packets_dtype.itemsize == 36 and assn.dtype == packets.assn_dtype()
