@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """
-simulate_pixels.py -- command-line driver for the charge path, keeping the reference's flag surface
-(cli/simulate_pixels.py:124-145, run through `fire` there; argparse here, fire is optional).
+simulate_pixels.py -- command-line driver keeping the reference's flag surface (cli/simulate_pixels.py:124-145, run through
+`fire` there; argparse here).
 
-Covers what SURVEY §8 puts on the hot path: input checks, config resolution, segment preparation
-(segment_id / n_photons / t0 columns, spill-time reset, x<->z swap), active-volume selection, batching,
-quench -> drift -> [light incidence] -> charge chain, and a numbers-only output (npz, or HDF5 when h5py is
-importable).  LArPix packet export, light waveforms and truth pass-through are out of scope:
-flags that only concern them are accepted and ignored with a notice.
+input checks -> configuration resolution (larndsim_amd.config, the reference's get_config rules) -> segment preparation
+(segment_id / n_photons / t0 columns, spill-time reset, x<->z swap) -> active-volume selection -> batching ->
+quench + drift -> [light incidence + photon sum per batch] -> charge chain with FEE noise -> LArPix packets +
+mc_packets_assn per batch -> output file (HDF5 when h5py is importable, else .npz with the same dataset names) with the
+updated segments, light_dat and the truth datasets of the input passed through.
+
+Not built (a flag that only concerns them is accepted and reported): module-to-module variation, the light waveform chain
+after the photon sum (Poisson fluctuation, SiPM response, noise, triggers, digitisation), bad-channel lists by id,
+memory logging.
 """
 import argparse
 import os
 import sys
 import warnings
+from time import time
 
 import numpy as np
 import numpy.lib.recfunctions as rfn
@@ -20,25 +25,36 @@ import numpy.lib.recfunctions as rfn
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from larndsim_amd import batching, consts, fee, synth  # noqa: E402
+from larndsim_amd import batching, consts, fee, packets, synth  # noqa: E402
+from larndsim_amd import config as cfgmod  # noqa: E402
 from larndsim_amd.chain import ChargeChain  # noqa: E402
 
-CONFIG_SNAPSHOTS = {"module0": "module0", "2x2_no_modvar": "2x2_no_modvar", "2x2": "2x2_no_modvar", "ndlar": "ndlar"}
-IGNORED = ("light_det_noise_filename", "bad_channels", "pixel_thresholds_id", "pixel_gains_id", "save_memory",
-           "pixel_layout_id", "response_id", "light_lut_id")
+SEED = int(time())
+IGNORED = ("light_det_noise_filename", "pixel_thresholds_id", "pixel_gains_id", "save_memory", "pixel_layout_id",
+           "response_id", "light_lut_id")
+TRUTH_DATASETS = ("trajectories", "vertices", "mc_hdr", "mc_stack")
 
 
-def load_segments(path, dset="segments"):
-    if path.endswith(".npy"):
-        return np.load(path)
-    if path.endswith(".npz"):
-        return np.load(path)[dset]
+def _h5py():
     try:
         import h5py
-    except ImportError as e:
-        raise RuntimeError("HDF5 input needs h5py; .npy/.npz structured arrays with the same dtype are accepted") from e
+        return h5py
+    except ImportError:
+        return None
+
+
+def load_input(path, dset="segments"):
+    """(segments, {truth dataset name: array}) from HDF5 (needs h5py), .npz (same dataset names) or .npy (segments only)."""
+    if path.endswith(".npy"):
+        return np.load(path), {}
+    if path.endswith(".npz"):
+        with np.load(path) as f:
+            return f[dset], {k: f[k] for k in TRUTH_DATASETS if k in f.files}
+    h5py = _h5py()
+    if h5py is None:
+        raise RuntimeError("HDF5 input needs h5py; .npy/.npz structured arrays with the same dtype are accepted")
     with h5py.File(path, "r") as f:
-        return np.array(f[dset])
+        return np.array(f[dset]), {k: np.array(f[k]) for k in TRUTH_DATASETS if k in f}
 
 
 def prepare_tracks(tracks):
@@ -62,83 +78,202 @@ def prepare_tracks(tracks):
     return batching.swap_coordinates(tracks)
 
 
+def gen_event_times(nevents, rng):
+    """fee.gen_event_times (fee.py:70-82): cumulative exponential gaps after NON_BEAM_EVENT_GAP (numpy generator here, cupy's there)."""
+    d = consts.detector
+    return np.cumsum(rng.exponential(scale=d.EVENT_RATE, size=int(nevents))) + d.NON_BEAM_EVENT_GAP
+
+
+class _Output:
+    """HDF5 when h5py is importable, else one .npz with the same dataset names (written at close)."""
+
+    def __init__(self, filename):
+        self.filename = filename
+        self.h5py = _h5py() if filename.endswith((".h5", ".hdf5")) else None
+        if filename.endswith((".h5", ".hdf5")) and self.h5py is None:
+            raise RuntimeError("HDF5 output needs h5py; give an .npz output name instead")
+        self.parts = {}
+
+    def append_packets(self, pk, assn):
+        if self.h5py is not None:
+            packets.write_hdf5(self.filename, pk, assn)
+        else:
+            self.parts.setdefault("packets", []).append(pk)
+            self.parts.setdefault("mc_packets_assn", []).append(assn)
+
+    def put(self, name, data, attrs=None):
+        if self.h5py is not None:
+            with self.h5py.File(self.filename, "a") as f:
+                ds = f.create_dataset(name, data=data)
+                for k, v in (attrs or {}).items():
+                    ds.attrs[k] = v
+        else:
+            self.parts[name.replace("/", "__")] = [data]
+
+    def close(self):
+        if self.h5py is None:
+            out = {k: (np.concatenate(v) if len(v) > 1 else v[0]) for k, v in self.parts.items() if len(v)}
+            np.savez_compressed(self.filename, **out)
+
+
 def run_simulation(input_filename, output_filename, config="module0", mod2mod_variation=None, pixel_layout=None,
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
-                   light_lut_filename=None, n_events=None, rand_seed=None, chunk_segments=50000,
-                   pixel_thresholds_file=None, pixel_gains_file=None, **ignored):
+                   light_lut_filename=None, bad_channels=None, n_events=None, pixel_thresholds_file=None,
+                   pixel_gains_file=None, rand_seed=None, config_root=None, tracks_current_mc=False, chunk_segments=50000,
+                   raw_arrays=False, **ignored):
     if not os.path.exists(input_filename):
         raise Exception(f"Input file {input_filename} does not exist.")
     if os.path.exists(output_filename):
         raise Exception(f"Output file {output_filename} already exists.")
     for k, v in ignored.items():
         if v is not None:
-            print(f"[simulate_pixels] --{k} concerns an out-of-scope stage and is ignored")
-    if mod2mod_variation:
-        raise NotImplementedError("mod2mod_variation is out of scope (SURVEY §8f)")
+            print(f"[simulate_pixels] --{k} concerns a stage that is not built and is ignored")
+
+    # ---- configuration (cli/simulate_pixels.py:269-384) ------------------------------------------------------------------
+    cfg = cfgmod.get_config(config, config_root)
+    cfgmod.check_single_configuration(config, cfg, mod2mod_variation)
+    one = lambda v: v[0] if isinstance(v, (list, tuple)) else v          # noqa: E731  single-configuration lists
+    pixel_layout = pixel_layout or (one(cfg.get("PIXEL_LAYOUT")) if "SNAPSHOT" not in cfg else None)
+    detector_properties = detector_properties or (cfg.get("DET_PROPERTIES") if "SNAPSHOT" not in cfg else None)
+    simulation_properties = simulation_properties or (cfg.get("SIM_PROPERTIES") if "SNAPSHOT" not in cfg else None)
     if detector_properties and pixel_layout and simulation_properties:
         consts.load_properties(detector_properties, pixel_layout, simulation_properties)
+    elif "SNAPSHOT" in cfg and not (detector_properties or pixel_layout or simulation_properties):
+        consts.load_snapshot(cfg["SNAPSHOT"])
     else:
-        if config not in CONFIG_SNAPSHOTS:
-            raise KeyError(f"Key {config} not in supported keywords {list(CONFIG_SNAPSHOTS)}")
-        consts.load_snapshot(CONFIG_SNAPSHOTS[config])
-    det, sim = consts.detector, consts.sim
-    if any(getattr(det, k) for k in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOISE")):
-        warnings.warn("FEE noise is switched off: the reference's Numba RNG stream is not reproduced")
-        det.RESET_NOISE_CHARGE = det.UNCORRELATED_NOISE_CHARGE = det.DISCRIMINATOR_NOISE = 0
-    if response_file:
+        raise AssertionError("pixel_layout, detector_properties and simulation_properties (files) must all be specified")
+    det, sim, light = consts.detector, consts.sim, consts.light
+    if response_file is None and "SNAPSHOT" not in cfg:
+        response_file = one(cfg.get("RESPONSE"))
+    if response_file and os.path.isfile(response_file):
         response = np.load(response_file)
     else:
-        warnings.warn("no --response_file: using the synthetic survey response table")
-        response = synth.make_response("survey")
+        warnings.warn(f"response file {response_file!r} not available (the reference checkout ships none): using the "
+                      f"synthetic survey response table")
+        response = synth.make_response("survey", response_sampling=det.RESPONSE_SAMPLING)
+    if light_simulated is None:
+        light_simulated = bool(cfg.get("LIGHT_SIMULATED", True))
+    light_simulated = bool(light_simulated) and bool(light.LIGHT_SIMULATED) and light.N_OP_CHANNEL > 0
+    lut = None
+    if light_simulated:
+        light_lut_filename = light_lut_filename or one(cfg.get("LIGHT_LUT"))
+        if light_lut_filename and os.path.isfile(light_lut_filename):
+            lut = np.load(light_lut_filename)["arr"]
+            mask = lut["vis"] > 0                                   # no voxel with 0 visibility (cli/simulate_pixels.py:770-771)
+            lut["vis"][~mask] = lut["vis"][mask].min()
+        else:
+            print("light_lut_filename is not provided (required if light_simulated is True): light is not simulated")
+            light_simulated = False
+    if not rand_seed:
+        rand_seed = SEED
+    print("Random seed:", rand_seed)
+    bad_list = None
+    if bad_channels:
+        import yaml
+        with open(bad_channels) as f:
+            bad_list = yaml.safe_load(f)
 
-    tracks = load_segments(input_filename, sim.TRACKS_DSET_NAME)
+    # ---- input (:476-587) ---------------------------------------------------------------------------------------------------------
+    tracks, truth = load_input(input_filename, sim.TRACKS_DSET_NAME)
     if tracks.size == 0:
         print("Empty input dataset, exiting")
         return None
     if n_events:
         max_ev = np.unique(tracks[sim.EVENT_SEPARATOR])[n_events - 1]
         tracks = tracks[tracks[sim.EVENT_SEPARATOR] <= max_ev]
+        truth = {k: v[v[sim.EVENT_SEPARATOR] <= max_ev] for k, v in truth.items()}
     tracks = prepare_tracks(tracks)
+    num_evids = int(tracks[sim.EVENT_SEPARATOR].max() % sim.MAX_EVENTS_PER_FILE) + 1
+    host_rng = np.random.default_rng(rand_seed)
+    event_times = (np.arange(num_evids) * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else gen_event_times(num_evids, host_rng))
     tracks = tracks[batching.select_active_volume(tracks, det.TPC_BORDERS)]
     bid, order, table = batching.assign_batches(tracks)
     tracks, bid = np.ascontiguousarray(tracks[order]), bid[order]
     nsim = int((bid >= 0).sum())
+    traj_field = "file_traj_id" if "file_traj_id" in tracks.dtype.names else "traj_id"
 
+    # ---- device-resident simulation ---------------------------------------------------------------------------------------------
     chain = ChargeChain(response)
     chain.clear_pixel_tables()
-    if pixel_thresholds_file is not None:                          # cli/simulate_pixels.py:439-443, 1079-1084
+    chain.seed_rng(rand_seed)                                       # create_xoroshiro128p_states(1024*256, seed) (:396)
+    if pixel_thresholds_file is not None:                          # :439-443, 1079-1084
         print("Pixel thresholds file:", pixel_thresholds_file)
         chain.set_pixel_thresholds(*fee.load_pixel_table(pixel_thresholds_file))
     if pixel_gains_file is not None:                               # :445-449, 1097-1100
         print("Pixel gains file:", pixel_gains_file)
         chain.set_pixel_gains(*fee.load_pixel_table(pixel_gains_file))
-    chain.upload(tracks, bid)
-    chain.quench_drift(consts.physics.BIRKS)
-    chain.download_segments(tracks)
-    parts = []
-    edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
-    b = 0
-    for e in edges[1:]:
-        if e - b >= chunk_segments or e == nsim:
-            chain.run(int(b), int(e), want_fractions=True)
-            parts.append(chain.download())
+    from larndsim_amd import lib
+    lib.set_option("mc_current", 1 if tracks_current_mc else 0)
+    out = _Output(output_filename)
+    try:
+        chain.upload(tracks, bid)
+        chain.quench_drift(consts.physics.BIRKS)
+        chain.download_segments(tracks)
+        edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
+        if light_simulated:
+            chain.light_incidence(lut)
+            op_channel = light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32)
+            light_rows = []
+            for b0, b1 in zip(edges[:-1], edges[1:]):               # :1120-1153; the waveform chain that follows is not built
+                n_ticks, t_start = chain.sum_light(int(b0), int(b1), op_channel,
+                                                   segment_track_id=tracks["segment_id"][b0:b1].astype(np.int64))
+                if raw_arrays:
+                    light_rows.append(chain.download_light(truth=False)[0])
+            inc, _ = chain.download_light_incidence(0, len(tracks))
+            inc["segment_id"] = tracks["segment_id"][:, None]
+            out.put("light_dat/light_dat_allmodules", inc)
+            if raw_arrays and light_rows:
+                out.put("light_sample_inc", np.stack(light_rows))
+        parts, n_hits, n_packets = [], 0, 0
+        b = 0
+        for e in edges[1:]:
+            if not (e - b >= chunk_segments or e == nsim):
+                continue
+            st = chain.run(int(b), int(e), want_fractions=True)
+            res = chain.download()
+            # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
+            for bb in np.unique(res["batch"]):
+                m = res["batch"] == bb
+                lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
+                seg_ids = tracks["segment_id"][lo:].astype(np.int64)
+                trj_ids = tracks[traj_field][lo:].astype(np.int64)
+                tpm = res["track_pixel_map"][m]
+                track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
+                traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
+                event = table[int(bb)][0]
+                ev_ids = np.full(res["adc_digit"][m].shape, event)
+                ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
+                pk, assn = packets.build_packets(ev_ids, res["adc_digit"][m], res["adc_ticks_list"][m], res["unique_pix"][m],
+                                                 res["current_fractions"][m], track_ids, traj_ids, ev_time,
+                                                 light_trigger_times=np.zeros(1), light_trigger_event_id=np.array([event]),
+                                                 light_trigger_modules=np.ones(1), bad_channels=bad_list)
+                out.append_packets(pk, assn)
+                n_packets += len(pk)
+            n_hits += int((res["adc_list"] != 0).sum())
+            if raw_arrays:
+                res["event_id"] = np.array([t[0] for t in table])[res["batch"]]
+                parts.append(res)
             b = e
-    res = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]} if parts else {}
-    if res:
-        ev = np.array([t[0] for t in table])
-        res["event_id"] = ev[res["batch"]]
-    out_tracks = batching.swap_coordinates(tracks.copy())          # stored un-swapped like the reference (:1275)
-    if output_filename.endswith((".h5", ".hdf5")):
-        import h5py
-        with h5py.File(output_filename, "w") as f:
-            f.create_dataset("segments", data=out_tracks)
-            for k, v in res.items():
-                f.create_dataset(k, data=v)
-    else:
-        np.savez_compressed(output_filename, segments=out_tracks, **res)
-    print(f"simulated {nsim} segments in {len(table)} batches -> {len(res.get('unique_pix', []))} pixel rows, "
-          f"{int((res.get('adc_list', np.zeros(0)) != 0).sum())} hits")
-    return res
+        if raw_arrays and parts:
+            for k in parts[0]:
+                out.put("raw/" + k, np.concatenate([p[k] for p in parts]))
+        # ---- truth pass-through (:1226-1297): true timing structure restored, edep-sim coordinate convention ---------------------------
+        out_tracks = tracks.copy()
+        if sim.IS_SPILL_SIM:
+            ev = out_tracks[sim.EVENT_SEPARATOR]
+            local = ev - (ev // sim.MAX_EVENTS_PER_FILE) * sim.MAX_EVENTS_PER_FILE
+            for f in ("t0_start", "t0_end", "t0"):
+                out_tracks[f] = out_tracks[f] + local * sim.SPILL_PERIOD
+        batching.swap_coordinates(out_tracks)
+        out.put(sim.TRACKS_DSET_NAME, out_tracks, attrs={"zbeam": True})
+        for k, v in truth.items():
+            out.put(k, v)
+        out.close()
+    finally:
+        lib.set_option("mc_current", 0)
+    print(f"simulated {nsim} segments in {len(table)} batches -> {n_hits} hits, {n_packets} packets")
+    print("Output saved in:", output_filename)
+    return dict(n_segments=nsim, n_batches=len(table), n_hits=n_hits, n_packets=n_packets)
 
 
 def main(argv=None):
@@ -146,13 +281,19 @@ def main(argv=None):
     ap.add_argument("--input_filename", required=True)
     ap.add_argument("--output_filename", required=True)
     ap.add_argument("--config", default="module0")
-    ap.add_argument("--mod2mod_variation", type=lambda s: s.lower() in ("1", "true"), default=None)
+    ap.add_argument("--config_root", default=None, help="larnd-sim tree holding config/config.yaml and the YAML families "
+                                                        "(default: $LARNDSIM_ROOT, else the built-in snapshot keywords)")
+    tf = lambda s: s.lower() in ("1", "true", "yes")                # noqa: E731
+    ap.add_argument("--mod2mod_variation", type=tf, default=None)
+    ap.add_argument("--light_simulated", type=tf, default=None)
     for k in ("pixel_layout", "detector_properties", "simulation_properties", "response_file", "light_lut_filename",
-              "pixel_thresholds_file", "pixel_gains_file", *IGNORED):
+              "bad_channels", "pixel_thresholds_file", "pixel_gains_file", *IGNORED):
         ap.add_argument("--" + k, default=None)
-    ap.add_argument("--light_simulated", default=None)
     ap.add_argument("--n_events", type=int, default=None)
     ap.add_argument("--rand_seed", type=int, default=None)
+    ap.add_argument("--tracks_current_mc", action="store_true",
+                    help="induced currents from tracks_current_mc like the reference driver (default: tracks_current)")
+    ap.add_argument("--raw_arrays", action="store_true", help="also store the per-pixel arrays (raw/...) and light_sample_inc")
     a = vars(ap.parse_args(argv))
     run_simulation(**a)
 

@@ -1,0 +1,88 @@
+"""
+Configuration keywords -> file sets, mirroring ``larndsim.config.get_config`` (larndsim/config/config.py:40-69).
+
+Two sources:
+* a user-supplied larnd-sim tree (``root`` argument or the ``LARNDSIM_ROOT`` environment variable: the directory that holds
+  ``config/config.yaml``, ``detector_properties/``, ``pixel_layouts/``, ``simulation_properties/`` and ``bin/``): the YAML
+  map is read from there and resolved exactly like the reference does -- bare file names are joined to their family's
+  directory, names containing ``/`` are kept, lists are resolved element by element, extra keys pass through;
+* without one, the built-in keywords whose constants ship as numbers-only snapshots (``snapshots/*.json``).
+
+A keyword whose entry has ``MOD2MOD_VARIATION: True`` (``2x2``, ``2x2_mpvmpr``, ``2x2_old_response``, ... in the reference's
+config.yaml) describes a detector with per-module pixel layouts / responses / LUTs; that mode is not built, and such a
+keyword is never mapped onto a single-configuration detector: ``check_single_configuration`` raises for it.
+"""
+import os
+
+import yaml
+
+CONFIG_DIR_NAMES = dict(SIM_PROPERTIES='simulation_properties', PIXEL_LAYOUT='pixel_layouts',
+                        DET_PROPERTIES='detector_properties', RESPONSE='bin', LIGHT_LUT='bin', LIGHT_DET_NOISE='bin')
+
+# built-in keywords: the file names are the ones the reference's own tests / config.yaml name for these detectors
+BUILTIN = {
+    'module0': dict(SNAPSHOT='module0', SIM_PROPERTIES='singles_sim.yaml', PIXEL_LAYOUT='multi_tile_layout-2.3.16.yaml',
+                    DET_PROPERTIES='module0.yaml', RESPONSE='response_44.npy', LIGHT_SIMULATED=True),
+    '2x2_no_modvar': dict(SNAPSHOT='2x2_no_modvar', SIM_PROPERTIES='2x2_NuMI_sim_no_modvar.yaml',
+                          PIXEL_LAYOUT='multi_tile_layout-2.4.16.yaml', DET_PROPERTIES='2x2_no_modvar.yaml',
+                          RESPONSE='response_44.npy', LIGHT_SIMULATED=True, MOD2MOD_VARIATION=False),
+    'ndlar': dict(SNAPSHOT='ndlar', SIM_PROPERTIES='NDLAr_LBNF_sim.yaml', PIXEL_LAYOUT='multi_tile_layout-3.0.40.yaml',
+                  DET_PROPERTIES='ndlar-module.yaml', RESPONSE='response_38.npy', LIGHT_SIMULATED=True, LIGHT_LUT='',
+                  LIGHT_DET_NOISE=''),
+}
+
+
+def _root(root=None):
+    root = root or os.environ.get('LARNDSIM_ROOT')
+    if root and not os.path.isfile(os.path.join(root, 'config', 'config.yaml')):
+        raise FileNotFoundError(f"{root} is not a larnd-sim tree: config/config.yaml not found")
+    return root
+
+
+def config_map(root=None):
+    root = _root(root)
+    if not root:
+        return BUILTIN
+    with open(os.path.join(root, 'config', 'config.yaml')) as f:
+        return yaml.safe_load(f)
+
+
+def list_config_keys(root=None):
+    return config_map(root).keys()
+
+
+def get_config(keyname, root=None):
+    """Resolved entry of ``keyname``; raises KeyError like the reference for an unknown keyword."""
+    root = _root(root)
+    cmap = config_map(root)
+    if keyname not in cmap:
+        extra = "" if root else (" (built-in snapshots only: set LARNDSIM_ROOT or pass --config_root to resolve the keywords "
+                                 "of a larnd-sim tree's config.yaml)")
+        raise KeyError(f'Key {keyname} not in supported keywords {list(cmap.keys())}{extra}')
+    cfg_map = cmap[keyname]
+    if not root:
+        return dict(cfg_map)
+    res = {}
+    for key, val in cfg_map.items():
+        if key not in CONFIG_DIR_NAMES:
+            res[key] = val
+        elif isinstance(val, str):
+            res[key] = val if '/' in val else os.path.join(root, CONFIG_DIR_NAMES[key], val)
+        elif isinstance(val, list):
+            res[key] = [v if '/' in v else os.path.join(root, CONFIG_DIR_NAMES[key], v) for v in val]
+    return res
+
+
+def check_single_configuration(keyname, cfg, mod2mod_variation=None):
+    """The reference's mod2mod decision (cli/simulate_pixels.py:355-372) up to the point where per-module files would be
+    loaded: returns normally when every module uses one configuration, raises NotImplementedError otherwise."""
+    m2m = cfg.get('MOD2MOD_VARIATION') if mod2mod_variation is None else mod2mod_variation
+    if not m2m:
+        return
+    single = all(isinstance(cfg.get(k), str) or cfg.get(k) is None or len(cfg.get(k)) == 1
+                 for k in ('PIXEL_LAYOUT', 'RESPONSE', 'LIGHT_LUT'))
+    if single:
+        return      # the reference deactivates module variation with a warning in this case (:365-367)
+    raise NotImplementedError(
+        f"configuration '{keyname}' needs module-to-module variation (per-module pixel layouts / responses / light LUTs, "
+        f"cli/simulate_pixels.py:678-715), which is not built; use a *_no_modvar keyword or explicit single files")

@@ -272,3 +272,35 @@ def test_packets_writer_golden(cfg):
     assert np.array_equal(assn["file_traj_ids"], g["assn_file_traj_ids"])
     assert np.array_equal(assn["fraction_traj"], g["assn_fraction_traj"])
     assert packets.packets_dtype.itemsize == 36 and assn.dtype == packets.assn_dtype()
+
+
+def test_config_keyword_resolution():
+    """config.get_config follows larndsim/config/config.py:40-69: bare names joined to their family's directory, names with
+    '/' kept, lists element by element, other keys passed through; mod2mod keywords are refused, never aliased."""
+    from larndsim_amd import config
+    assert set(config.list_config_keys()) == {"module0", "2x2_no_modvar", "ndlar"}          # built-in snapshots
+    assert config.get_config("ndlar")["SNAPSHOT"] == "ndlar"
+    with pytest.raises(KeyError, match="not in supported keywords"):
+        config.get_config("2x2")
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present on this box")
+    keys = set(config.list_config_keys(REF))
+    assert {"module0", "2x2", "2x2_no_modvar", "2x2_mpvmpr", "ndlar"} <= keys
+    c = config.get_config("2x2_no_modvar", REF)
+    assert c["DET_PROPERTIES"] == os.path.join(REF, "detector_properties", "2x2_no_modvar.yaml")
+    assert c["PIXEL_LAYOUT"] == os.path.join(REF, "pixel_layouts", "multi_tile_layout-2.4.16.yaml")
+    assert c["RESPONSE"] == os.path.join(REF, "bin", "response_44.npy")
+    assert c["LIGHT_LUT"].startswith("/global/cfs/")                   # has a '/': kept as written
+    assert c["MOD2MOD_VARIATION"] is False and c["LIGHT_SIMULATED"] is True
+    config.check_single_configuration("2x2_no_modvar", c)
+    m = config.get_config("2x2", REF)
+    assert m["PIXEL_LAYOUT"] == [os.path.join(REF, "pixel_layouts", f) for f in
+                                 ("multi_tile_layout-2.4.16.yaml", "multi_tile_layout-2.5.16.yaml")]
+    assert m["PIXEL_LAYOUT_ID"] == [0, 0, 1, 0] and m["MOD2MOD_VARIATION"] is True
+    with pytest.raises(NotImplementedError, match="module-to-module variation"):
+        config.check_single_configuration("2x2", m)
+    with pytest.raises(KeyError):
+        config.get_config("2x2_mod2mod_variation", REF)               # the reference CLI's default keyword is not in its own map
+    # the resolved files load through the package's own YAML loader
+    consts.load_properties(c["DET_PROPERTIES"], c["PIXEL_LAYOUT"], c["SIM_PROPERTIES"])
+    assert consts.detector.TPC_BORDERS.shape == (8, 3, 2) and len(consts.detector.PIXEL_CONNECTION_DICT) == 4900

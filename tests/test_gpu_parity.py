@@ -1277,52 +1277,86 @@ def test_f32_tail_class_equals_all_f64(cfg, kind):
     np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
 
 
-def test_cli_end_to_end(tmp_path):
-    """simulate_pixels CLI on a .npy segment file (edep-sim frame) == ChargeChain on the same prepared input."""
+def _load_cli():
     import importlib.util
     import os
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("sp_cli", os.path.join(repo, "larnd-sim_amd", "cli", "simulate_pixels.py"))
     cli = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cli)
+    return cli
+
+
+def test_cli_end_to_end(tmp_path):
+    """simulate_pixels CLI on a .npy segment file (edep-sim frame), shipped noise charges, seeded: the per-pixel arrays equal
+    a ChargeChain run by hand with the same seed, the LArPix packets are what packets.build_packets makes of them, the
+    segments come back in the edep-sim frame, and a mod2mod keyword is refused instead of aliased."""
+    from larndsim_amd import packets
+    cli = _load_cli()
     H.load_cfg("module0")
     seg = synth.make_segments(40, seed=9, segs_per_event=20)
     np.save(tmp_path / "in.npy", seg)
     resp = synth.make_response("survey")
     np.save(tmp_path / "resp.npy", resp)
     res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out.npz"), config="module0",
-                             response_file=str(tmp_path / "resp.npy"))
+                             response_file=str(tmp_path / "resp.npy"), rand_seed=5, raw_arrays=True)
     out = np.load(tmp_path / "out.npz")
     assert out["segments"].shape[0] <= 40 and (out["segments"]["n_electrons"] > 0).any()
-    # same thing by hand
-    H.load_cfg("module0")
+    # same thing by hand: the CLI keeps the shipped noise charges and seeds the state table with rand_seed
+    H.load_cfg("module0", noise_zero=False)
+    assert consts.detector.RESET_NOISE_CHARGE > 0
     tr = cli.prepare_tracks(seg.copy())
     tr = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
     bid, order, table = batching.assign_batches(tr)
     tr, bid = np.ascontiguousarray(tr[order]), bid[order]
     ch = ChargeChain(resp)
+    ch.seed_rng(5)
     ch.upload(tr, bid); ch.quench_drift(); ch.run(0, len(tr), want_fractions=True)
     ref = ch.download()
-    assert np.array_equal(out["unique_pix"], ref["unique_pix"]) and np.array_equal(out["adc_digit"], ref["adc_digit"])
-    assert np.array_equal(out["adc_ticks_list"], ref["adc_ticks_list"])
-    np.testing.assert_allclose(out["adc_list"], ref["adc_list"], rtol=1e-12, atol=0)   # not bitwise: DESIGN "Reproducibility"
-    assert np.array_equal(out["event_id"], np.array([t[0] for t in table])[ref["batch"]])
+    assert np.array_equal(out["raw__unique_pix"], ref["unique_pix"]) and np.array_equal(out["raw__adc_digit"], ref["adc_digit"])
+    assert np.array_equal(out["raw__adc_ticks_list"], ref["adc_ticks_list"])
+    np.testing.assert_allclose(out["raw__adc_list"], ref["adc_list"], rtol=1e-12, atol=0)
+    assert np.array_equal(out["raw__event_id"], np.array([t[0] for t in table])[ref["batch"]])
+    # packets: one data packet per hit above the pedestal code, the association rows travel with them
+    pk, assn = out["packets"], out["mc_packets_assn"]
+    assert pk.dtype == packets.packets_dtype and len(pk) == len(assn) == res["n_packets"]
+    n_data = int((ref["adc_digit"] > packets._digitize0()).sum())
+    assert (pk["packet_type"] == 0).sum() == n_data > 0
+    seg_ids = set(int(x) for x in seg["segment_id"])
+    used = assn["segment_ids"][pk["packet_type"] == 0]
+    assert set(int(x) for x in used[used >= 0]) <= seg_ids and (assn["fraction"][pk["packet_type"] == 0][:, 0] > 0).all()
     # stored un-swapped: x is the drift axis again
     by_id = {int(r["segment_id"]): r for r in seg}
     for r in out["segments"]:
         assert r["x"] == by_id[int(r["segment_id"])]["x"] and r["z"] == by_id[int(r["segment_id"])]["z"]
+    # a keyword of another detector description is refused, not aliased (there is no built-in '2x2')
+    with pytest.raises(KeyError, match="not in supported keywords"):
+        cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out2.npz"), config="2x2")
+
+
+def test_cli_light_leg(tmp_path):
+    """--light_lut_filename: the CLI runs the device-resident light leg and writes light_dat like the reference's driver."""
+    cli = _load_cli()
+    H.load_cfg("module0")
+    seg = synth.make_segments(60, seed=10, segs_per_event=30)
+    np.save(tmp_path / "in.npy", seg)
+    lut = synth.make_lut((14, 26, 8), 48, 40, 3)
+    np.savez(tmp_path / "lut.npz", arr=lut)
+    res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out.npz"), config="module0", rand_seed=1,
+                             light_lut_filename=str(tmp_path / "lut.npz"), raw_arrays=True)
+    out = np.load(tmp_path / "out.npz")
+    dat = out["light_dat__light_dat_allmodules"]
+    assert dat.shape == (out["segments"].shape[0], consts.light.N_OP_CHANNEL)
+    assert (dat["n_photons_det"] > 0).any() and np.array_equal(dat["segment_id"][:, 0], out["segments"]["segment_id"])
+    inc = out["light_sample_inc"]
+    assert inc.shape[0] == res["n_batches"] and inc.sum() > 0
 
 
 def test_cli_pixel_threshold_and_gain_files(tmp_path):
     """--pixel_thresholds_file / --pixel_gains_file (the reference's keys / values / default .npz, cli/simulate_pixels.py:
     439-449) reach the fused chain: same result as setting the tables by hand, different from running without them, and
     the next run without the flags is back on the constants."""
-    import importlib.util
-    import os
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("sp_cli", os.path.join(repo, "larnd-sim_amd", "cli", "simulate_pixels.py"))
-    cli = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(cli)
+    cli = _load_cli()
     H.load_cfg("module0")
     det = consts.detector
     seg = synth.make_segments(40, seed=9, segs_per_event=20)
@@ -1336,23 +1370,27 @@ def test_cli_pixel_threshold_and_gain_files(tmp_path):
     gain = det.GAIN * consts.units.mV / consts.units.e * rng.uniform(0.5, 1.5, keys.size)
     np.savez(tmp_path / "thr.npz", keys=keys, values=thr, default=np.array([2.0 * det.DISCRIMINATION_THRESHOLD]))
     np.savez(tmp_path / "gain.npz", keys=keys, values=gain, default=np.array([det.GAIN * consts.units.mV / consts.units.e]))
-    common = dict(config="module0", response_file=str(tmp_path / "resp.npy"))
-    with_files = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "a.npz"), pixel_thresholds_file=str(tmp_path / "thr.npz"),
-                                    pixel_gains_file=str(tmp_path / "gain.npz"), **common)
-    without = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "b.npz"), **common)
+    common = dict(config="module0", response_file=str(tmp_path / "resp.npy"), rand_seed=8, raw_arrays=True)
+    cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "a.npz"), pixel_thresholds_file=str(tmp_path / "thr.npz"),
+                       pixel_gains_file=str(tmp_path / "gain.npz"), **common)
+    cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "b.npz"), **common)
+    with_files = {k[5:]: v for k, v in np.load(tmp_path / "a.npz").items() if k.startswith("raw__")}
+    without = {k[5:]: v for k, v in np.load(tmp_path / "b.npz").items() if k.startswith("raw__")}
     assert not np.array_equal(with_files["adc_digit"], without["adc_digit"])
-    H.load_cfg("module0")
+    H.load_cfg("module0", noise_zero=False)
     tr = cli.prepare_tracks(seg.copy())
     tr = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
     bid, order, table = batching.assign_batches(tr)
     tr, bid = np.ascontiguousarray(tr[order]), bid[order]
     ch = ChargeChain(resp)
     ch.upload(tr, bid); ch.quench_drift()
+    ch.seed_rng(8)
     ch.run(0, len(tr), want_fractions=True)
     plain = ch.download()
     try:
         ch.set_pixel_thresholds(keys, thr, 2.0 * det.DISCRIMINATION_THRESHOLD)
         ch.set_pixel_gains(keys, gain, det.GAIN * consts.units.mV / consts.units.e)
+        ch.seed_rng(8)
         ch.run(0, len(tr), want_fractions=True)
         by_hand = ch.download()
     finally:
