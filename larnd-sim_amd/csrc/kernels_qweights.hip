@@ -14,7 +14,7 @@
 //
 // Pairs whose segment is longer than ~130 widths (N > 256: sT -> 0 next to the anode) and pairs that exceed the item /
 // correction / run capacities are flagged and recomputed by the monolithic current_kernel, like in weights_kernel.
-#include "split_common.h"
+#include "qpair.h"
 
 #define QNB 16            // quadrature nodes per batch (tables of one batch live in LDS)
 #define QTILES 512        // (cell, 8-shift block) tiles per column group: two per thread, accumulated in registers
@@ -22,8 +22,9 @@
 #define Q_CELLS 512       // response cells per group
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, const double* __restrict__ glx,
-                                                                  const double* __restrict__ glw, int qn_max) {
+__global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, const PairParams* __restrict__ pp,
+                                                                  const double* __restrict__ glx,
+                                                                  const double* __restrict__ glw) {
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -31,24 +32,23 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
   if (pair >= A.n_pairs) return;
   int32_t* hdr = S.hdr + pair * HDR_INTS;
 
-  int64_t seg, pID;
-  {
-    int32_t v = A.pair_val[pair];
-    seg = A.seg_begin + v / A.P;
-    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
+  // the pair's constants come from pair_setup_kernel's record (one thread per pair there; here every wave of the workgroup
+  // used to repeat the geometry): the doubles sit in LDS and are read where a phase needs them
+  __shared__ double s_par[32];
+  const PairParams* __restrict__ P = pp + pair;
+  const int status = (A.debug_phases & 0x100) ? 0 : P->status;
+  if (status != 1) {           // nothing to emit, or handed to the monolithic kernel
+    if (tid < HDR_INTS) hdr[tid] = (status == 2 && tid == 7) ? 1 : 0;
+    if (status == 2 && tid == 0) atomicAdd(&A.counters[6], 1ull);
+    return;
   }
-  int T = A.T;
-  if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
-
-  PairGeo g;
-  pair_geometry(A, seg, pID, g);
+  const int NQ = P->NQ, iz_lo = P->iz_lo, iz_hi = P->iz_hi, it0 = P->it0, T = P->T, it_w0 = P->it_w0, it_w1 = P->it_w1;
+  if (tid < PP_COUNT) s_par[tid] = ((const double*)((const char*)P + 32))[tid];
+  __syncthreads();
   auto write_empty = [&]() {
     if (tid < HDR_INTS) hdr[tid] = 0;
   };
-  if (!g.ok) { write_empty(); return; }
-  if (A.debug_phases & 0x100) { write_empty(); return; }      // timing tools: stop after the geometry
   const int NS = c->sampled_points;
-  const double dt = c->time_sampling, dtr = c->response_sampling, TW = c->time_window;
   const double bin = c->response_bin_size;
 
   __shared__ double s_X[QNB][QCOLS], s_Y[QNB][NJ_MAX], s_Z[QNB][ZC], s_Zi[QNB][ZC];
@@ -69,14 +69,14 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
     int i = -1;
     double ddx = 0;
     if (lane < NS) {
-      double x = g.x_start + g.sgnx * (lane * g.x_step - 4 * g.sT);
-      double xd = fabs(g.x_p - x);
+      double x = s_par[PP_X_START] + s_par[PP_SGNX] * (lane * s_par[PP_X_STEP] - 4 * s_par[PP_ST]);
+      double xd = fabs(s_par[PP_X_P] - x);
       if (!(xd > bin * A.ni)) {
         i = (int)py_round(xd / bin - 0.5);
         if (i < 0 || i >= A.ni) i = -1;
       }
       s_icell[lane] = (short)i;
-      ddx = x - g.sx;
+      ddx = x - s_par[PP_SX];
       s_dx[lane] = ddx;
     }
     int leader = lane;
@@ -122,14 +122,14 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
     int j = -1;
     double ddy = 0;
     if (lane < NS) {
-      double y = g.y_start + g.sgny * (lane * g.y_step - 4 * g.sT);
-      double yd = fabs(g.y_p - y);
+      double y = s_par[PP_Y_START] + s_par[PP_SGNY] * (lane * s_par[PP_Y_STEP] - 4 * s_par[PP_ST]);
+      double yd = fabs(s_par[PP_Y_P] - y);
       if (!(yd > bin * A.nj)) {
         j = (int)py_round(yd / bin - 0.5);
         if (j < 0 || j >= A.nj) j = -1;
       }
       s_jcell[lane] = (short)j;
-      ddy = y - g.sy;
+      ddy = y - s_par[PP_SY];
       s_dy[lane] = ddy;
     }
     int jmin = (j >= 0) ? j : (1 << 20), jmax = j;
@@ -162,124 +162,19 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
   if (ncol == 0 || NJ <= 0 || NJ > NJ_MAX) { write_empty(); return; }
   if (A.debug_phases & 0x200) { write_empty(); return; }      // timing tools: stop after the sample maps
 
-  const double V = TW / dtr;
-  int edge_k[NEDGE] = {0, -1, -1};
-  int k_top;
-  {
-    int ka = (int)floor(V - 0.5 - 1e-6);
-    if ((double)ka + 0.5 >= V - 1e-6) ka--;
-    int kn = (int)ceil(V + 0.5 + 1e-6);
-    k_top = kn - 1;
-    int ne = 1;
-    for (int k = ka + 1; k <= k_top && ne < NEDGE; k++) edge_k[ne++] = k;
-    if (k_top - ka > NEDGE - 1) k_top = ka + NEDGE - 1;
-  }
-  const int k_stage_hi = min(min(k_top, A.nk - 1), A.k_last);
-  const int k_stage_lo = max(0, A.k_first);
-
-  int it0 = 0;
-  if (g.t_start < 0) {
-    int cand = (int)ceil(-g.t_start / dt) - 1;
-    if (cand < 0) cand = 0;
-    while (g.t_start + cand * dt < 0.) cand++;
-    it0 = cand;
-  }
-  int iz_lo = 0, iz_hi = g.z_steps - 1;
-  if (A.prune_log > 0 && g.z_step > 0) {
-    double cz = sqrt(2.0 * A.prune_log) * g.sL;
-    double zl = g.sz - cz, zh = g.sz + g.Dz + cz;
-    double fl = floor((zl - g.z_start_int) / g.z_step) - 1, fh = ceil((zh - g.z_start_int) / g.z_step) + 1;
-    if (fl > iz_lo) iz_lo = (int)fmin(fl, (double)g.z_steps);
-    if (fh < iz_hi) iz_hi = (int)fmax(fh, -1.0);
-  }
-  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
-  const double i2T = 1.0 / (2 * g.sT2), i2L = 1.0 / (2 * g.sL2);
-  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
-  const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
-  // numba_f32: _b divides by sigma*sigma typed f32 while delta and a use the f64 square (detsim.py:116-118,141-148), so per
-  // axis the exponent is -[(d - r u s)^2 + u^2 s^2 (1 - r^2)] / (2 sigma^2), r = sigma^2 / (sigma*sigma)_f32: still one
-  // Gaussian per axis (centre scaled by r) times a factor that depends on the node only.  r = 1, kappa = 0 otherwise.
-  const double uxr = ux * g.rT, uyr = uy * g.rT, uzr = uz * g.rL;
-  const double kappa = (ux * ux + uy * uy) * (1.0 - g.rT * g.rT) * i2T + uz * uz * (1.0 - g.rL * g.rL) * i2L;
-
-  // ---- the part of the segment that can reach the sample box, and the Gauss-Legendre rule on it --------------------------------
-  // a node whose distance to the box along any axis exceeds G widths adds less than exp(-G^2/2) of the on-axis density
-  const double G = sqrt(2.0 * ((A.prune_log > 0 ? A.prune_log : 43.0) + 7.0));
-  double s_lo = 0, s_hi = g.Dr;
-  {
-    const double z0 = g.z_start_int + iz_lo * g.z_step - g.sz, z1 = g.z_start_int + iz_hi * g.z_step - g.sz;
-    const double lo3[3] = {s_rng[0], s_rng[2], fmin(z0, z1)}, hi3[3] = {s_rng[1], s_rng[3], fmax(z0, z1)};
-    const double u3[3] = {ux, uy, uz}, w3[3] = {sqrt(g.sT2), sqrt(g.sT2), sqrt(g.sL2)};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const double lo = lo3[k] - G * w3[k], hi = hi3[k] + G * w3[k];
-      if (u3[k] != 0.0) {
-        const double sa = lo / u3[k], sb = hi / u3[k];
-        s_lo = fmax(s_lo, fmin(sa, sb));
-        s_hi = fmin(s_hi, fmax(sa, sb));
-      } else if (lo > 0 || hi < 0) {
-        s_hi = -1;   // the segment does not move along this axis and the box is out of reach
-      }
-    }
-  }
-  if (!(s_hi > s_lo) || iz_hi < iz_lo) { write_empty(); return; }
-  const double qlen = s_hi - s_lo;
-  const double ratio = qlen * sqrt(2.0 * a);           // length in units of the Gaussian's width along the segment
-  const double nq_f = ceil(6.0 + 1.9 * ratio);
-  const bool too_long = !(nq_f <= (double)qn_max);
-  const int NQ = too_long ? 0 : (int)nq_f;
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
   const double* __restrict__ gx_tab = glx + (int64_t)NQ * (NQ - 1) / 2;
   const double* __restrict__ gw_tab = glw + (int64_t)NQ * (NQ - 1) / 2;
-  const double wscale = factor * g.dV * 0.5 * qlen;
   const bool do_prune = A.prune_log > 0;
+  // numba_f32: _b divides by sigma*sigma typed f32 while delta and a use the f64 square (detsim.py:116-118,141-148), so per
+  // axis the exponent is -[(d - r u s)^2 + u^2 s^2 (1 - r^2)] / (2 sigma^2), r = sigma^2 / (sigma*sigma)_f32: still one
+  // Gaussian per axis (centre scaled by r) times a factor that depends on the node only (pair_setup_kernel: uxr.., kappa).
+  const double uxr = s_par[PP_UXR], uyr = s_par[PP_UYR], uzr = s_par[PP_UZR], i2T = s_par[PP_I2T], i2L = s_par[PP_I2L];
+  const double kappa = s_par[PP_KAPPA], s_lo = s_par[PP_S_LO], qlen = s_par[PP_QLEN], wscale = s_par[PP_WSCALE];
   // bins below exp(-prune_log) of the weight of an on-axis interior sample are not emitted
-  const double thr = do_prune ? exp(-A.prune_log) * factor * g.dV * sqrt(M_PI / a) : 0.0;
-
-  auto slice_shift = [&](int iz, double& z, double& t0, bool count) -> int {
-    z = g.z_start_int + iz * g.z_step;
-    t0 = fabs(z - g.z_anode) / c->v_drift - TW;
-    int it_ref = (int)((t0 + 0.5 * TW - g.t_start) / dt);
-    if (it_ref < 0) it_ref = 0;
-    double tt = g.t_start + it_ref * dt;
-    double val = (tt - t0) / dtr;
-    double kr = py_round(val);
-    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
-    return (int)kr - M * it_ref;
-  };
-  {
-    int smin = 1 << 30, smax = -(1 << 30);
-    for (int iz = iz_lo + tid; iz <= iz_hi; iz += CUR_THREADS) {
-      double z, t0;
-      int sh = slice_shift(iz, z, t0, false);
-      smin = min(smin, sh);
-      smax = max(smax, sh);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      smin = min(smin, __shfl_down(smin, off));
-      smax = max(smax, __shfl_down(smax, off));
-    }
-    if (lane == 0) {
-      s_misc[8 + wv] = smin;
-      s_misc[12 + wv] = smax;
-    }
-  }
-  __syncthreads();
-  const int sh_min = min(min(s_misc[8], s_misc[9]), min(s_misc[10], s_misc[11]));
-  const int sh_max = max(max(s_misc[12], s_misc[13]), max(s_misc[14], s_misc[15]));
-  int it_w0 = it0, it_w1 = T;
-  if (sh_min <= sh_max) {
-    int lo = (k_stage_lo - sh_max) / M - 1, hi = (k_stage_hi - sh_min) / M + 2;
-    it_w0 = max(it_w0, lo);
-    it_w1 = min(it_w1, hi);
-  }
-  if (sh_min > sh_max || it_w1 <= it_w0 || k_stage_hi < k_stage_lo) { write_empty(); return; }
-  if (A.debug_phases & 0x400) { write_empty(); return; }      // timing tools: stop after the shift scan
-  if (too_long) {
-    // hand the pair to the monolithic kernel
-    if (tid < HDR_INTS) hdr[tid] = (tid == 7) ? 1 : 0;
-    if (tid == 0) atomicAdd(&A.counters[6], 1ull);
-    return;
-  }
+  const double thr = s_par[PP_THR];
+  if (A.debug_phases & 0x400) { write_empty(); return; }      // timing tools: stop before the chunk loop
 
   constexpr int IMAX = ItemCap<M>::value;
   Item* items = S.items + pair * IMAX;
@@ -293,10 +188,12 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
       int nmax = min(ZC, iz_hi - iz_next + 1);
       int sh = 0, inval = 0;
       if (lane < nmax) {
-        int iz = iz_next + lane;
         double z, t0;
-        sh = slice_shift(iz, z, t0, true);
-        s_dz[lane] = z - g.sz;
+        bool amb;
+        sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_next + lane, z,
+                               t0, amb);
+        if (amb) atomicAdd(&A.counters[0], 1ull);
+        s_dz[lane] = z - s_par[PP_SZ];
         s_shift[lane] = sh;
 #pragma unroll
         for (int e = 0; e < NEDGE; e++) {
@@ -309,7 +206,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
             const int it_e = num / M;
             if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
               int64_t kk;
-              need = !(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e]);
+              need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
             }
           }
           if (need) inval |= 1 << e;
@@ -387,7 +284,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
               double sum = 0;
               for (int k = s_colstart[col0 + b]; k < s_colstart[col0 + b + 1]; k++) {
                 const double d = s_dx[s_ixord[k]] - cen;
-                sum += exp(-d * d * i2T);
+                sum += exp_neg(-d * d * i2T);
               }
               s_X[n][b] = sum;
             } else if (kind == 1) {
@@ -395,7 +292,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
               double sum = 0;
               for (int k = s_jstart[b]; k < s_jstart[b + 1]; k++) {
                 const double d = s_dy[s_iyord[k]] - cen;
-                sum += exp(-d * d * i2T);
+                sum += exp_neg(-d * d * i2T);
               }
               s_Y[n][b] = sum;
             } else {
@@ -404,12 +301,12 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
               for (int k = s_ustart[b]; k < s_ustart[b + 1]; k++) {
                 const int sl = s_zord[k];
                 const double d = s_dz[sl] - cen;
-                const double e = exp(-d * d * i2L);
+                const double e = exp_neg(-d * d * i2L);
                 sum += e;
                 if (s_inval[sl]) sumi += e;      // refined per edge below when several edges are flagged
               }
               double wn = wscale * gw_tab[n0 + n];
-              if (kappa != 0.0) wn *= exp(-sn * sn * kappa);
+              if (kappa != 0.0) wn *= exp_neg(-sn * sn * kappa);
               s_Z[n][b] = wn * sum;
               s_Zi[n][b] = wn * sumi;
             }
@@ -452,11 +349,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
                   const int sl = s_zord[k];
                   if (s_inval[sl] & (1 << e)) {
                     const double d = s_dz[sl] - cen;
-                    sumi += exp(-d * d * i2L);
+                    sumi += exp_neg(-d * d * i2L);
                   }
                 }
                 double wn = wscale * gw_tab[n0 + n];
-                if (kappa != 0.0) wn *= exp(-sn * sn * kappa);
+                if (kappa != 0.0) wn *= exp_neg(-sn * sn * kappa);
                 s_Zi[n][b] = wn * sumi;
               }
             }
@@ -616,18 +513,17 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, c
   }
 }
 
-extern "C++" int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M) {
+extern "C++" int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params) {
   if (S.c.n_pairs == 0) return 0;
-  if (!ctx->d_glx || !ctx->d_glw) {
-    ldsim_set_error("Gauss-Legendre tables missing");
-    return LDSIM_ESTATE;
-  }
+  int rc = qpair_setup_launch(ctx, S, M, params);
+  if (rc) return rc;
+  const PairParams* pp = (const PairParams*)params;
   if (M == 1)
-    hipLaunchKernelGGL(qweights_kernel<1>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, ctx->d_glx,
-                       ctx->d_glw, ctx->gl_nmax);
+    hipLaunchKernelGGL(qweights_kernel<1>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, pp, ctx->d_glx,
+                       ctx->d_glw);
   else
-    hipLaunchKernelGGL(qweights_kernel<2>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, ctx->d_glx,
-                       ctx->d_glw, ctx->gl_nmax);
+    hipLaunchKernelGGL(qweights_kernel<2>, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S, pp, ctx->d_glx,
+                       ctx->d_glw);
   HIPCHK(hipGetLastError());
   return 0;
 }

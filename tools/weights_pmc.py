@@ -1,5 +1,5 @@
-"""Phase timing of qweights_kernel via the debug_phases switches (results are wrong unless 15): 1 tables, 2 accumulate,
-4 window-edge corrections, 8 emission."""
+"""Runs the weights stage in modes 1 (qweights_kernel, workgroup per pair) and 2 (qwave_kernel, wave per pair) on 20k module0
+segments, three launches each -- the target of rocprofv3 --pmc passes (profiles/README.md)."""
 import os
 import sys
 
@@ -16,11 +16,8 @@ seg, bid = prepared(cfg, 20000, synth.SEED_BASE + 2, 5000)
 ch = ChargeChain(H.response_for("survey"))
 ch.upload(seg, bid)
 ch.quench_drift()
-lib.set_option("weights_mode", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
-ch.run(0, len(seg), want_fractions=True)
-for mask in (15, 0x100, 0x200, 0, 1, 2, 4, 8, 3, 7, 11, 15):
-    lib.set_option("debug_phases", mask)
-    ch.run(0, len(seg), want_fractions=True)
-    ms = ch.kernel_ms()
-    print(f"{cfg} debug_phases {mask:4d}: weights {ms['weights_ms']:.2f} ms  mac {ms['mac_ms']:.2f}", flush=True)
-lib.set_option("debug_phases", 15)
+for mode in (1, 2):
+    lib.set_option("weights_mode", mode)
+    for _ in range(3):
+        ch.run(0, len(seg), want_fractions=True)
+    print(mode, ch.kernel_ms())
