@@ -16,7 +16,7 @@
 #include "current_common.h"
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 2) current_kernel(CurArgs A) {
+__global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(CurArgs A) {
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t pair = blockIdx.x;

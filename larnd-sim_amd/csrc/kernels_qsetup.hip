@@ -1,0 +1,140 @@
+// kernels_qsetup.hip -- per-pair set-up pass of the quadrature weights stage (kernels_qweights.hip).
+//
+// pair_setup_kernel: one THREAD per (segment, pixel) pair computes what is uniform inside the pair -- the geometry of
+// detsim.py:366-414, the valid sample range on either axis, the slice range, the response-shift range and tick window, the
+// part of the segment that can reach the sample box and the Gauss-Legendre node count -- and writes a 240-byte record.
+// qweights_kernel (a 256-thread workgroup per pair) used to repeat this in each of its four waves; here 64 different pairs
+// share a wave.  (A wave-per-pair form of the whole weights stage was tried on top of this record and measured slower:
+// DESIGN.md section 4, profiles/r02_qwave_phase_timing.log.)
+#include "qpair.h"
+
+// =============================================================================================================
+template <int M>
+__global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams* __restrict__ pp, int qn_max) {
+  const CurArgs& A = S.c;
+  const LdsimConsts* c = A.c;
+  const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pair >= A.n_pairs) return;
+  PairParams P;
+  memset(&P, 0, sizeof(P));
+  int64_t seg, pID;
+  {
+    int32_t v = A.pair_val[pair];
+    seg = A.seg_begin + v / A.P;
+    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
+  }
+  int T = A.T;
+  if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
+  PairGeo g;
+  pair_geometry(A, seg, pID, g);
+  if (!g.ok) { pp[pair] = P; return; }
+  const int NS = c->sampled_points;
+  const double dt = c->time_sampling, bin = c->response_bin_size;
+  // valid samples of either axis (inside the response table) and their extent relative to the segment start
+  double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+  for (int s = 0; s < NS; s++) {
+    const double x = g.x_start + g.sgnx * (s * g.x_step - 4 * g.sT);
+    const double xd = fabs(g.x_p - x);
+    if (!(xd > bin * A.ni)) {
+      const int i = (int)py_round(xd / bin - 0.5);
+      if (i >= 0 && i < A.ni) { xlo = fmin(xlo, x - g.sx); xhi = fmax(xhi, x - g.sx); }
+    }
+    const double y = g.y_start + g.sgny * (s * g.y_step - 4 * g.sT);
+    const double yd = fabs(g.y_p - y);
+    if (!(yd > bin * A.nj)) {
+      const int j = (int)py_round(yd / bin - 0.5);
+      if (j >= 0 && j < A.nj) { ylo = fmin(ylo, y - g.sy); yhi = fmax(yhi, y - g.sy); }
+    }
+  }
+  if (xhi < xlo || yhi < ylo) { pp[pair] = P; return; }
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  int it0 = 0;
+  if (g.t_start < 0) {
+    int cand = (int)ceil(-g.t_start / dt) - 1;
+    if (cand < 0) cand = 0;
+    while (g.t_start + cand * dt < 0.) cand++;
+    it0 = cand;
+  }
+  int iz_lo = 0, iz_hi = g.z_steps - 1;
+  if (A.prune_log > 0 && g.z_step > 0) {
+    double cz = sqrt(2.0 * A.prune_log) * g.sL;
+    double zl = g.sz - cz, zh = g.sz + g.Dz + cz;
+    double fl = floor((zl - g.z_start_int) / g.z_step) - 1, fh = ceil((zh - g.z_start_int) / g.z_step) + 1;
+    if (fl > iz_lo) iz_lo = (int)fmin(fl, (double)g.z_steps);
+    if (fh < iz_hi) iz_hi = (int)fmax(fh, -1.0);
+  }
+  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
+  const double i2T = 1.0 / (2 * g.sT2), i2L = 1.0 / (2 * g.sL2);
+  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
+  const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
+  // the part of the segment that can reach the sample box (kernels_qweights.hip)
+  const double G = sqrt(2.0 * ((A.prune_log > 0 ? A.prune_log : 43.0) + 7.0));
+  double s_lo = 0, s_hi = g.Dr;
+  {
+    const double z0 = g.z_start_int + iz_lo * g.z_step - g.sz, z1 = g.z_start_int + iz_hi * g.z_step - g.sz;
+    const double lo3[3] = {xlo, ylo, fmin(z0, z1)}, hi3[3] = {xhi, yhi, fmax(z0, z1)};
+    const double u3[3] = {ux, uy, uz}, w3[3] = {sqrt(g.sT2), sqrt(g.sT2), sqrt(g.sL2)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double lo = lo3[k] - G * w3[k], hi = hi3[k] + G * w3[k];
+      if (u3[k] != 0.0) {
+        const double sa = lo / u3[k], sb = hi / u3[k];
+        s_lo = fmax(s_lo, fmin(sa, sb));
+        s_hi = fmin(s_hi, fmax(sa, sb));
+      } else if (lo > 0 || hi < 0) {
+        s_hi = -1;
+      }
+    }
+  }
+  if (!(s_hi > s_lo) || iz_hi < iz_lo) { pp[pair] = P; return; }
+  const double qlen = s_hi - s_lo;
+  const double nq_f = ceil(6.0 + 1.9 * qlen * sqrt(2.0 * a));
+  // response shifts of the slices -> the tick window in which any of them sees a staged response entry
+  int sh_min = 1 << 30, sh_max = -(1 << 30);
+  for (int iz = iz_lo; iz <= iz_hi; iz++) {
+    double z, t0;
+    bool amb;
+    const int sh = slice_shift_of<M>(c, g.z_start_int, g.z_step, g.z_anode, g.t_start, iz, z, t0, amb);
+    sh_min = min(sh_min, sh);
+    sh_max = max(sh_max, sh);
+  }
+  int it_w0 = it0, it_w1 = T;
+  {
+    int lo = (k_stage_lo - sh_max) / M - 1, hi = (k_stage_hi - sh_min) / M + 2;
+    it_w0 = max(it_w0, lo);
+    it_w1 = min(it_w1, hi);
+  }
+  if (it_w1 <= it_w0 || k_stage_hi < k_stage_lo) { pp[pair] = P; return; }
+  P.status = (nq_f <= (double)qn_max) ? 1 : 2;
+  P.NQ = P.status == 1 ? (int)nq_f : 0;
+  P.iz_lo = iz_lo; P.iz_hi = iz_hi; P.it0 = it0; P.T = T; P.it_w0 = it_w0; P.it_w1 = it_w1;
+  P.x_p = g.x_p; P.y_p = g.y_p; P.x_start = g.x_start; P.y_start = g.y_start; P.x_step = g.x_step; P.y_step = g.y_step;
+  P.sgnx = g.sgnx; P.sgny = g.sgny; P.sT = g.sT; P.sx = g.sx; P.sy = g.sy;
+  P.z_start_int = g.z_start_int; P.z_step = g.z_step; P.z_anode = g.z_anode; P.t_start = g.t_start; P.sz = g.sz;
+  // numba_f32 (kernels_qweights.hip): centres scaled by r = sigma^2 / (sigma*sigma)_f32, node factor exp(-s^2 kappa)
+  P.uxr = ux * g.rT; P.uyr = uy * g.rT; P.uzr = uz * g.rL; P.i2T = i2T; P.i2L = i2L;
+  P.kappa = (ux * ux + uy * uy) * (1.0 - g.rT * g.rT) * i2T + uz * uz * (1.0 - g.rL * g.rL) * i2L;
+  P.s_lo = s_lo; P.qlen = qlen;
+  P.wscale = factor * g.dV * 0.5 * qlen;
+  P.thr = A.prune_log > 0 ? exp(-A.prune_log) * factor * g.dV * sqrt(M_PI / a) : 0.0;
+  pp[pair] = P;
+}
+
+extern "C++" size_t qpair_params_bytes(int64_t n_pairs) { return (size_t)n_pairs * sizeof(PairParams); }
+
+// the per-pair records of both quadrature weight kernels
+extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params) {
+  if (S.c.n_pairs == 0) return 0;
+  if (!ctx->d_glx || !ctx->d_glw || !params) {
+    ldsim_set_error("Gauss-Legendre tables / pair parameter buffer missing");
+    return LDSIM_ESTATE;
+  }
+  PairParams* pp = (PairParams*)params;
+  const unsigned g0 = (unsigned)((S.c.n_pairs + 255) / 256);
+  if (M == 1) hipLaunchKernelGGL(pair_setup_kernel<1>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax);
+  else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+

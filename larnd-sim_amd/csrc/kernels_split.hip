@@ -722,10 +722,9 @@ extern "C++" int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void*
   if (!M) return 1;
   SplitArgs S = split_args(args, items, hdr, corr, wbuf, wbuf_cap, cursor);
   if (ctx->weights_mode) {
-    int rc = ldsim_ensure(ctx, SB_PPAR, qwave_params_bytes(args.n_pairs));
+    int rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(args.n_pairs));
     if (rc) return rc;
-    return ctx->weights_mode == 2 ? qwave_launch(ctx, S, M, ctx->scratch[SB_PPAR].p)
-                                  : qweights_launch(ctx, S, M, ctx->scratch[SB_PPAR].p);
+    return qweights_launch(ctx, S, M, ctx->scratch[SB_PPAR].p);
   }
   if (M == 1) hipLaunchKernelGGL(weights_kernel<1>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   else hipLaunchKernelGGL(weights_kernel<2>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);

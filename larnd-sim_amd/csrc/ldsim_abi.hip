@@ -220,7 +220,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
   else if (!strcmp(name, "weights_mode")) {
-    if (!(value == 0 || value == 1 || value == 2)) { ldsim_set_error("weights_mode must be 0, 1 or 2"); return LDSIM_EINVAL; }
+    if (!(value == 0 || value == 1)) { ldsim_set_error("weights_mode must be 0 or 1"); return LDSIM_EINVAL; }
     ctx->weights_mode = (int)value;
     ctx->wbuf_learned = 0;
   }

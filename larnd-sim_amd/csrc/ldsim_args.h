@@ -76,6 +76,5 @@ int split_launch_mac(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr
 struct SplitArgs;
 int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params);
 int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params);
-int qwave_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params);
-size_t qwave_params_bytes(int64_t n_pairs);
+size_t qpair_params_bytes(int64_t n_pairs);
 int split_sizes(const ldsim_ctx* ctx, const CurArgs& args, size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes);

@@ -1,5 +1,5 @@
-// qpair.h -- per-pair record of the quadrature weight kernels (pair_setup_kernel in kernels_qwave.hip writes it, one thread
-// per pair; qweights_kernel and qwave_kernel read it) and small device helpers they share.
+// qpair.h -- per-pair record of the quadrature weight kernels (pair_setup_kernel in kernels_qsetup.hip writes it, one thread
+// per pair; qweights_kernel reads it) and small device helpers they share.
 #pragma once
 #include "split_common.h"
 

@@ -33,7 +33,7 @@ def compare(cfg, kind, n=1200):
     ch.upload(seg, bid)
     ch.quench_drift()
     res = {}
-    for name, split, mode in (("mono", 0, 0), ("sample", 1, 0), ("quad", 1, 1), ("qwave", 1, 2)):
+    for name, split, mode in (("mono", 0, 0), ("sample", 1, 0), ("quad", 1, 1)):
         lib.set_option("split_kernels", split)
         lib.set_option("weights_mode", mode)
         st = ch.run(0, len(seg), want_fractions=True)
@@ -41,10 +41,9 @@ def compare(cfg, kind, n=1200):
         print(f"  {cfg}/{kind} {name}: pairs {st.n_pairs} fallback {st.n_fallback} wbuf/pair {st.n_wbuf / max(st.n_pairs, 1):.0f} "
               f"samples-or-nodes/pair {st.n_samples / max(st.n_pairs, 1):.1f} dfma/seg {st.n_dfma / n:.3g}", flush=True)
     lib.set_option("split_kernels", 1)
-    lib.set_option("weights_mode", 2)
+    lib.set_option("weights_mode", 1)
     a = res["mono"]
-    print("  qwave == quad bitwise:", {k: bool(np.array_equal(res["quad"][k], res["qwave"][k])) for k in res["quad"]})
-    for name in ("sample", "quad", "qwave"):
+    for name in ("sample", "quad"):
         b = res[name]
         ok = (np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"]))
         hits = np.array_equal(a["adc_list"] != 0, b["adc_list"] != 0)
@@ -62,7 +61,7 @@ def timing(cfg, kind, n=20000):
     ch = ChargeChain(H.response_for(kind))
     ch.upload(seg, bid)
     ch.quench_drift()
-    for mode in (1, 2, 1, 2):
+    for mode in (0, 1, 0, 1):
         lib.set_option("weights_mode", mode)
         ch.run(0, len(seg), want_fractions=True)     # warm-up (pool sizing)
         t0 = time.perf_counter()
@@ -72,7 +71,7 @@ def timing(cfg, kind, n=20000):
         print(f"  {cfg}/{kind} weights_mode {mode}: weights {ms['weights_ms']:.2f} ms mac {ms['mac_ms']:.2f} fallback "
               f"{ms['fallback_ms']:.2f} adc {ms['adc_ms']:.2f} total {ms['total_ms']:.2f} wall {1e3 * wall:.1f} ms; "
               f"fallback pairs {st.n_fallback}/{st.n_pairs}", flush=True)
-    lib.set_option("weights_mode", 2)
+    lib.set_option("weights_mode", 1)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ seg, bid = prepared(cfg, 20000, synth.SEED_BASE + 2, 5000)
 ch = ChargeChain(H.response_for("survey"))
 ch.upload(seg, bid)
 ch.quench_drift()
-lib.set_option("weights_mode", int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+lib.set_option("weights_mode", 1)
 ch.run(0, len(seg), want_fractions=True)
 for mask in (15, 0x100, 0x200, 0, 1, 2, 4, 8, 3, 7, 11, 15):
     lib.set_option("debug_phases", mask)
