@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 3
+#define LDSIM_ABI_VERSION 4
 
 /* error codes */
 #define LDSIM_OK 0
@@ -94,6 +94,12 @@ typedef struct {
   int32_t sipm_response_model;             /* 0 = RLC model, 1 = measured impulse (IMPULSE_MODEL passed as an array) */
   int32_t mc_sample_multiplier;            /* sim.MC_SAMPLE_MULTIPLIER (ABI 3, tracks_current_mc, detsim.py:318-323) */
   double min_step_size;                    /* sim.MIN_STEP_SIZE [cm] */
+  /* light triggers and digitisation (ABI 4): get_triggers / sim_triggers / gen_light_detector_noise, light_sim.py:339-619 */
+  double light_trig_window[2];             /* LIGHT_TRIG_WINDOW [us] */
+  double light_digit_sample_spacing;       /* LIGHT_DIGIT_SAMPLE_SPACING [us] */
+  double light_det_noise_sample_spacing;   /* LIGHT_DET_NOISE_SAMPLE_SPACING [us] */
+  int32_t light_nbit;                      /* LIGHT_NBIT */
+  int32_t op_channel_per_trig;             /* OP_CHANNEL_PER_TRIG */
 } LdsimConsts;
 
 typedef struct ldsim_ctx ldsim_ctx;
@@ -154,6 +160,10 @@ int ldsim_synchronize(ldsim_ctx* ctx);
 int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states);
 int ldsim_rng_states_download(ldsim_ctx* ctx, uint64_t* states /* [n][2] = s0, s1 */, int64_t n);
 int ldsim_rng_clear(ldsim_ctx* ctx);
+/* maybe_create_rng_states(n, seed, rng_states) (cli/simulate_pixels.py:92-104): no table -> n states from `seed`; a shorter
+ * table -> create_xoroshiro128p_states(n - len, seed) appended; otherwise untouched.  ldsim_rng_count: states held, -1 none. */
+int ldsim_rng_extend(ldsim_ctx* ctx, int64_t n_states, uint64_t seed);
+int64_t ldsim_rng_count(ldsim_ctx* ctx);
 
 /* ---- (1) stage-by-stage, host buffers ---------------------------------------------------------- */
 /* quenching.quench[bpg,tpb](tracks, mode)            -- reference larndsim/quenching.py:11-44 */
@@ -239,6 +249,46 @@ int ldsim_light_detector_response(ldsim_ctx* ctx, const float* light_sample_inc,
                                   const double* light_gain, const double* impulse_model, int32_t n_impulse,
                                   float* response, int64_t* response_true_track_id, double* response_true_photons);
 
+/* Second half of the light chain: Poisson fluctuations, triggers, detector noise, digitised waveforms.
+ * light_sim.calc_stat_fluctuations[bpg,tpb](light_sample_inc, light_sample_inc_disc, rng_states)
+ *                                                                         -- larndsim/light_sim.py:186-238
+ * Element (idet, itick) draws from state idet*n_ticks + itick of the ldsim_rng_seed table (advanced in place): one float32
+ * uniform for a mean below 30 PE per tick, one float32 normal above.  The generator is third-party and unpinned. */
+int ldsim_stat_fluctuations(ldsim_ctx* ctx, const float* light_sample_inc, int32_t n_det, int32_t n_ticks,
+                            float* light_sample_inc_disc);
+/* light_sim.get_triggers(signal, group_threshold, op_channel_idx, i_subbatch), LIGHT_TRIG_MODE 0 branch
+ *                                                                         -- larndsim/light_sim.py:339-411
+ * signal [n_det][n_ticks] f4 (NULL: the resident response of ldsim_dev_light_response), group_threshold [n_grp] with
+ * n_det = n_grp * OP_CHANNEL_PER_TRIG; row_module [n_det] = index (0..n_mod-1, ascending module id) of the module whose
+ * channels contain the row's optical channel, -1 for none.  Returns the trigger ticks module by module in the order the
+ * reference appends them, with the reference's bookkeeping of the re-sliced mask (:404-411).  LDSIM_ENOSPC with *n_trig =
+ * the number found when `capacity` is too small.  (LIGHT_TRIG_MODE 1 is one trigger at tick 0 and needs no call.) */
+int ldsim_light_triggers(ldsim_ctx* ctx, const float* signal, int32_t n_det, int32_t n_ticks, const double* group_threshold,
+                         int32_t n_grp, const int32_t* row_module, int32_t n_mod, int64_t* trigger_idx,
+                         int32_t* trigger_module, int64_t capacity, int64_t* n_trig);
+/* light_sim.gen_light_detector_noise(shape, light_det_noise)              -- larndsim/light_sim.py:445-478
+ * spectrum [n_rows][nbins] (the rows light_det_noise[...] selects), noise [n_rows][n_samples] f8.  phases [n_rows]
+ * [n_samples/2+1] = the uniform numbers of :465, or NULL to draw them from a counter hash seeded by ldsim_rng_seed (the
+ * reference draws them from cupy's global generator: unpinned by construction).  n_samples < 2 is refused (NaN there). */
+int ldsim_light_detector_noise(ldsim_ctx* ctx, int32_t n_rows, int32_t n_samples, const double* spectrum, int32_t nbins,
+                               const double* phases, double* noise);
+/* light_sim.sim_triggers(bpg, tpb, signal, signal_op_channel_idx, signal_true_track_id, signal_true_photons, trigger_idx,
+ *                        op_channel_idx, digit_samples, light_det_noise) incl. digitize_signal
+ *                                                                         -- larndsim/light_sim.py:480-619
+ * signal [n_det][n_ticks] f4 with truth [n_det][n_ticks][max_truth] (signal NULL: the resident response and its truth);
+ * trigger_op_channel_idx [n_trig][n_det_trig]; light_det_noise [n_noise_channels][n_noise_bins] indexed by optical channel
+ * (NULL or all zero: no noise).  phases_signal [n_det][Tp/2+1] / phases_missing [n_missing][Tp/2+1] (Tp = padded length)
+ * stand for the two cp.random.uniform calls, NULL = counter hash.  Outputs digit_signal [n_trig][n_det_trig][digit_samples]
+ * f8 (rounded to the digitiser's LSB), truth ids (i8, -1) / photons (f8) [..][max_truth].  The padded copies of the
+ * reference are not materialised; an f4 signal that needs no padding keeps its f4 rounding when the noise is added. */
+int ldsim_sim_triggers(ldsim_ctx* ctx, const float* signal, const int32_t* signal_op_channel_idx, int32_t n_det,
+                       int32_t n_ticks, const int64_t* signal_true_track_id, const double* signal_true_photons,
+                       int32_t max_truth, const int64_t* trigger_idx, int32_t n_trig,
+                       const int32_t* trigger_op_channel_idx, int32_t n_det_trig, int32_t digit_samples,
+                       const double* light_det_noise, int32_t n_noise_channels, int32_t n_noise_bins,
+                       const double* phases_signal, const double* phases_missing, double* digit_signal,
+                       int64_t* digit_true_track_id, double* digit_true_photons);
+
 /* ---- (2) device-resident chain ---------------------------------------------------------------------- */
 /* Upload `n` records (H2D) and unpack them into the ctx's SoA segment store.  `batch_id[i]` is the
  * reference's (event, TPC-group, sub-batch) batch of segment i (cli/simulate_pixels.py:864,902);
@@ -307,6 +357,17 @@ int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, cons
 int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* true_track_id, double* true_photons);
 /* HIP-event durations of the last ldsim_dev_light_incidence launch and the last ldsim_dev_sum_light call */
 int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms);
+/* calc_scintillation_effect -> calc_stat_fluctuations (fluctuate != 0; needs ldsim_rng_seed) -> calc_light_detector_response
+ * on the photon sum of the last ldsim_dev_sum_light, all in HBM (cli/simulate_pixels.py:1159-1180).  light_gain [n_det] by
+ * array row, impulse_model as in ldsim_light_detector_response.  ldsim_light_triggers / ldsim_sim_triggers with a NULL
+ * signal then work on the result. */
+int ldsim_dev_light_response(ldsim_ctx* ctx, const double* light_gain, const double* impulse_model, int32_t n_impulse,
+                             int32_t fluctuate);
+/* the three stages' arrays to host ([n_det][n_ticks] f4; truth of the response); any pointer may be NULL */
+int ldsim_dev_light_response_download(ldsim_ctx* ctx, float* scint, float* disc, float* response,
+                                      int64_t* response_true_track_id, double* response_true_photons);
+/* HIP-event durations of the three stages of the last ldsim_dev_light_response */
+int ldsim_light_response_ms(ldsim_ctx* ctx, double* scint_ms, double* fluct_ms, double* response_ms);
 
 /* ---- multi-GPU: the one exchange step of the batch-sharded path, RCCL over xGMI -------------------------------
  * One process per GPU; (event, TPC-group) batches are sharded over the ranks and never share a pixel, so the only

@@ -52,44 +52,52 @@ static void rng_jump_host(RngState& st) {
   st.s1 = s1;
 }
 
-// create_xoroshiro128p_states(n, seed) continued to `n` states: state 0 = SplitMix64(seed) in both words, state i = state
-// i-1 jumped 2^64 steps.  States [0, ctx->rng_n) keep whatever the kernels advanced them to; new ones are appended.
-int rng_ensure_states(ldsim_ctx* ctx, int64_t n) {
-  if (!ctx->rng_seeded) {
-    ldsim_set_error("noise charges are non-zero but no random state exists: call ldsim_rng_seed first");
-    return LDSIM_ESTATE;
-  }
+static uint64_t splitmix_first(uint64_t seed) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// Append states so that the table holds exactly `n`: a fresh create_xoroshiro128p_states(n - rng_n, seed) chain when
+// `fresh_seed` is given (maybe_create_rng_states, cli/simulate_pixels.py:92-104), else the continuation of the last chain
+// (state i = state i-1 jumped 2^64 steps).  States [0, rng_n) keep whatever the kernels advanced them to.  The allocation
+// grows geometrically, the logical length ctx->rng_n is exact.
+static int rng_append(ldsim_ctx* ctx, int64_t n, const uint64_t* fresh_seed) {
   if (n <= ctx->rng_n) return 0;
-  const int64_t cap = n + n / 4 + 1024;
-  std::vector<RngState> fresh((size_t)(cap - ctx->rng_n));
+  std::vector<RngState> fresh((size_t)(n - ctx->rng_n));
   RngState cur;
   cur.s0 = ctx->rng_last_init[0];
   cur.s1 = ctx->rng_last_init[1];
   for (size_t i = 0; i < fresh.size(); i++) {
-    if (ctx->rng_n == 0 && i == 0) {
-      uint64_t z = ctx->rng_seed + 0x9E3779B97F4A7C15ULL;
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-      z = z ^ (z >> 31);
-      cur.s0 = cur.s1 = z;
-    } else {
-      rng_jump_host(cur);
-    }
+    if (i == 0 && (fresh_seed || ctx->rng_n == 0)) cur.s0 = cur.s1 = splitmix_first(fresh_seed ? *fresh_seed : ctx->rng_seed);
+    else rng_jump_host(cur);
     fresh[i] = cur;
   }
-  DevBuf nb;
-  int rc = ldsim_ensure_buf(ctx, &nb, (size_t)cap * sizeof(RngState));
-  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (ctx->rng_n) HIPCHK(hipMemcpy(nb.p, ctx->d_rng.p, (size_t)ctx->rng_n * sizeof(RngState), hipMemcpyDeviceToDevice));
-  HIPCHK(hipMemcpy((char*)nb.p + (size_t)ctx->rng_n * sizeof(RngState), fresh.data(), fresh.size() * sizeof(RngState),
+  if ((size_t)n * sizeof(RngState) > ctx->d_rng.bytes) {
+    const int64_t cap = n + n / 4 + 1024;
+    DevBuf nb;
+    int rc = ldsim_ensure_buf(ctx, &nb, (size_t)cap * sizeof(RngState));
+    if (rc) return rc;
+    if (ctx->rng_n) HIPCHK(hipMemcpy(nb.p, ctx->d_rng.p, (size_t)ctx->rng_n * sizeof(RngState), hipMemcpyDeviceToDevice));
+    if (ctx->d_rng.p) (void)hipFree(ctx->d_rng.p);
+    ctx->d_rng = nb;
+  }
+  HIPCHK(hipMemcpy((char*)ctx->d_rng.p + (size_t)ctx->rng_n * sizeof(RngState), fresh.data(), fresh.size() * sizeof(RngState),
                    hipMemcpyHostToDevice));
-  if (ctx->d_rng.p) (void)hipFree(ctx->d_rng.p);
-  ctx->d_rng = nb;
-  ctx->rng_n = cap;
+  ctx->rng_n = n;
   ctx->rng_last_init[0] = cur.s0;
   ctx->rng_last_init[1] = cur.s1;
   return 0;
+}
+
+int rng_ensure_states(ldsim_ctx* ctx, int64_t n) {
+  if (!ctx->rng_seeded) {
+    ldsim_set_error("this stage draws random numbers but no random state exists: call ldsim_rng_seed first");
+    return LDSIM_ESTATE;
+  }
+  return rng_append(ctx, n, nullptr);
 }
 
 // upper bound of the normals one pixel's scan can consume (fee.py:557-655): the first reset draw, 2 per loop pass (every
@@ -129,9 +137,24 @@ extern "C" int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states) {
   ctx->rng_n = 0;
   ctx->rng_seed = seed;
   ctx->rng_seeded = 1;
+  ctx->light_noise_calls = 0;
   ctx->rng_last_init[0] = ctx->rng_last_init[1] = 0;
   return n_states ? rng_ensure_states(ctx, n_states) : 0;
 }
+
+// maybe_create_rng_states(n, seed, rng_states) (cli/simulate_pixels.py:92-104): no table yet -> create n states from `seed`;
+// a shorter table -> append create_xoroshiro128p_states(n - len, seed); long enough -> untouched
+extern "C" int ldsim_rng_extend(ldsim_ctx* ctx, int64_t n_states, uint64_t seed) {
+  if (!ctx || n_states < 0) {
+    ldsim_set_error("bad argument");
+    return LDSIM_EINVAL;
+  }
+  if (!ctx->rng_seeded) return ldsim_rng_seed(ctx, seed, n_states);
+  HIPCHK(hipSetDevice(ctx->device));
+  return rng_append(ctx, n_states, &seed);
+}
+
+extern "C" int64_t ldsim_rng_count(ldsim_ctx* ctx) { return ctx && ctx->rng_seeded ? ctx->rng_n : -1; }
 
 // forget the table: noisy calls are refused again until the next ldsim_rng_seed
 extern "C" int ldsim_rng_clear(ldsim_ctx* ctx) {

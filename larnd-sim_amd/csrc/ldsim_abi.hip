@@ -851,6 +851,7 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
   HIPCHK(hipEventElapsedTime(&ms, ctx->evl[2], ctx->evl[3]));
   ctx->ms_light_sum = ms;
   ctx->light_sum_ndet = n_det; ctx->light_sum_nticks = n_ticks; ctx->light_sum_truth = max_truth;
+  ctx->light_resp_valid = 0;
   return 0;
 }
 
@@ -984,6 +985,107 @@ extern "C" int ldsim_light_detector_response(ldsim_ctx* ctx, const float* light_
   for (int64_t n = 0; n <= C; n++) w[(size_t)n] = sipm_response_model(n, impulse_model, n_impulse, h);
   return light_response_stage(ctx, true, light_sample_inc, true_track_id, true_photons, n_det, n_ticks, max_truth, w,
                               light_gain, response, response_true_track_id, response_true_photons);
+}
+
+// light_sim.calc_scintillation_effect -> calc_stat_fluctuations -> calc_light_detector_response on the resident photon sum
+// (cli/simulate_pixels.py:1159-1180), everything staying in HBM
+int light_launch_stat_fluct(ldsim_ctx* ctx, const float* inc, float* out, int64_t n);      // light_wvfm.hip
+
+extern "C" int ldsim_dev_light_response(ldsim_ctx* ctx, const double* light_gain, const double* impulse_model,
+                                        int32_t n_impulse, int32_t fluctuate) {
+  NEED(ctx && light_gain, "bad argument");
+  NEED(ctx->light_sum_ndet > 0, "no resident photon sum (ldsim_dev_sum_light)");
+  const LdsimConsts& h = ctx->h_consts;
+  NEED(h.light_tick_size > 0 && h.tau_s > 0 && h.tau_t > 0, "light constants not set");
+  NEED(h.sipm_response_model == 0 || (h.sipm_response_model == 1 && impulse_model && n_impulse > 0 && h.impulse_tick_size > 0),
+       "SIPM_RESPONSE_MODEL 1 needs IMPULSE_MODEL and IMPULSE_TICK_SIZE");
+  const int64_t C = conv_ticks(h);
+  NEED(C >= 0 && C < (1 << 24), "LIGHT_WINDOW / LIGHT_TICK_SIZE out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int D = ctx->light_sum_ndet, T = ctx->light_sum_nticks, Mt = ctx->light_sum_truth;
+  const size_t bo = (size_t)D * T, bt = bo * (size_t)Mt;
+  ctx->light_resp_valid = 0;
+  std::vector<double> w0((size_t)C + 1), w1((size_t)C + 1);
+  for (int64_t n = 0; n <= C; n++) {
+    w0[(size_t)n] = scintillation_model(n, h);
+    w1[(size_t)n] = sipm_response_model(n, impulse_model, n_impulse, h);
+  }
+  hipStream_t st = ctx->stream;
+  CK(ldsim_ensure_buf(ctx, &ctx->light_w[0], w0.size() * 8));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_w[1], w1.size() * 8));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_gain, (size_t)D * 8));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_scint, bo * 4 + 16));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_disc, bo * 4 + 16));
+  CK(ldsim_ensure_buf(ctx, &ctx->light_resp, bo * 4 + 16));
+  HIPCHK(hipMemcpyAsync(ctx->light_w[0].p, w0.data(), w0.size() * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->light_w[1].p, w1.data(), w1.size() * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->light_gain.p, light_gain, (size_t)D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->light_scint.p, 0, bo * 4, st));
+  HIPCHK(hipMemsetAsync(ctx->light_resp.p, 0, bo * 4, st));
+  if (Mt) {
+    CK(ldsim_ensure_buf(ctx, &ctx->light_scint_tid, bt * 8 + 16));
+    CK(ldsim_ensure_buf(ctx, &ctx->light_scint_tph, bt * 8 + 16));
+    CK(ldsim_ensure_buf(ctx, &ctx->light_resp_tid, bt * 8 + 16));
+    CK(ldsim_ensure_buf(ctx, &ctx->light_resp_tph, bt * 8 + 16));
+    HIPCHK(hipMemsetAsync(ctx->light_scint_tid.p, 0xFF, bt * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->light_scint_tph.p, 0, bt * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->light_resp_tid.p, 0xFF, bt * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->light_resp_tph.p, 0, bt * 8, st));
+  }
+  if (bo == 0) {
+    ctx->light_resp_valid = 1;
+    return 0;
+  }
+  hipEvent_t ev[4];
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipEventRecord(ev[0], st));
+  CK(light_response_launch(ctx, false, (const float*)ctx->light_out.p, (const int64_t*)ctx->light_tid.p,
+                           (const double*)ctx->light_tph.p, D, T, Mt, (const double*)ctx->light_w[0].p, (int)C, nullptr,
+                           (float*)ctx->light_scint.p, (int64_t*)ctx->light_scint_tid.p, (double*)ctx->light_scint_tph.p));
+  HIPCHK(hipEventRecord(ev[1], st));
+  const float* disc = (const float*)ctx->light_scint.p;
+  if (fluctuate) {
+    CK(light_launch_stat_fluct(ctx, (const float*)ctx->light_scint.p, (float*)ctx->light_disc.p, (int64_t)bo));
+    disc = (const float*)ctx->light_disc.p;
+  }
+  HIPCHK(hipEventRecord(ev[2], st));
+  CK(light_response_launch(ctx, true, disc, (const int64_t*)ctx->light_scint_tid.p, (const double*)ctx->light_scint_tph.p, D,
+                           T, Mt, (const double*)ctx->light_w[1].p, (int)C, (const double*)ctx->light_gain.p,
+                           (float*)ctx->light_resp.p, (int64_t*)ctx->light_resp_tid.p, (double*)ctx->light_resp_tph.p));
+  HIPCHK(hipEventRecord(ev[3], st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < 3; i++) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    ctx->ms_light_resp[i] = ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  ctx->light_resp_valid = 1;
+  return 0;
+}
+
+extern "C" int ldsim_dev_light_response_download(ldsim_ctx* ctx, float* scint, float* disc, float* response,
+                                                 int64_t* response_true_track_id, double* response_true_photons) {
+  NEED(ctx, "null ctx");
+  NEED(ctx->light_resp_valid, "no resident detector response (ldsim_dev_light_response)");
+  const size_t bo = (size_t)ctx->light_sum_ndet * ctx->light_sum_nticks, bt = bo * (size_t)ctx->light_sum_truth;
+  if (bo == 0) return 0;
+  hipStream_t st = ctx->stream;
+  if (scint) HIPCHK(hipMemcpyAsync(scint, ctx->light_scint.p, bo * 4, hipMemcpyDeviceToHost, st));
+  if (disc) HIPCHK(hipMemcpyAsync(disc, ctx->light_disc.p, bo * 4, hipMemcpyDeviceToHost, st));
+  if (response) HIPCHK(hipMemcpyAsync(response, ctx->light_resp.p, bo * 4, hipMemcpyDeviceToHost, st));
+  if (bt && response_true_track_id) HIPCHK(hipMemcpyAsync(response_true_track_id, ctx->light_resp_tid.p, bt * 8, hipMemcpyDeviceToHost, st));
+  if (bt && response_true_photons) HIPCHK(hipMemcpyAsync(response_true_photons, ctx->light_resp_tph.p, bt * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int ldsim_light_response_ms(ldsim_ctx* ctx, double* scint_ms, double* fluct_ms, double* response_ms) {
+  NEED(ctx, "null ctx");
+  if (scint_ms) *scint_ms = ctx->ms_light_resp[0];
+  if (fluct_ms) *fluct_ms = ctx->ms_light_resp[1];
+  if (response_ms) *response_ms = ctx->ms_light_resp[2];
+  return 0;
 }
 
 // ---- (2) chain -------------------------------------------------------------------------------------------------------

@@ -133,6 +133,13 @@ struct ldsim_ctx {
   DevBuf light_out, light_tid, light_tph, light_opc, light_trk;   // last photon sum: [n_det][n_ticks] f32, truth ids / photons
   int32_t light_sum_ndet = 0, light_sum_nticks = 0, light_sum_truth = 0;
   DevBuf light_tmp[9];
+  // resident waveform stages on the last photon sum (ldsim_dev_light_response): scintillation profile (+ truth), Poisson
+  // fluctuated rate, detector response (+ truth), all [light_sum_ndet][light_sum_nticks]
+  DevBuf light_scint, light_scint_tid, light_scint_tph, light_disc, light_resp, light_resp_tid, light_resp_tph, light_w[2],
+      light_gain;
+  int light_resp_valid = 0;
+  uint64_t light_noise_calls = 0;
+  double ms_light_resp[3] = {0, 0, 0};
   double ms_light_inc = 0, ms_light_sum = 0;
   hipEvent_t evl[4] = {nullptr, nullptr, nullptr, nullptr};
   // random streams (kernels_rng.hip): numba-style table of xoroshiro128p states, grown on demand

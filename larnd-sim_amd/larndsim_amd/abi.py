@@ -43,6 +43,8 @@ class LdsimConsts(C.Structure):
         ("light_response_time", C.c_double), ("light_oscillation_period", C.c_double),
         ("impulse_tick_size", C.c_double), ("sipm_response_model", C.c_int32), ("mc_sample_multiplier", C.c_int32),
         ("min_step_size", C.c_double),
+        ("light_trig_window", C.c_double * 2), ("light_digit_sample_spacing", C.c_double),
+        ("light_det_noise_sample_spacing", C.c_double), ("light_nbit", C.c_int32), ("op_channel_per_trig", C.c_int32),
     ]
 
 
@@ -53,7 +55,7 @@ class LdsimChainStats(C.Structure):
                 ("n_ambiguous", C.c_int32), ("n_dfma", C.c_int64), ("n_fallback", C.c_int64), ("n_samples", C.c_int64), ("n_wbuf", C.c_int64)]
 
 
-ABI_VERSION = 3      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
+ABI_VERSION = 4      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):
@@ -97,4 +99,8 @@ def pack_consts(noise_zero=False):
     c.light_response_time, c.light_oscillation_period = l.LIGHT_RESPONSE_TIME, l.LIGHT_OSCILLATION_PERIOD
     c.impulse_tick_size, c.sipm_response_model = l.IMPULSE_TICK_SIZE, int(l.SIPM_RESPONSE_MODEL)
     c.mc_sample_multiplier, c.min_step_size = int(s.MC_SAMPLE_MULTIPLIER), float(s.MIN_STEP_SIZE)
+    c.light_trig_window[0], c.light_trig_window[1] = float(l.LIGHT_TRIG_WINDOW[0]), float(l.LIGHT_TRIG_WINDOW[1])
+    c.light_digit_sample_spacing = float(l.LIGHT_DIGIT_SAMPLE_SPACING)
+    c.light_det_noise_sample_spacing = float(l.LIGHT_DET_NOISE_SAMPLE_SPACING)
+    c.light_nbit, c.op_channel_per_trig = int(l.LIGHT_NBIT), int(l.OP_CHANNEL_PER_TRIG)
     return c

@@ -186,7 +186,42 @@ class ChargeChain:
                                                  C.c_int32(opc.shape[0]), lib.ptr(tid), C.c_int32(int(mt)),
                                                  C.c_double(float(t_start)), C.c_int32(int(n_ticks))))
         self._light_shape = (opc.shape[0], int(n_ticks), int(mt))
+        lib.set_light_shape(self._light_shape)
         return n_ticks, t_start
+
+    def light_response(self, fluctuate=True):
+        """``calc_scintillation_effect`` -> ``calc_stat_fluctuations`` (if ``fluctuate``; needs ``seed_rng``) ->
+        ``calc_light_detector_response`` on the photon sum of the last ``sum_light``, in HBM
+        (cli/simulate_pixels.py:1159-1180).  ``light_sim.get_triggers(None, ...)`` / ``light_sim.sim_triggers(.., None, ..)``
+        then work on the resident result; ``download_light_response`` fetches it."""
+        self._check_constants()
+        light = consts.light
+        nd = self._light_shape[0]
+        gain = np.ascontiguousarray(light.LIGHT_GAIN, dtype=np.float64)
+        if gain.shape[0] < nd:
+            raise IndexError(f"LIGHT_GAIN has {gain.shape[0]} entries, the photon sum has {nd} rows")
+        imp = np.ascontiguousarray(light.IMPULSE_MODEL, dtype=np.float64)
+        lib.check(lib.load().ldsim_dev_light_response(self.ctx, lib.ptr(gain), lib.ptr(imp), C.c_int32(imp.shape[0]),
+                                                      C.c_int32(int(bool(fluctuate)))))
+
+    def download_light_response(self, stages=False, truth=True):
+        """response f4 [n_det][n_ticks] (+ true ids i8, true photons f8); with ``stages`` also the scintillation and the
+        fluctuated arrays: (scint, disc, response, ids, photons)."""
+        nd, nt, mt = self._light_shape
+        resp = np.zeros((nd, nt), dtype=np.float32)
+        sc = np.zeros((nd, nt), dtype=np.float32) if stages else None
+        di = np.zeros((nd, nt), dtype=np.float32) if stages else None
+        tid = np.full((nd, nt, mt), -1, dtype=np.int64)
+        tph = np.zeros((nd, nt, mt))
+        lib.check(lib.load().ldsim_dev_light_response_download(
+            self.ctx, lib.ptr(sc), lib.ptr(di), lib.ptr(resp), lib.ptr(tid) if (mt and truth) else None,
+            lib.ptr(tph) if (mt and truth) else None))
+        return (sc, di, resp, tid, tph) if stages else (resp, tid, tph)
+
+    def light_response_ms(self):
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        lib.check(lib.load().ldsim_light_response_ms(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return {"scintillation": a.value, "fluctuations": b.value, "detector_response": c.value}
 
     def download_light(self, truth=True):
         """(light_sample_inc f4 [n_det][n_ticks], true_track_id i8 [..][max_truth], true_photons f8 [..][max_truth])."""

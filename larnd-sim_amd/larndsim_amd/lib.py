@@ -36,7 +36,9 @@ EXPORTS = [
     "ldsim_chain_download", "ldsim_chain_compact_hits", "ldsim_chain_kernel_ms", "ldsim_chain_kernel_ms_detail",
     "ldsim_dev_light_incidence", "ldsim_dev_light_incidence_download", "ldsim_dev_light_t0_range", "ldsim_dev_sum_light",
     "ldsim_dev_light_download", "ldsim_light_kernel_ms",
-    "ldsim_rng_seed", "ldsim_rng_states_download", "ldsim_rng_clear",
+    "ldsim_rng_seed", "ldsim_rng_states_download", "ldsim_rng_clear", "ldsim_rng_extend", "ldsim_rng_count",
+    "ldsim_stat_fluctuations", "ldsim_light_triggers", "ldsim_light_detector_noise", "ldsim_sim_triggers",
+    "ldsim_dev_light_response", "ldsim_dev_light_response_download", "ldsim_light_response_ms",
     "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
     "ldsim_comm_allgather_hits", "ldsim_comm_gathered_download",
 ]
@@ -62,6 +64,21 @@ def load():
 
 def device_count():
     return int(load().ldsim_device_count())
+
+
+LDSIM_ENOSPC = -3
+
+_light_shape = (0, 0, 0)
+
+
+def set_light_shape(shape):
+    """(n_det, n_ticks, max_truth) of the device-resident photon sum (ChargeChain.sum_light)."""
+    global _light_shape
+    _light_shape = tuple(int(v) for v in shape)
+
+
+def context_light_shape():
+    return _light_shape
 
 
 def check(rc):

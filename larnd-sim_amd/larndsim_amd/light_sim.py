@@ -1,7 +1,10 @@
 """Light waveforms per (optical channel, tick) -- mirrors larndsim/light_sim.py: get_nticks (:24-41), sum_light_signals
-(:58-129), calc_scintillation_effect (:148-184) and calc_light_detector_response (:303-337).  The stages that draw random
-numbers (calc_stat_fluctuations, detector noise) and the trigger / digitisation stages are out of scope."""
+(:58-129), calc_scintillation_effect (:148-184), calc_stat_fluctuations (:186-238), calc_light_detector_response (:303-337),
+get_triggers (:339-443), gen_light_detector_noise (:445-478), sim_triggers incl. digitize_signal (:480-619) and the
+light_trig / light_wvfm / light_wvfm_mc_assn writers (:621-757).  Random numbers: the numba-style state table for the Poisson
+stage, a counter hash for the noise phases (the reference uses cupy's global generator there); both unpinned."""
 import ctypes as C
+from math import ceil
 
 import numpy as np
 
@@ -103,3 +106,132 @@ def calc_light_detector_response(light_sample_inc, light_sample_inc_true_track_i
         light_response_true_track_id[:] = otid
         light_response_true_photons[:] = otph
 
+
+
+@kernel
+def calc_stat_fluctuations(light_sample_inc, light_sample_inc_disc, rng_states):
+    """``calc_stat_fluctuations[bpg, tpb](light_sample_inc, light_sample_inc_disc, rng_states)``: Poisson fluctuations of the
+    PE count per tick.  ``rng_states`` is the handle of ``rng.create_xoroshiro128p_states`` (the table lives on the device);
+    element ``(idet, itick)`` uses state ``idet*ntick + itick``."""
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    n_det, n_ticks = inc.shape
+    if rng_states is None or len(rng_states) < inc.size:
+        raise IndexError(f"rng_states holds {0 if rng_states is None else len(rng_states)} states, {inc.size} are indexed")
+    out = np.zeros(inc.shape, dtype=np.float32)
+    lib.check(lib.load().ldsim_stat_fluctuations(lib.context(), lib.ptr(inc), C.c_int32(n_det), C.c_int32(n_ticks),
+                                                 lib.ptr(out)))
+    light_sample_inc_disc[:] = out
+
+
+def _module_rows(op_channel_idx):
+    """(sorted module ids, row -> module index, module -> its optical channels) like light_sim.py:374-384."""
+    light, detector = consts.light, consts.detector
+    op_channel_idx = np.asarray(op_channel_idx)
+    tpc_ids = np.unique(light.OP_CHANNEL_TO_TPC[op_channel_idx])
+    mod_ids = np.unique([detector.TPC_TO_MODULE[int(t)] for t in tpc_ids])
+    row_module = np.full(op_channel_idx.shape[0], -1, dtype=np.int32)
+    channels = []
+    for im, mod in enumerate(mod_ids):
+        ch = light.TPC_TO_OP_CHANNEL[detector.MODULE_TO_TPCS[mod]].ravel()
+        channels.append(ch)
+        row_module[np.isin(op_channel_idx, ch)] = im
+    return mod_ids, row_module, channels
+
+
+def get_triggers(signal, group_threshold, op_channel_idx, i_subbatch):
+    """Ticks that start a trigger: ``(trigger_idx, op_channel_idx per trigger, trigger_type)``.  ``signal`` is the detector
+    response ``[ndet, nticks]``, or ``None`` for the device-resident one of ``chain.light_response``."""
+    light = consts.light
+    op_channel_idx = np.asarray(op_channel_idx)
+    trig, chans, types = [], [], []
+    if light.LIGHT_TRIG_MODE == 0:
+        _, row_module, channels = _module_rows(op_channel_idx)
+        thr = np.ascontiguousarray(group_threshold, dtype=np.float64)
+        n_det = op_channel_idx.shape[0]
+        if signal is not None:
+            signal = np.ascontiguousarray(signal, dtype=np.float32)
+            if signal.shape[0] != n_det:
+                raise ValueError("signal rows and op_channel_idx differ")
+            n_ticks = signal.shape[1]
+        else:
+            n_ticks = lib.context_light_shape()[1]
+        cap = max(16, n_ticks // max(1, _digit_ticks()) * len(channels) + len(channels))
+        while True:
+            idx = np.zeros(cap, dtype=np.int64); mod = np.zeros(cap, dtype=np.int32); n = C.c_int64(0)
+            rc = lib.load().ldsim_light_triggers(
+                lib.context(), lib.ptr(signal), C.c_int32(n_det), C.c_int32(n_ticks), lib.ptr(thr), C.c_int32(thr.shape[0]),
+                lib.ptr(row_module), C.c_int32(len(channels)), lib.ptr(idx), lib.ptr(mod), C.c_int64(cap), C.byref(n))
+            if rc == lib.LDSIM_ENOSPC:
+                cap = int(n.value)
+                continue
+            lib.check(rc)
+            break
+        for i in range(int(n.value)):
+            trig.append(int(idx[i])); types.append(0); chans.append(channels[int(mod[i])])
+    elif light.LIGHT_TRIG_MODE == 1 and i_subbatch == 0:
+        trig.append(0); chans.append(op_channel_idx); types.append(1)
+    if trig:
+        return np.array(trig), np.array(chans), np.array(types)
+    return np.empty((0,), dtype=int), np.empty((0, len(op_channel_idx)), dtype=int), np.empty((0,), dtype=int)
+
+
+def _digit_ticks():
+    light = consts.light
+    return ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_TICK_SIZE)
+
+
+def gen_light_detector_noise(shape, light_det_noise, phases=None):
+    """Uncorrelated noise with the frequency spectrum ``light_det_noise`` (one row per output row): ``[shape[0], shape[1]]``
+    f8 in digitiser LSBs.  ``phases`` (``[shape[0], shape[1]//2 + 1]`` uniform numbers) replaces the internal draw."""
+    shape = (int(shape[0]), int(shape[1]))
+    if not shape[0]:
+        return np.empty(shape)
+    spec = np.ascontiguousarray(light_det_noise, dtype=np.float64)
+    if spec.ndim != 2 or spec.shape[0] != shape[0]:
+        raise ValueError("shape[0] must equal light_det_noise.shape[0]")
+    ph = None if phases is None else np.ascontiguousarray(phases, dtype=np.float64)
+    if ph is not None and ph.shape != (shape[0], shape[1] // 2 + 1):
+        raise ValueError("phases must be [shape[0], shape[1]//2 + 1]")
+    out = np.zeros(shape)
+    lib.check(lib.load().ldsim_light_detector_noise(lib.context(), C.c_int32(shape[0]), C.c_int32(shape[1]), lib.ptr(spec),
+                                                    C.c_int32(spec.shape[1]), lib.ptr(ph), lib.ptr(out)))
+    return out
+
+
+def sim_triggers(bpg, tpb, signal, signal_op_channel_idx, signal_true_track_id, signal_true_photons, trigger_idx,
+                 op_channel_idx, digit_samples, light_det_noise, phases_signal=None, phases_missing=None):
+    """Digitised waveforms at the trigger ticks, reference argument order (``bpg``/``tpb`` are accepted and unused):
+    ``(digit_signal [ntrigs, ndet_module, digit_samples] f8, true track ids, true photons)``.  ``signal=None`` digitises the
+    device-resident response of ``chain.light_response`` (its truth arrays stay on the device too)."""
+    trigger_idx = np.ascontiguousarray(trigger_idx, dtype=np.int64)
+    top = np.ascontiguousarray(op_channel_idx, dtype=np.int32)
+    ntrig = trigger_idx.shape[0]
+    ndm = top.shape[-1] if top.ndim else 0
+    if top.ndim == 1:
+        top = np.ascontiguousarray(np.broadcast_to(top, (ntrig, ndm)))
+    sop = np.ascontiguousarray(signal_op_channel_idx, dtype=np.int32)
+    if signal is not None:
+        sig = np.ascontiguousarray(signal, dtype=np.float32)
+        n_det, n_ticks = sig.shape
+        mt, tid, tph = _truth(signal_true_track_id, signal_true_photons)
+        id_dtype = signal_true_track_id.dtype if mt else np.int64
+        ph_dtype = signal_true_photons.dtype if mt else np.float64
+    else:
+        sig, tid, tph = None, None, None
+        n_det, n_ticks, mt = lib.context_light_shape()
+        id_dtype, ph_dtype = np.int64, np.float64
+    digit = np.zeros((ntrig, ndm, int(digit_samples)), dtype='f8')
+    dtid = np.full((ntrig, ndm, int(digit_samples), mt), -1, dtype=np.int64)
+    dtph = np.zeros((ntrig, ndm, int(digit_samples), mt), dtype=np.float64)
+    if ntrig == 0:
+        return digit, dtid.astype(id_dtype), dtph.astype(ph_dtype)
+    noise = None if light_det_noise is None else np.ascontiguousarray(light_det_noise, dtype=np.float64)
+    ps = None if phases_signal is None else np.ascontiguousarray(phases_signal, dtype=np.float64)
+    pm = None if phases_missing is None else np.ascontiguousarray(phases_missing, dtype=np.float64)
+    lib.check(lib.load().ldsim_sim_triggers(
+        lib.context(), lib.ptr(sig), lib.ptr(sop), C.c_int32(n_det), C.c_int32(n_ticks), lib.ptr(tid), lib.ptr(tph),
+        C.c_int32(mt), lib.ptr(trigger_idx), C.c_int32(ntrig), lib.ptr(top), C.c_int32(ndm), C.c_int32(int(digit_samples)),
+        lib.ptr(noise), C.c_int32(noise.shape[0] if noise is not None else 0),
+        C.c_int32(noise.shape[1] if noise is not None else 0), lib.ptr(ps), lib.ptr(pm), lib.ptr(digit),
+        lib.ptr(dtid) if mt else None, lib.ptr(dtph) if mt else None))
+    return digit, dtid.astype(id_dtype, copy=False), dtph.astype(ph_dtype, copy=False)

@@ -32,3 +32,14 @@ class RngStates:
 
 def create_xoroshiro128p_states(n, seed=0, ctx=None):
     return RngStates(n, seed, ctx)
+
+
+def maybe_create_rng_states(n, seed=0, rng_states=None, ctx=None):
+    """cli/simulate_pixels.py:92-104: create the table, or extend a shorter one with a fresh
+    ``create_xoroshiro128p_states(n - len, seed)`` chain; a long enough table is returned untouched."""
+    if rng_states is None:
+        return RngStates(n, seed, ctx)
+    if int(n) > len(rng_states):
+        lib.check(lib.load().ldsim_rng_extend(rng_states.ctx, C.c_int64(int(n)), C.c_uint64(int(seed) & (2 ** 64 - 1))))
+        rng_states.n = int(n)
+    return rng_states

@@ -588,6 +588,153 @@ def gen_light_response():
               "truth slots used", int((s_tid >= 0).sum()), int((r_tid >= 0).sum()))
 
 
+def det_phases(shape, seed):
+    """Deterministic stand-in for cp.random.uniform(size=shape): a multiplicative hash of (row, column, seed) in [0, 1).
+    tests/helpers.py holds the same formula."""
+    shape = tuple(int(v) for v in np.atleast_1d(shape))
+    i, k = np.meshgrid(np.arange(shape[0], dtype=np.uint64), np.arange(shape[1], dtype=np.uint64), indexing='ij')
+    h = (i * np.uint64(7919) + k * np.uint64(104729) + np.uint64(seed)) * np.uint64(2654435761)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    return h.astype(np.float64) / 4294967296.0
+
+
+class _GA(np.ndarray):
+    """ndarray with cupy's .get()"""
+    def get(self):
+        return np.asarray(self)
+
+
+def _ga(a):
+    return np.asarray(a).view(_GA)
+
+
+def gen_light_wvfm():
+    """The second half of the light chain on small arrays: calc_stat_fluctuations (light_sim.py:186-238) with the restated
+    xoroshiro128p generator supplied as numba.cuda.random (the generator itself is third-party and unpinned; this pins the
+    Poisson logic around it), get_triggers (:339-443), gen_light_detector_noise (:445-478) with the uniform phases recorded,
+    sim_triggers + digitize_signal (:480-619).  LIGHT_TRIG_WINDOW is shortened where the pure-Python grid walk of
+    digitize_signal would otherwise take hours; the functions read it at call time."""
+    import ctypes as C
+    try:
+        from oracle import oracle as O
+    except ImportError:
+        import oracle as O
+    ol = O.lib()
+    ol.o_rng_uniform_f32.restype = C.c_float
+    ol.o_rng_normal_f32.restype = C.c_float
+
+    def rng_fn(name):
+        f = getattr(ol, name)
+        return lambda states, i: float(f(C.c_void_p(states.ctypes.data + int(i) * states.dtype.itemsize)))
+
+    cases = (("module0", 71, dict()),
+             ("2x2_no_modvar", 72, dict(LIGHT_TRIG_MODE=0, LIGHT_TRIG_WINDOW=(0.2, 0.6))),
+             ("2x2_no_modvar", 73, dict(LIGHT_TRIG_WINDOW=(0.1, 0.7))))
+    for icase, (cfg, seed, over) in enumerate(cases):
+        ref = Ref(cfg)
+        light, sim, ls = ref.light, ref.sim, ref.light_sim
+        crandom = sys.modules["numba.cuda.random"]
+        crandom.xoroshiro128p_uniform_float32 = rng_fn("o_rng_uniform_f32")
+        crandom.xoroshiro128p_normal_float32 = rng_fn("o_rng_normal_f32")
+        for k, v in over.items():
+            setattr(light, k, v)
+        rng = np.random.default_rng(seed)
+        out = dict(light_trig_mode=light.LIGHT_TRIG_MODE, light_trig_window=np.array(light.LIGHT_TRIG_WINDOW),
+                   mc_truth_threshold=sim.MC_TRUTH_THRESHOLD)
+
+        # -- calc_stat_fluctuations: means on both sides of 30, zeros, a negative value
+        D0, T0 = 5, 700
+        inc = np.zeros((D0, T0), dtype='f4')
+        on = rng.random((D0, T0)) < 0.6
+        inc[on] = (10 ** rng.uniform(1.0, 5.3, on.sum())).astype('f4')         # PE/us: mean per tick 0.01 .. 200
+        inc[0, :5] = (-3.0, 0.0, 29999.0, 30000.0, 30001.0)
+        states = O.rng_create_states(D0 * T0, 4242 + icase)
+        out["fluct_states_before"] = states.copy().view('u8').reshape(-1, 2)
+        disc = np.zeros((D0, T0), dtype='f4')
+        ls.calc_stat_fluctuations[(D0, -(-T0 // 64)), (1, 64)](inc.astype('f8'), disc, states)
+        out.update(fluct_inc=inc, fluct_disc=disc, fluct_states_after=states.view('u8').reshape(-1, 2))
+
+        # -- a detector response with pulses: get_triggers
+        op_channel = light.TPC_TO_OP_CHANNEL[:].ravel()
+        nd = op_channel.shape[0]
+        digit_ticks = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_TICK_SIZE))
+        T = 3 * digit_ticks + 1777
+        Mt = 2
+        resp = np.zeros((nd, T), dtype='f4')        # quiet background except in the pulsed groups: keeps the fixture small
+        tid = np.full((nd, T, Mt), -1, dtype='i8'); tph = np.zeros((nd, T, Mt))
+        per = light.OP_CHANNEL_PER_TRIG
+        thr = np.repeat(np.asarray(light.LIGHT_TRIG_THRESHOLD)[..., None], per, axis=-1).ravel()[op_channel].copy()
+        thr = thr.reshape(-1, per)[..., 0]
+        groups = rng.choice(nd // per, size=min(6, nd // per), replace=False)
+        pulse_at = [137, 137 + digit_ticks + 55, 2 * digit_ticks + 600, 3 * digit_ticks + 1200]
+        for g in groups:
+            if thr[g] < -1e6:
+                continue
+            resp[g * per:(g + 1) * per] = rng.normal(0, 2.0, (per, T)).astype('f4')
+            for t0 in pulse_at[:int(rng.integers(2, 5))]:
+                t0 = t0 + int(rng.integers(0, 40))
+                w = int(rng.integers(25, 90))
+                amp = thr[g] / per * rng.uniform(1.2, 3.0)
+                rows = slice(g * per, (g + 1) * per)
+                shape = np.exp(-np.arange(w) / (w / 3.0))
+                resp[rows, t0:t0 + w] += (amp * shape).astype('f4')
+                for r in range(g * per, (g + 1) * per):
+                    for t in range(t0, min(t0 + w, T)):
+                        tid[r, t, 0] = 1000 + g
+                        tph[r, t, 0] = -float(resp[r, t]) * 0.7
+                        if (t + r) % 3 == 0:
+                            tid[r, t, 1] = 2000 + g
+                            tph[r, t, 1] = -float(resp[r, t]) * 0.3 if t % 5 else 1e-9
+        trig, trig_op, trig_type = ls.get_triggers(resp, thr, _ga(op_channel), 0)
+        trig2 = ls.get_triggers(resp, thr, _ga(op_channel), 1)
+        out.update(response=resp, response_true_id=tid.astype('i4'), response_true_photons=tph, group_threshold=thr,
+                   op_channel=op_channel.astype('i4'), trigger_idx=np.asarray(trig), trigger_op_channel_idx=np.asarray(trig_op),
+                   trigger_type=np.asarray(trig_type), n_trig_subbatch1=len(trig2[0]))
+        print("light_wvfm", cfg, over, "triggers", np.asarray(trig).tolist(), "types", np.asarray(trig_type).tolist())
+
+        # -- gen_light_detector_noise with recorded phases
+        nbins = 257
+        noise_tab = np.abs(rng.normal(0, 1.0, (light.N_OP_CHANNEL, nbins))) * np.linspace(6000.0, 400.0, nbins)
+        rec = []
+
+        def uniform(size=None):
+            u = det_phases(size, 100 * seed + len(rec))      # a formula, so the fixture need not store them
+            rec.append(u)
+            return u
+        sys.modules["cupy"].random = types.SimpleNamespace(uniform=uniform)
+        for shp in ((4, 1500), (3, 1501)):        # shape[1] < 2 divides by an empty mean in the reference (NaN)
+            nz = ls.gen_light_detector_noise(shp, noise_tab[:shp[0]])
+            out[f"noise_{shp[1]}"] = nz
+            out[f"noise_{shp[1]}_phase_seed"] = 100 * seed + len(rec) - 1
+        out["noise_spectrum"] = noise_tab
+
+        # -- sim_triggers: zero spectrum (deterministic), then a real one with recorded phases
+        digit_samples = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING))
+        if len(trig) == 0:
+            raise RuntimeError("no trigger in the golden case")
+        for tag, tab in (("quiet", np.zeros_like(noise_tab)), ("noisy", noise_tab)):
+            del rec[:]
+            # drop a few rows of the signal so that sim_triggers has to add "missing" channels
+            keep = np.ones(nd, bool)
+            keep[[1, nd // 2, nd - 1]] = False
+            args = [a[keep] for a in (resp, op_channel, tid, tph)]
+            dsig, dtid, dtph = ls.sim_triggers(
+                (max(len(trig), 1), max(np.asarray(trig_op).shape[1], 1), -(-digit_samples // 64)), (1, 1, 64),
+                args[0].copy(), _ga(args[1]), args[2].copy(), args[3].copy(), np.asarray(trig), np.asarray(trig_op),
+                digit_samples, tab)
+            out[f"wvfm_{tag}"] = dsig
+            if tag == "quiet":
+                out["wvfm_true_id"] = dtid.astype('i4'); out["wvfm_true_photons"] = dtph
+            else:
+                out["wvfm_noisy_phase_seeds"] = np.array([100 * seed + i for i in range(len(rec))])
+            print("  sim_triggers", tag, dsig.shape, "nonzero", int((dsig != 0).sum()), "truth", int((dtid >= 0).sum()),
+                  "noise calls", len(rec))
+        out["wvfm_keep_rows"] = keep
+        out["digit_samples"] = digit_samples
+        np.savez_compressed(os.path.join(GOLD, f"light_wvfm_{cfg}_{icase}.npz"), **out)
+
+
 def gen_packets():
     """fee.export_to_hdf5 (fee.py:84-356) on the golden chain's ADC arrays, replicated over events.  larpix-control is a
     third-party package that is not installed: its packet classes are replaced by attribute bags that record what the
@@ -731,7 +878,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for s in a.sets.split(","):
         {"consts": gen_consts, "qd": gen_qd, "pixels": gen_pixels, "light": gen_light, "light_response": gen_light_response,
-         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs), "packets": gen_packets}[s]()
+         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs), "packets": gen_packets, "light_wvfm": gen_light_wvfm}[s]()
     return 0
 
 

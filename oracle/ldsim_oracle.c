@@ -954,3 +954,102 @@ int o_light_detector_response(const float* inc, const int64_t* tid, const double
   return 0;
 }
 
+
+/* ---- light: Poisson fluctuations and waveform digitisation (second half) ------------------------------ */
+/* light_sim.xoroshiro128p_poisson_int32 (:186-216): inversion below a mean of 30 (one float32 uniform), else a truncated
+ * normal (one float32 normal = two uniforms).  The generator is the restated third-party one above (unpinned). */
+int32_t o_poisson_int32(double mean, ORng* st) {
+  if (mean <= 0) return 0;
+  if (mean < 30) {
+    double u = (double)o_rng_uniform_f32(st);
+    int32_t x = 0;
+    double p = exp(-mean), s = p, prev_s = s;
+    while (u > s) {
+      x += 1;
+      p = p * mean / x;
+      prev_s = s;
+      s = s + p;
+      if (s == prev_s) break;
+    }
+    return x;
+  }
+  double v = (double)o_rng_normal_f32(st) * sqrt(mean) + mean;
+  int64_t iv = (int64_t)v;                    /* int(): truncation toward zero */
+  return iv > 0 ? (int32_t)iv : 0;
+}
+
+/* light_sim.calc_stat_fluctuations (:219-238): element e = idet*ntick + itick uses states[e]; the f4 input times the f64
+ * tick size is f64 under Numba; the result is stored into the f4 output array. */
+int o_stat_fluctuations(const float* inc, int64_t n, ORng* states, float* out, const LdsimConsts* c) {
+  for (int64_t e = 0; e < n; e++) {
+    if (inc[e] > 0)
+      out[e] = (float)(1. / c->light_tick_size * (double)o_poisson_int32((double)inc[e] * c->light_tick_size, &states[e]));
+    else
+      out[e] = 0.f;
+  }
+  return 0;
+}
+
+/* light_sim.interp (:241-271) */
+static double o_interp2(double idx, const double* arr, int64_t len, double low, double high, int f32diff) {
+  int64_t i0 = (int64_t)floor(idx);
+  if (i0 < 0) return low;
+  if (i0 > len - 1) return high;
+  if ((double)i0 == idx) return arr[i0];
+  if (i0 > len - 2) return high;
+  double d = f32diff ? (double)((float)arr[i0 + 1] - (float)arr[i0]) : arr[i0 + 1] - arr[i0];
+  return arr[i0] + d * (idx - (double)i0);
+}
+
+/* light_sim.digitize_signal (:480-543).  signal [R][Tp] (f64 holding the values of the padded array; sig_is_f4 says the
+ * reference's array was still f4 at that point, which only matters for Numba's f4 - f4 typing), signal_op [R],
+ * trig_op [ntrig][ndm], truth [R][Tp][Mt]; outputs digit [ntrig][ndm][ns] (zero on entry), dtid (-1), dtph (0) [..][Mt].
+ * Literal, including the row index `idet` (the optical channel id, not idet_signal) of the photons0 read (:520). */
+int o_digitize_signal(const double* signal, int sig_is_f4, const int64_t* signal_op, int64_t R, int64_t Tp,
+                      const int64_t* trig_op, int64_t ntrig, int64_t ndm, const int64_t* tid, const double* tph, int32_t Mt,
+                      int64_t ns, double* digit, int64_t* dtid, double* dtph, const LdsimConsts* c) {
+  for (int64_t itrig = 0; itrig < ntrig; itrig++)
+    for (int64_t idm = 0; idm < ndm; idm++)
+      for (int64_t is = 0; is < ns; is++) {
+        double sample_tick = (double)is * c->light_digit_sample_spacing / c->light_tick_size;
+        int64_t idet = trig_op[itrig * ndm + idm];
+        int64_t s = 0;
+        for (s = 0; s < R; s++)
+          if (idet == signal_op[s]) break;
+        /* Python's `for ... break` leaves idet_signal at R-1 when nothing matched (the `== signal.shape[0]` test of :497
+         * can never fire), so an unmatched channel reads the LAST row */
+        if (s == R) s = R - 1;
+        if (R == 0) continue;
+        const int64_t o = (itrig * ndm + idm) * ns + is;
+        digit[o] = o_interp2(sample_tick, signal + s * Tp, Tp, 0, 0, sig_is_f4 && g_numba_f32);
+        if (Mt == 0) continue;
+        int64_t itick0 = (int64_t)floor(sample_tick), itick1 = (int64_t)ceil(sample_tick);
+        if (itick0 < 0 || itick0 >= Tp) continue;       /* the reference would index out of bounds */
+        int itrue = 0;
+        for (int j = 0; j < Mt; j++) {
+          if (itrue >= Mt) break;
+          const int64_t id0 = tid[(s * Tp + itick0) * Mt + j];
+          if (id0 == -1) break;
+          double photons0 = 0, photons1 = 0;
+          int64_t* slot = &dtid[o * Mt + itrue];
+          if (id0 == *slot || *slot == -1) {
+            *slot = id0;
+            itrue += 1;
+            photons0 = (idet >= 0 && idet < R) ? tph[(idet * Tp + itick0) * Mt + j] : 0.0;
+            if (fabs(photons0) < c->mc_truth_threshold) continue;
+            if (itick1 < Tp) {
+              if (id0 == tid[(s * Tp + itick1) * Mt + j]) photons1 = tph[(s * Tp + itick1) * Mt + j];
+              else
+                for (int k = 0; k < Mt; k++)
+                  if (id0 == tid[(s * Tp + itick1) * Mt + k]) { photons1 = tph[(s * Tp + itick1) * Mt + k]; break; }
+            }
+          }
+          const int last = itrue - 1 < 0 ? Mt - 1 : itrue - 1;      /* Python's negative index wraps */
+          if (dtid[o * Mt + last] != -1) {
+            double pair[2] = {photons0, photons1};
+            dtph[o * Mt + last] = o_interp2(sample_tick - (double)itick0, pair, 2, 0, 0, 0);
+          }
+        }
+      }
+  return 0;
+}

@@ -335,3 +335,146 @@ def light_detector_response(light_sample_inc, light_gain, impulse_model, true_id
                                     C.byref(c))
     return out, otid, otph
 
+
+
+# ---- light: fluctuations, triggers, noise, digitisation (light_sim.py:186-238, 339-619) -------------------------------------
+def stat_fluctuations(light_sample_inc, rng_states):
+    """light_sim.calc_stat_fluctuations: element (idet, itick) draws from rng_states[idet*ntick + itick] (advanced in place)."""
+    c = _consts()
+    inc = np.ascontiguousarray(light_sample_inc, dtype=np.float32)
+    assert rng_states.dtype == RNG_DTYPE and len(rng_states) >= inc.size
+    out = np.zeros(inc.shape, dtype=np.float32)
+    lib().o_stat_fluctuations(_p(inc), C.c_int64(inc.size), _p(rng_states), _p(out), C.byref(c))
+    return out
+
+
+def get_triggers(signal, group_threshold, op_channel_idx, i_subbatch):
+    """light_sim.get_triggers (:339-443): (trigger tick indices, op channels per trigger, trigger type).
+    The group sum keeps the array's f4 (rows added in order), the padded copy and the sample mean are f8, and the
+    threshold loop keeps the reference's bookkeeping (the slice offset of the third and later triggers of a module is the
+    absolute tick of the previous trigger, not the relative one -- :404-411 -- so those indices come out the way the
+    reference computes them, not where the waveform crosses)."""
+    light, detector = consts.light, consts.detector
+    signal = np.asarray(signal)
+    op_channel_idx = np.asarray(op_channel_idx)
+    nd, nt = signal.shape
+    per = light.OP_CHANNEL_PER_TRIG
+    ng = nd // per
+    gsum = signal.reshape(ng, per, nt).sum(axis=1, keepdims=True)
+    sf = round(light.LIGHT_DIGIT_SAMPLE_SPACING / light.LIGHT_TICK_SIZE)
+    padding = sf - nt % sf
+    if padding > 0:
+        gsum = np.concatenate((gsum, np.zeros((ng, 1, padding))), axis=-1)
+    blocks = gsum.reshape(-1, 1, gsum.shape[-1] // sf, sf).mean(axis=-1, keepdims=True)
+    flat = np.broadcast_to(blocks, blocks.shape[:3] + (sf,)).reshape(-1, 1, nt + padding)
+    flat = flat[..., :(-padding if padding > 0 else nt)]
+    above = np.broadcast_to(flat < np.asarray(group_threshold)[:, None, None], (ng, per, nt)).reshape(nd, nt)
+    digit_ticks = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_TICK_SIZE))
+    tpcs = np.unique(light.OP_CHANNEL_TO_TPC[op_channel_idx])
+    mods = np.unique([detector.TPC_TO_MODULE[int(t)] for t in tpcs])
+    trig, chans, types = [], [], []
+    if light.LIGHT_TRIG_MODE == 0:
+        for mod in mods:
+            mod_channels = light.TPC_TO_OP_CHANNEL[detector.MODULE_TO_TPCS[mod]].ravel()
+            rows = np.isin(op_channel_idx, mod_channels)
+            hot = np.any(above[rows], axis=0)
+            last = 0
+            while np.any(hot):
+                nxt = int(np.flatnonzero(hot)[0]) + last
+                trig.append(nxt); types.append(0); chans.append(mod_channels)
+                hot = hot[nxt + digit_ticks:]
+                last = nxt + digit_ticks
+    elif light.LIGHT_TRIG_MODE == 1 and i_subbatch == 0:
+        trig.append(0); chans.append(op_channel_idx); types.append(1)
+    if trig:
+        return np.array(trig), np.array(chans), np.array(types)
+    return np.empty((0,), dtype=int), np.empty((0, len(op_channel_idx)), dtype=int), np.empty((0,), dtype=int)
+
+
+def gen_light_detector_noise(shape, light_det_noise, phases):
+    """light_sim.gen_light_detector_noise (:445-478) with the uniform random phases handed in (`phases`, shape
+    (shape[0], shape[1]//2 + 1), what cp.random.uniform(size=noise_spectrum.shape) returns there)."""
+    light = consts.light
+    if not shape[0]:
+        return np.empty(shape)
+    light_det_noise = np.asarray(light_det_noise, dtype=np.float64)
+    noise_freq = np.fft.rfftfreq((light_det_noise.shape[-1] - 1) * 2, d=light.LIGHT_DET_NOISE_SAMPLE_SPACING)
+    desired_freq = np.fft.rfftfreq(shape[-1], d=light.LIGHT_TICK_SIZE)
+    bin_size = np.diff(desired_freq).mean()
+    spec = np.zeros((shape[0], desired_freq.shape[0]))
+    for idet in range(shape[0]):
+        spec[idet] = np.interp(desired_freq, noise_freq, light_det_noise[idet], left=0, right=0)
+    spec *= np.sqrt(np.diff(noise_freq, axis=-1).mean() / bin_size) * light.LIGHT_DIGIT_SAMPLE_SPACING / light.LIGHT_TICK_SIZE
+    noise = spec * np.exp(2j * np.pi * np.asarray(phases))
+    scale = 2 ** (16 - light.LIGHT_NBIT)
+    if shape[1] < 2:
+        noise = np.round(np.real(noise)) * scale
+    else:
+        noise = np.round(np.fft.irfft(noise, axis=-1)) * scale
+    if noise.shape[1] < shape[1]:
+        noise = np.concatenate([noise, np.zeros((noise.shape[0], shape[1] - noise.shape[1]))], axis=-1)
+    return noise[:, :shape[1]]
+
+
+def sim_triggers(signal, signal_op_channel_idx, signal_true_track_id, signal_true_photons, trigger_idx, op_channel_idx,
+                 digit_samples, light_det_noise, phases_signal=None, phases_missing=None):
+    """light_sim.sim_triggers (:545-619).  phases_* = the uniform numbers of the two gen_light_detector_noise calls (None =
+    zero spectrum expected).  Returns (digit_signal f8, true ids i8, true photons f8)."""
+    light = consts.light
+    c = _consts()
+    signal = np.asarray(signal)
+    sop = np.asarray(signal_op_channel_idx).astype(np.int64)
+    tid = np.asarray(signal_true_track_id, dtype=np.int64)
+    tph = np.asarray(signal_true_photons, dtype=np.float64)
+    trigger_idx = np.asarray(trigger_idx).astype(np.int64)
+    op_channel_idx = np.asarray(op_channel_idx).astype(np.int64)
+    Mt = tid.shape[-1]
+    ntrig, ndm = trigger_idx.shape[0], op_channel_idx.shape[-1]
+    digit = np.zeros((ntrig, ndm, digit_samples))
+    dtid = np.full((ntrig, ndm, digit_samples, Mt), -1, dtype=np.int64)
+    dtph = np.zeros((ntrig, ndm, digit_samples, Mt))
+    if ntrig == 0:
+        return digit, dtid, dtph
+    padded = trigger_idx.copy()
+    pre = int(np.ceil(light.LIGHT_TRIG_WINDOW[0] / light.LIGHT_TICK_SIZE))
+    if trigger_idx.min() - pre < 0:
+        n0 = int(pre - trigger_idx.min())
+        signal = np.concatenate([np.zeros((signal.shape[0], n0)), signal], axis=-1)
+        tid = np.concatenate([np.full((tid.shape[0], n0, Mt), -1, dtype=np.int64), tid], axis=1)
+        tph = np.concatenate([np.zeros((tph.shape[0], n0, Mt)), tph], axis=1)
+        padded += n0
+    post = int(np.ceil(light.LIGHT_TRIG_WINDOW[1] / light.LIGHT_TICK_SIZE))
+    if post + padded.max() > signal.shape[1]:
+        n1 = int(post + padded.max() - signal.shape[1])
+        signal = np.concatenate([signal, np.zeros((signal.shape[0], n1))], axis=-1)
+        tid = np.concatenate([tid, np.full((tid.shape[0], n1, Mt), -1, dtype=np.int64)], axis=1)
+        tph = np.concatenate([tph, np.zeros((tph.shape[0], n1, Mt))], axis=1)
+    sig_is_f4 = signal.dtype == np.float32
+    noise_tab = np.asarray(light_det_noise, dtype=np.float64)
+    if phases_signal is None:
+        assert not np.any(noise_tab[sop]), "phases needed for a non-zero noise spectrum"
+        phases_signal = np.zeros((signal.shape[0], signal.shape[1] // 2 + 1))
+    signal = signal.copy()
+    signal += gen_light_detector_noise(signal.shape, noise_tab[sop], phases_signal)     # f4 += f8 rounds to f4 if still f4
+    absent = ~np.isin(op_channel_idx, sop)
+    if np.any(absent):
+        missing = np.unique(op_channel_idx[absent])
+        if phases_missing is None:
+            assert not np.any(noise_tab[missing])
+            phases_missing = np.zeros((missing.shape[0], signal.shape[1] // 2 + 1))
+        signal = np.concatenate([signal, gen_light_detector_noise((missing.shape[0], signal.shape[1]), noise_tab[missing],
+                                                                  phases_missing)], axis=0)
+        sop = np.concatenate([sop, missing])
+        tid = np.concatenate([tid, np.full((missing.shape[0],) + tid.shape[1:], -1, dtype=np.int64)], axis=0)
+        tph = np.concatenate([tph, np.zeros((missing.shape[0],) + tph.shape[1:])], axis=0)
+        order = np.argsort(sop)
+        signal, sop, tid, tph = signal[order], sop[order], tid[order], tph[order]
+    sig = np.ascontiguousarray(signal, dtype=np.float64)
+    tid = np.ascontiguousarray(tid); tph = np.ascontiguousarray(tph); sop = np.ascontiguousarray(sop)
+    top = np.ascontiguousarray(np.broadcast_to(op_channel_idx, (ntrig, ndm)) if op_channel_idx.ndim == 1 else op_channel_idx)
+    lib().o_digitize_signal(_p(sig), C.c_int(int(sig_is_f4)), _p(sop), C.c_int64(sig.shape[0]), C.c_int64(sig.shape[1]),
+                            _p(top), C.c_int64(ntrig), C.c_int64(ndm), _p(tid), _p(tph), C.c_int32(Mt),
+                            C.c_int64(digit_samples), _p(digit), _p(dtid), _p(dtph), C.byref(c))
+    scale = 2 ** (16 - light.LIGHT_NBIT)
+    digit = np.round(digit / scale) * scale
+    return digit, dtid, dtph

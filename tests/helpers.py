@@ -90,3 +90,28 @@ def load_light_response_case(cfg):
     consts.sim.MC_TRUTH_THRESHOLD = float(g["mc_truth_threshold"])
     return g
 
+
+
+LIGHT_WVFM_CASES = ("light_wvfm_module0_0", "light_wvfm_2x2_no_modvar_1", "light_wvfm_2x2_no_modvar_2")
+
+
+def load_light_wvfm_case(name):
+    """Constants of a tests/golden/light_wvfm_*.npz case (oracle/gen_golden.py gen_light_wvfm)."""
+    cfg = "module0" if "module0" in name else "2x2_no_modvar"
+    load_cfg(cfg)
+    g = gold(name + ".npz")
+    consts.light.LIGHT_TRIG_MODE = int(g["light_trig_mode"])
+    consts.light.LIGHT_TRIG_WINDOW = tuple(float(x) for x in g["light_trig_window"])
+    consts.sim.MC_TRUTH_THRESHOLD = float(g["mc_truth_threshold"])
+    return g
+
+
+def det_phases(shape, seed):
+    """The golden generator's stand-in for cp.random.uniform(size=shape) (oracle/gen_golden.py det_phases): a
+    multiplicative hash of (row, column, seed) in [0, 1), so the fixtures need not store the phases."""
+    shape = tuple(int(v) for v in np.atleast_1d(shape))
+    i, k = np.meshgrid(np.arange(shape[0], dtype=np.uint64), np.arange(shape[1], dtype=np.uint64), indexing='ij')
+    h = (i * np.uint64(7919) + k * np.uint64(104729) + np.uint64(seed)) * np.uint64(2654435761)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    return h.astype(np.float64) / 4294967296.0

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/ldsim.h but not exported"
     assert set(lib.EXPORTS) == declared
-    assert l.ldsim_abi_version() == abi.ABI_VERSION == 3
+    assert l.ldsim_abi_version() == abi.ABI_VERSION == 4
 
 
 def test_graft_entry_build_succeeds():

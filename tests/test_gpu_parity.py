@@ -846,6 +846,145 @@ def test_resident_light_leg_golden(cfg):
     np.testing.assert_allclose(out3, ref, rtol=1e-5, atol=0)
 
 
+def _lsb_mismatch(got, ref, lsb):
+    """fraction of values that differ, and whether every difference is exactly one digitiser LSB"""
+    d = np.abs(np.asarray(got) - np.asarray(ref))
+    bad = d != 0
+    return bad.mean(), bool(np.all(d[bad] == lsb))
+
+
+@pytest.mark.parametrize("name", H.LIGHT_WVFM_CASES)
+def test_light_waveform_chain_golden(name):
+    """Second half of the light chain through the C-ABI against the reference's own functions (light_sim.py:186-238,
+    339-619; fixtures of oracle/gen_golden.py gen_light_wvfm): Poisson counts and the advanced random states, trigger ticks
+    (module by module, with the reference's re-slicing bookkeeping), noise from given phases, digitised waveforms and their
+    truth slots.  Exact where the arithmetic is integer or a copy; where a libm call of the device (exp, log, cos, sincos)
+    sits in front of an integer rounding, a difference of one count / one LSB is tolerated in < 1e-3 of the values."""
+    from larndsim_amd import rng as lrng
+    g = H.load_light_wvfm_case(name)
+    icase = H.LIGHT_WVFM_CASES.index(name)
+    light = consts.light
+    # -- calc_stat_fluctuations
+    inc = g["fluct_inc"]
+    D0, T0 = inc.shape
+    st = lrng.create_xoroshiro128p_states(D0 * T0, seed=4242 + icase)
+    assert np.array_equal(st.copy_to_host().view('u8').reshape(-1, 2), g["fluct_states_before"])
+    disc = np.full((D0, T0), -1, dtype='f4')
+    light_sim.calc_stat_fluctuations[(D0, -(-T0 // 64)), (1, 64)](inc, disc, st)
+    assert np.array_equal(st.copy_to_host().view('u8').reshape(-1, 2), g["fluct_states_after"])
+    frac, one = _lsb_mismatch(disc, g["fluct_disc"], np.float32(1.0 / light.LIGHT_TICK_SIZE))
+    assert frac < 1e-3 and one, (frac, one)
+    assert np.array_equal(disc[inc <= 0], np.zeros((inc <= 0).sum(), dtype='f4'))
+    with pytest.raises(IndexError):
+        light_sim.calc_stat_fluctuations[1, 1](np.ones((D0 + 1, T0), dtype='f4'), np.zeros((D0 + 1, T0), dtype='f4'), st)
+    # -- get_triggers
+    trig, trig_op, trig_type = light_sim.get_triggers(g["response"], g["group_threshold"], g["op_channel"], 0)
+    assert np.array_equal(trig, g["trigger_idx"]) and np.array_equal(trig_op, g["trigger_op_channel_idx"])
+    assert np.array_equal(trig_type, g["trigger_type"]) and len(trig) > 0
+    assert len(light_sim.get_triggers(g["response"], g["group_threshold"], g["op_channel"], 1)[0]) == int(g["n_trig_subbatch1"])
+    quiet = np.zeros_like(g["response"])
+    assert len(light_sim.get_triggers(quiet, g["group_threshold"], g["op_channel"], 0)[0]) == (0 if light.LIGHT_TRIG_MODE == 0 else 1)
+    # -- gen_light_detector_noise with the recorded phases
+    lsb = 2.0 ** (16 - light.LIGHT_NBIT)
+    for n in (1500, 1501):
+        ref = g[f"noise_{n}"]
+        ph = H.det_phases((ref.shape[0], n // 2 + 1), int(g[f"noise_{n}_phase_seed"]))
+        got = light_sim.gen_light_detector_noise(ref.shape, g["noise_spectrum"][:ref.shape[0]], phases=ph)
+        frac, one = _lsb_mismatch(got, ref, lsb)
+        assert frac < 1e-3 and one and np.abs(ref).max() > 100 * lsb, (n, frac, one)
+    with pytest.raises(lib.LdsimError, match="at least 2 samples"):
+        light_sim.gen_light_detector_noise((2, 1), g["noise_spectrum"][:2])
+    # -- sim_triggers + digitize_signal: zero spectrum is deterministic
+    keep = g["wvfm_keep_rows"]
+    ns = int(g["digit_samples"])
+    args = (g["response"][keep], g["op_channel"][keep], g["response_true_id"][keep].astype('i8'),
+            g["response_true_photons"][keep], g["trigger_idx"], g["trigger_op_channel_idx"], ns)
+    d, dt, dp = light_sim.sim_triggers(None, None, *args, np.zeros_like(g["noise_spectrum"]))
+    assert np.array_equal(d, g["wvfm_quiet"]) and np.array_equal(dt, g["wvfm_true_id"])
+    np.testing.assert_allclose(dp, g["wvfm_true_photons"], rtol=1e-15, atol=0)
+    d0, _, _ = light_sim.sim_triggers(None, None, *args, None)
+    assert np.array_equal(d0, d)
+    # with the recorded phases of both noise calls
+    pre = int(np.ceil(light.LIGHT_TRIG_WINDOW[0] / light.LIGHT_TICK_SIZE)); post = int(np.ceil(light.LIGHT_TRIG_WINDOW[1] / light.LIGHT_TICK_SIZE))
+    tmin, tmax = int(g["trigger_idx"].min()), int(g["trigger_idx"].max())
+    n0 = max(pre - tmin, 0)
+    Tp = g["response"].shape[1] + n0
+    Tp += max(post + tmax + n0 - Tp, 0)
+    seeds = g["wvfm_noisy_phase_seeds"]
+    n_missing = len(np.setdiff1d(np.unique(g["trigger_op_channel_idx"]), g["op_channel"][keep]))
+    ph_sig = H.det_phases((int(keep.sum()), Tp // 2 + 1), int(seeds[0]))
+    ph_mis = H.det_phases((n_missing, Tp // 2 + 1), int(seeds[1])) if len(seeds) > 1 else None
+    d2, dt2, _ = light_sim.sim_triggers(None, None, *args, g["noise_spectrum"], phases_signal=ph_sig, phases_missing=ph_mis)
+    frac, one = _lsb_mismatch(d2, g["wvfm_noisy"], lsb)
+    assert frac < 1e-3 and one, (frac, one)
+    assert np.array_equal(dt2, dt)
+    # internal phases: needs a seeded generator, is reproducible with it, and has the same power
+    lib.check(lib.load().ldsim_rng_clear(lib.context()))
+    with pytest.raises(lib.LdsimError, match="ldsim_rng_seed first"):
+        light_sim.sim_triggers(None, None, *args, g["noise_spectrum"])
+    lrng.create_xoroshiro128p_states(16, seed=5)
+    a = light_sim.sim_triggers(None, None, *args, g["noise_spectrum"])[0]
+    lrng.create_xoroshiro128p_states(16, seed=5)
+    b = light_sim.sim_triggers(None, None, *args, g["noise_spectrum"])[0]
+    assert np.array_equal(a, b) and not np.array_equal(a, d2)
+    assert 0.8 < (a - d).std() / (g["wvfm_noisy"] - g["wvfm_quiet"]).std() < 1.25
+
+
+def test_resident_light_waveform_chain_vs_oracle():
+    """The light leg from the resident segments to digitised waveforms without leaving HBM between the stages
+    (sum_light -> light_response -> get_triggers(None) -> sim_triggers(None)) against the oracle fed with the downloaded
+    photon sum: scintillation, Poisson counts (same state table), detector response, trigger ticks, waveforms, truth."""
+    from larndsim_amd import rng as lrng
+    cfg = "module0"
+    H.load_cfg(cfg)
+    light = consts.light
+    light.LIGHT_WINDOW = (0.2, 1.2)                       # 1000-tick convolutions keep the oracle's O(T*C) loops short
+    light.LIGHT_TRIG_WINDOW = (0.2, 0.5)
+    consts.sim.MAX_MC_TRUTH_IDS = 2
+    g = H.gold(f"light_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    n = len(r)
+    lut = synth.make_lut((14, 26, 8), 48, int(g["n_prof"]), int(g["lut_seed"]))
+    ch = ChargeChain()
+    ch.upload(r, np.zeros(n, dtype=np.int32))
+    ch.light_incidence(lut)
+    opc = light.TPC_TO_OP_CHANNEL[:].ravel()
+    n_ticks, t_start = ch.sum_light(0, n, opc, np.arange(n, dtype='i8'))
+    inc, tid, tph = ch.download_light()
+    assert inc.sum() > 0 and n_ticks > 1400
+    nd = opc.shape[0]
+    ch.seed_rng(77, nd * n_ticks)
+    states = O.rng_create_states(nd * n_ticks, 77)
+    ch.light_response(fluctuate=True)
+    sc, di, resp, rtid, rtph = ch.download_light_response(stages=True)
+    o_sc, o_stid, o_stph = O.scintillation_effect(inc, tid, tph)
+    assert np.array_equal(sc, o_sc)
+    o_di = O.stat_fluctuations(o_sc, states)
+    frac, one = _lsb_mismatch(di, o_di, np.float32(1.0 / light.LIGHT_TICK_SIZE))
+    assert frac < 1e-3 and one and (o_di > 0).sum() > 100, (frac, one)
+    # downstream of the fluctuations compare on the device's own counts, so that a one-count difference cannot propagate
+    o_resp, o_rtid, o_rtph = O.light_detector_response(di, light.LIGHT_GAIN, light.IMPULSE_MODEL, o_stid, o_stph)
+    assert np.array_equal(resp, o_resp) and np.array_equal(rtid, o_rtid)
+    np.testing.assert_allclose(rtph, o_rtph, rtol=1e-12, atol=0)
+    per = light.OP_CHANNEL_PER_TRIG
+    gsum = resp.reshape(-1, per, n_ticks).sum(axis=1)
+    thr = np.full(nd // per, float(np.sort(gsum.min(axis=1))[nd // per // 2]) * 0.5)       # about half of the groups fire
+    trig, trig_op, trig_type = light_sim.get_triggers(None, thr, opc, 0)
+    o_trig, o_op, o_type = O.get_triggers(resp, thr, opc, 0)
+    assert len(trig) > 0 and np.array_equal(trig, o_trig) and np.array_equal(trig_op, o_op) and np.array_equal(trig_type, o_type)
+    ns = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING))
+    d, dt, dp = light_sim.sim_triggers(None, None, None, opc, None, None, trig, trig_op, ns, None)
+    o_d, o_dt, o_dp = O.sim_triggers(resp, opc, rtid, rtph, trig, trig_op, ns, np.zeros((light.N_OP_CHANNEL, 4)))
+    assert np.array_equal(d, o_d) and np.array_equal(dt, o_dt) and (d != 0).sum() > 50 and (dt >= 0).sum() > 10
+    np.testing.assert_allclose(dp, o_dp, rtol=1e-12, atol=0)
+    # the host-buffer calls on the downloaded arrays are the same kernels
+    assert np.array_equal(light_sim.get_triggers(resp, thr, opc, 0)[0], trig)
+    d_h = light_sim.sim_triggers(None, None, resp, opc, rtid, rtph, trig, trig_op, ns, None)[0]
+    assert np.array_equal(d_h, d)
+    ms = ch.light_response_ms()
+    assert all(v > 0 for v in ms.values())
+
+
 def test_stage_call_between_upload_and_run_is_refused():
     """The host-buffer stage calls upload their records into the store the resident chain uses.  A chain call that finds
     the store taken over by a stage call must refuse (LDSIM_ESTATE) instead of simulating the stage call's records."""

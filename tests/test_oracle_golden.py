@@ -171,3 +171,52 @@ def test_light_response_golden(cfg):
     assert np.array_equal(O.light_detector_response(g["disc"], consts.light.LIGHT_GAIN, consts.light.IMPULSE_MODEL)[0],
                           g["response"])
 
+
+
+@pytest.mark.parametrize("name", H.LIGHT_WVFM_CASES)
+def test_light_waveform_chain_golden(name):
+    """calc_stat_fluctuations, get_triggers, gen_light_detector_noise and sim_triggers/digitize_signal of the oracle against
+    the reference's own functions (light_sim.py:186-238, 339-619; oracle/gen_golden.py gen_light_wvfm).  The random
+    generator under calc_stat_fluctuations is the restated one on both sides (third-party, unpinned): what this pins is
+    the Poisson logic, the state indexing and the number of draws."""
+    g = H.load_light_wvfm_case(name)
+    # Poisson fluctuations
+    states = np.ascontiguousarray(g["fluct_states_before"]).view(O.RNG_DTYPE).reshape(-1)
+    disc = O.stat_fluctuations(g["fluct_inc"], states)
+    assert np.array_equal(disc, g["fluct_disc"])
+    assert np.array_equal(states.view('u8').reshape(-1, 2), g["fluct_states_after"])
+    assert (disc > 0).sum() > 500 and disc[0, 0] == 0 and disc[0, 1] == 0
+    # triggers
+    trig, trig_op, trig_type = O.get_triggers(g["response"], g["group_threshold"], g["op_channel"], 0)
+    assert np.array_equal(trig, g["trigger_idx"]) and np.array_equal(trig_op, g["trigger_op_channel_idx"])
+    assert np.array_equal(trig_type, g["trigger_type"])
+    assert len(O.get_triggers(g["response"], g["group_threshold"], g["op_channel"], 1)[0]) == int(g["n_trig_subbatch1"])
+    # noise with the recorded phases: the values are integers x 2**(16-NBIT); the FFT sizes are the reference's
+    for n in (1500, 1501):
+        ref = g[f"noise_{n}"]
+        ph = H.det_phases((ref.shape[0], n // 2 + 1), int(g[f"noise_{n}_phase_seed"]))
+        got = O.gen_light_detector_noise(ref.shape, g["noise_spectrum"][:ref.shape[0]], ph)
+        assert np.array_equal(got, ref)
+    # digitised waveforms
+    keep = g["wvfm_keep_rows"]
+    args = (g["response"][keep], g["op_channel"][keep], g["response_true_id"][keep].astype('i8'),
+            g["response_true_photons"][keep], g["trigger_idx"], g["trigger_op_channel_idx"], int(g["digit_samples"]))
+    d, dt, dp = O.sim_triggers(*args, np.zeros_like(g["noise_spectrum"]))
+    assert np.array_equal(d, g["wvfm_quiet"]) and np.array_equal(dt, g["wvfm_true_id"])
+    np.testing.assert_allclose(dp, g["wvfm_true_photons"], rtol=1e-15, atol=0)
+    assert (dt >= 0).sum() > 100 and (d != 0).sum() > 100
+    R = int(keep.sum())
+    Tp = None
+    # phases of the two noise calls: (rows, Tp//2+1) with Tp the padded length -- recompute it the way sim_triggers does
+    l = consts.light
+    pre = int(np.ceil(l.LIGHT_TRIG_WINDOW[0] / l.LIGHT_TICK_SIZE)); post = int(np.ceil(l.LIGHT_TRIG_WINDOW[1] / l.LIGHT_TICK_SIZE))
+    tmin, tmax = int(g["trigger_idx"].min()), int(g["trigger_idx"].max())
+    n0 = max(pre - tmin, 0)
+    Tp = g["response"].shape[1] + n0
+    Tp += max(post + tmax + n0 - Tp, 0)
+    seeds = g["wvfm_noisy_phase_seeds"]
+    n_missing = len(np.setdiff1d(np.unique(g["trigger_op_channel_idx"]), g["op_channel"][keep]))
+    ph_sig = H.det_phases((R, Tp // 2 + 1), int(seeds[0]))
+    ph_mis = H.det_phases((n_missing, Tp // 2 + 1), int(seeds[1])) if len(seeds) > 1 else None
+    d2, _, _ = O.sim_triggers(*args, g["noise_spectrum"], phases_signal=ph_sig, phases_missing=ph_mis)
+    assert np.array_equal(d2, g["wvfm_noisy"])
