@@ -5,16 +5,17 @@ simulate_pixels.py -- command-line driver keeping the reference's flag surface (
 
 input checks -> configuration resolution (larndsim_amd.config, the reference's get_config rules) -> segment preparation
 (segment_id / n_photons / t0 columns, spill-time reset, x<->z swap) -> active-volume selection -> batching ->
-quench + drift -> [light incidence + photon sum per batch] -> charge chain with FEE noise -> LArPix packets +
-mc_packets_assn per batch -> output file (HDF5 when h5py is importable, else .npz with the same dataset names) with the
-updated segments, light_dat and the truth datasets of the input passed through.
+quench + drift -> [light incidence; per batch: photon sum -> scintillation profile -> Poisson fluctuations -> SiPM response ->
+triggers -> digitised waveforms with detector noise] -> charge chain with FEE noise -> LArPix packets + mc_packets_assn per
+batch -> output file (HDF5 when h5py is importable, else .npz with the same dataset names) with the updated segments,
+light_dat, light_trig, light_wvfm, light_wvfm_mc_assn and the truth datasets of the input passed through.
 
-Not built (a flag that only concerns them is accepted and reported): module-to-module variation, the light waveform chain
-after the photon sum (Poisson fluctuation, SiPM response, noise, triggers, digitisation), bad-channel lists by id,
+Not built (a flag that only concerns them is accepted and reported): module-to-module variation, bad-channel lists by id,
 memory logging.
 """
 import argparse
 import os
+from math import ceil
 import sys
 import warnings
 from time import time
@@ -25,12 +26,12 @@ import numpy.lib.recfunctions as rfn
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from larndsim_amd import batching, consts, fee, packets, synth  # noqa: E402
+from larndsim_amd import batching, consts, fee, light_sim, packets, synth  # noqa: E402
 from larndsim_amd import config as cfgmod  # noqa: E402
 from larndsim_amd.chain import ChargeChain  # noqa: E402
 
 SEED = int(time())
-IGNORED = ("light_det_noise_filename", "pixel_thresholds_id", "pixel_gains_id", "save_memory", "pixel_layout_id",
+IGNORED = ("pixel_thresholds_id", "pixel_gains_id", "save_memory", "pixel_layout_id",
            "response_id", "light_lut_id")
 TRUTH_DATASETS = ("trajectories", "vertices", "mc_hdr", "mc_stack")
 
@@ -101,6 +102,16 @@ class _Output:
             self.parts.setdefault("packets", []).append(pk)
             self.parts.setdefault("mc_packets_assn", []).append(assn)
 
+    def append(self, name, data):
+        """resizable dataset grown along axis 0 (light_trig, light_wvfm, light_wvfm_mc_assn)"""
+        if data.shape[0] == 0:
+            return
+        if self.h5py is not None:
+            with self.h5py.File(self.filename, "a") as f:
+                light_sim._append(f, name, data, (None,) * data.ndim)
+        else:
+            self.parts.setdefault(name, []).append(data)
+
     def put(self, name, data, attrs=None):
         if self.h5py is not None:
             with self.h5py.File(self.filename, "a") as f:
@@ -118,7 +129,7 @@ class _Output:
 
 def run_simulation(input_filename, output_filename, config="module0", mod2mod_variation=None, pixel_layout=None,
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
-                   light_lut_filename=None, bad_channels=None, n_events=None, pixel_thresholds_file=None,
+                   light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None, pixel_thresholds_file=None,
                    pixel_gains_file=None, rand_seed=None, config_root=None, tracks_current_mc=False, chunk_segments=50000,
                    raw_arrays=False, **ignored):
     if not os.path.exists(input_filename):
@@ -210,20 +221,85 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
         chain.quench_drift(consts.physics.BIRKS)
         chain.download_segments(tracks)
         edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
+        light_trig_of = {}                                           # (event, TPC group) -> trigger arrays for the packet stream
+        n_light_trig = 0
         if light_simulated:
             chain.light_incidence(lut)
             op_channel = light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32)
-            light_rows = []
-            for b0, b1 in zip(edges[:-1], edges[1:]):               # :1120-1153; the waveform chain that follows is not built
-                n_ticks, t_start = chain.sum_light(int(b0), int(b1), op_channel,
-                                                   segment_track_id=tracks["segment_id"][b0:b1].astype(np.int64))
-                if raw_arrays:
-                    light_rows.append(chain.download_light(truth=False)[0])
+            n_det = op_channel.shape[0]
+            light_det_noise_filename = light_det_noise_filename or one(cfg.get("LIGHT_DET_NOISE"))
+            if light_det_noise_filename and os.path.isfile(light_det_noise_filename):
+                print("Light detector noise: ", light_det_noise_filename)
+                light_noise = np.load(light_det_noise_filename)
+            else:
+                print("light_det_noise_filename is not provided (required if light_simulated is True): no detector noise")
+                light_noise = None
+            digit_samples = ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING)
+            # group thresholds of the active channels (:1183-1185)
+            thr = np.repeat(np.array(light.LIGHT_TRIG_THRESHOLD)[..., np.newaxis], light.OP_CHANNEL_PER_TRIG, axis=-1)
+            thr = thr.ravel()[op_channel].copy().reshape(-1, light.OP_CHANNEL_PER_TRIG)[..., 0]
+            n_groups = int(np.ceil(det.TPC_BORDERS.shape[0] / sim.EVENT_BATCH_SIZE))
+            batch_of = {}
+            for ib, (ev, grp, sub, _n) in enumerate(table):
+                batch_of.setdefault((int(ev), int(grp)), []).append(ib)
+            light_rows, i_trig = [], 0
+            null_wvfm = None
+            for ev in np.unique(tracks[sim.EVENT_SEPARATOR]):       # the reference's loop order: events, TPC groups (:864)
+                ev_time = np.array([event_times[int(ev) % sim.MAX_EVENTS_PER_FILE]])
+                for grp in range(n_groups):
+                    acc = dict(start=[], idx=[], typ=[], opc=[], wv=[], tid=[], tph=[])
+                    ibs = batch_of.get((int(ev), grp), [])
+                    if not ibs:
+                        # nothing to simulate in this module group: waveforms of an empty response (:805-841, 894-899)
+                        if null_wvfm is None:
+                            nt0 = int((light.LIGHT_WINDOW[1] + light.LIGHT_WINDOW[0]) / light.LIGHT_TICK_SIZE)
+                            zero = np.zeros((n_det, nt0), dtype=np.float32)
+                            mt = sim.MAX_MC_TRUTH_IDS
+                            null_wvfm = light_sim.sim_triggers(
+                                None, None, zero, op_channel, np.full((n_det, nt0, mt), -1, dtype=np.int64),
+                                np.zeros((n_det, nt0, mt)), np.array([0]), op_channel[None, :], digit_samples, light_noise)
+                        acc["start"].append(np.full(1, 0.0)); acc["idx"].append(np.array([0]))
+                        acc["typ"].append(np.full(1, light.LIGHT_TRIG_MODE)); acc["opc"].append(op_channel[None, :])
+                        for k, v in zip(("wv", "tid", "tph"), null_wvfm):
+                            acc[k].append(v)
+                    for ib in ibs:                                  # sub-batches of BATCH_SIZE segments (:902-905, 1120-1205)
+                        b0, b1 = int(edges[ib]), int(edges[ib + 1])
+                        n_ticks, t_start = chain.sum_light(b0, b1, op_channel,
+                                                           segment_track_id=tracks["segment_id"][b0:b1].astype(np.int64))
+                        if raw_arrays:
+                            light_rows.append(chain.download_light(truth=False)[0])
+                        chain.extend_rng(n_det * (-(-int(n_ticks) // 64)) * 64, rand_seed + int(ev) + table[ib][2] * sim.BATCH_SIZE)
+                        chain.light_response(fluctuate=True)
+                        t_idx, t_opc, t_type = light_sim.get_triggers(None, thr, op_channel, table[ib][2])
+                        wv = light_sim.sim_triggers(None, None, None, op_channel, None, None, t_idx, t_opc, digit_samples,
+                                                    light_noise)
+                        acc["start"].append(np.full(t_idx.shape[0], t_start)); acc["idx"].append(t_idx)
+                        acc["typ"].append(t_type); acc["opc"].append(t_opc)
+                        for k, v in zip(("wv", "tid", "tph"), wv):
+                            acc[k].append(v)
+                    if not any(len(a) for a in acc["idx"]):
+                        continue
+                    cat = {k: np.concatenate(v, axis=0) for k, v in acc.items()}
+                    ntr = cat["idx"].shape[0]
+                    lev = np.full(ntr, ev)
+                    if light.LIGHT_TRIG_MODE == 0:
+                        out.append("light_trig", light_sim.build_light_trig(lev, cat["start"], cat["idx"], cat["opc"], ev_time))
+                    out.append("light_wvfm", cat["wv"])
+                    if sim.MAX_MC_TRUTH_IDS > 0:
+                        out.append("light_wvfm_mc_assn",
+                                   light_sim.zero_suppress_waveform_truth(cat["tid"], cat["tph"], lev[0], i_trig, -1))
+                    i_trig += 1
+                    n_light_trig += ntr
+                    if ibs:
+                        mods = (cat["typ"] if light.LIGHT_TRIG_MODE == 1 else
+                                np.array([det.TPC_TO_MODULE[int(t)] for t in light.OP_CHANNEL_TO_TPC[cat["opc"]][:, 0]]))
+                        light_trig_of[(int(ev), grp)] = (cat["start"] + cat["idx"] * light.LIGHT_TICK_SIZE, lev, mods)
             inc, _ = chain.download_light_incidence(0, len(tracks))
             inc["segment_id"] = tracks["segment_id"][:, None]
             out.put("light_dat/light_dat_allmodules", inc)
             if raw_arrays and light_rows:
-                out.put("light_sample_inc", np.stack(light_rows))
+                nt_max = max(r.shape[1] for r in light_rows)       # the tick count follows each batch's arrival times
+                out.put("light_sample_inc", np.stack([np.pad(r, ((0, 0), (0, nt_max - r.shape[1]))) for r in light_rows]))
         parts, n_hits, n_packets = [], 0, 0
         b = 0
         for e in edges[1:]:
@@ -243,10 +319,13 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
                 event = table[int(bb)][0]
                 ev_ids = np.full(res["adc_digit"][m].shape, event)
                 ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
+                # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger
+                lt_times, lt_events, lt_mods = light_trig_of.get((int(event), int(table[int(bb)][1])),
+                                                                 (np.zeros(1), np.array([event]), np.ones(1)))
                 pk, assn = packets.build_packets(ev_ids, res["adc_digit"][m], res["adc_ticks_list"][m], res["unique_pix"][m],
                                                  res["current_fractions"][m], track_ids, traj_ids, ev_time,
-                                                 light_trigger_times=np.zeros(1), light_trigger_event_id=np.array([event]),
-                                                 light_trigger_modules=np.ones(1), bad_channels=bad_list)
+                                                 light_trigger_times=lt_times, light_trigger_event_id=lt_events,
+                                                 light_trigger_modules=lt_mods, bad_channels=bad_list)
                 out.append_packets(pk, assn)
                 n_packets += len(pk)
             n_hits += int((res["adc_list"] != 0).sum())
@@ -257,6 +336,13 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
         if raw_arrays and parts:
             for k in parts[0]:
                 out.put("raw/" + k, np.concatenate([p[k] for p in parts]))
+        if light_simulated and light.LIGHT_TRIG_MODE == 1:          # one beam trigger per spill / event (:1252-1259)
+            ev_all = tracks[sim.EVENT_SEPARATOR]
+            lev = np.unique(ev_all - (ev_all // sim.MAX_EVENTS_PER_FILE) * sim.MAX_EVENTS_PER_FILE) if sim.IS_SPILL_SIM \
+                else (truth["vertices"]["event_id"] if "vertices" in truth else np.unique(ev_all))
+            lt = lev * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else event_times
+            out.append("light_trig", light_sim.build_light_trig(lev, np.full(len(lev), 0), np.full(len(lev), 0),
+                                                                light.TPC_TO_OP_CHANNEL[:].ravel(), lt))
         # ---- truth pass-through (:1226-1297): true timing structure restored, edep-sim coordinate convention ---------------------------
         out_tracks = tracks.copy()
         if sim.IS_SPILL_SIM:
@@ -271,9 +357,10 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
         out.close()
     finally:
         lib.set_option("mc_current", 0)
-    print(f"simulated {nsim} segments in {len(table)} batches -> {n_hits} hits, {n_packets} packets")
+    print(f"simulated {nsim} segments in {len(table)} batches -> {n_hits} hits, {n_packets} packets"
+          + (f", {n_light_trig} light triggers" if light_simulated else ""))
     print("Output saved in:", output_filename)
-    return dict(n_segments=nsim, n_batches=len(table), n_hits=n_hits, n_packets=n_packets)
+    return dict(n_segments=nsim, n_batches=len(table), n_hits=n_hits, n_packets=n_packets, n_light_triggers=n_light_trig)
 
 
 def main(argv=None):
@@ -287,7 +374,7 @@ def main(argv=None):
     ap.add_argument("--mod2mod_variation", type=tf, default=None)
     ap.add_argument("--light_simulated", type=tf, default=None)
     for k in ("pixel_layout", "detector_properties", "simulation_properties", "response_file", "light_lut_filename",
-              "bad_channels", "pixel_thresholds_file", "pixel_gains_file", *IGNORED):
+              "light_det_noise_filename", "bad_channels", "pixel_thresholds_file", "pixel_gains_file", *IGNORED):
         ap.add_argument("--" + k, default=None)
     ap.add_argument("--n_events", type=int, default=None)
     ap.add_argument("--rand_seed", type=int, default=None)

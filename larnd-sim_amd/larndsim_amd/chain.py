@@ -29,6 +29,10 @@ class ChargeChain:
         self.rng_states = rng.create_xoroshiro128p_states(n_states, seed, self.ctx)
         return self.rng_states
 
+    def extend_rng(self, n_states, seed):
+        """``maybe_create_rng_states(n, seed, rng_states)`` (cli/simulate_pixels.py:92-104) on the ctx's table."""
+        lib.check(lib.load().ldsim_rng_extend(self.ctx, C.c_int64(int(n_states)), C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
     def _check_constants(self):
         """The ctx is process-wide and this object froze its constants at construction: refuse to compute once anything
         (another ChargeChain, a stage call after ``consts`` was reloaded) has frozen different ones."""

@@ -235,3 +235,88 @@ def sim_triggers(bpg, tpb, signal, signal_op_channel_idx, signal_true_track_id, 
         C.c_int32(noise.shape[1] if noise is not None else 0), lib.ptr(ps), lib.ptr(pm), lib.ptr(digit),
         lib.ptr(dtid) if mt else None, lib.ptr(dtph) if mt else None))
     return digit, dtid.astype(id_dtype, copy=False), dtph.astype(ph_dtype, copy=False)
+
+
+# ---- output datasets (light_sim.py:621-757) -------------------------------------------------------------------------------
+light_wvfm_truth_dtype = np.dtype([('trigger_id', 'i4'), ('op_channel_id', 'i4'), ('tick', 'i4'), ('event_id', 'i4'),
+                                   ('segment_id', 'i8'), ('pe_current', 'f8')])
+
+
+def zero_suppress_waveform_truth(waveforms_true_track_id, waveforms_true_photons, i_evt, i_trig, i_mod=-1):
+    """Rows of ``light_wvfm_mc_assn``: one per truth slot that is not -1, in array order.  ``trigger_id`` follows the
+    reference (:634-645): the running ``i_trig`` is advanced by the row's own trigger index for every row, so with several
+    triggers in one call the ids drift exactly as they do there."""
+    light = consts.light
+    op_channel = (light.TPC_TO_OP_CHANNEL[(i_mod - 1) * 2:i_mod * 2].ravel() if i_mod > 0
+                  else light.TPC_TO_OP_CHANNEL[:].ravel())
+    ids = np.asarray(waveforms_true_track_id)
+    t, c, s, k = np.nonzero(ids != -1)
+    out = np.empty(t.shape[0], dtype=light_wvfm_truth_dtype)
+    out['trigger_id'] = i_trig + np.cumsum(t)
+    out['op_channel_id'] = op_channel[c]
+    out['tick'] = s
+    out['event_id'] = i_evt
+    out['segment_id'] = ids[t, c, s, k]
+    out['pe_current'] = np.asarray(waveforms_true_photons)[t, c, s, k]
+    return out
+
+
+def build_light_trig(event_id, start_times, trigger_idx, op_channel_idx, event_times):
+    """Rows of the ``light_trig`` dataset (:695-723): ``op_channel`` i4[ndet_module], ``ts_s`` f8 [s], ``ts_sync`` u8 [ticks]."""
+    light, detector = consts.light, consts.detector
+    event_id = np.asarray(event_id)
+    trigger_idx = np.asarray(trigger_idx)
+    op_channel_idx = np.asarray(op_channel_idx)
+    _, inv = np.unique(event_id, return_inverse=True)
+    event_times = np.asarray(event_times)
+    event_start_times = event_times[inv]
+    event_sync_times = (event_times[inv] / detector.CLOCK_CYCLE).astype(int) % detector.CLOCK_RESET_PERIOD
+    trig = np.empty(trigger_idx.shape[0], dtype=np.dtype([('op_channel', 'i4', (op_channel_idx.shape[-1])), ('ts_s', 'f8'),
+                                                           ('ts_sync', 'u8')]))
+    trig['op_channel'] = op_channel_idx
+    trig['ts_s'] = (start_times + trigger_idx * light.LIGHT_TICK_SIZE + event_start_times) * consts.units.mus / consts.units.s
+    trig['ts_sync'] = (((start_times + trigger_idx * light.LIGHT_TICK_SIZE) / detector.CLOCK_CYCLE
+                        + event_sync_times).astype(int) % detector.CLOCK_RESET_PERIOD)
+    return trig
+
+
+def _append(f, name, data, maxshape):
+    if name not in f:
+        f.create_dataset(name, data=data, maxshape=maxshape)
+    else:
+        f[name].resize(f[name].shape[0] + data.shape[0], axis=0)
+        f[name][-data.shape[0]:] = data
+
+
+def export_light_trig_to_hdf5(event_id, start_times, trigger_idx, op_channel_idx, output_filename, event_times):
+    """Append to ``light_trig`` (needs h5py; the CLI's .npz fallback uses ``build_light_trig`` directly)."""
+    if np.asarray(event_id).shape[0] == 0:
+        return
+    import h5py
+    trig = build_light_trig(event_id, start_times, trigger_idx, op_channel_idx, event_times)
+    with h5py.File(output_filename, 'a') as f:
+        _append(f, 'light_trig', trig, (None,))
+
+
+def export_light_wvfm_to_hdf5(event_id, waveforms, output_filename, waveforms_true_track_id, waveforms_true_photons, i_trig,
+                              i_mod=-1):
+    """Append to ``light_wvfm`` and, with ``MAX_MC_TRUTH_IDS > 0``, to ``light_wvfm_mc_assn`` (:647-693).  Module-to-module
+    variation (per-module ``light_wvfm_mod<i>`` datasets) is not built and refused."""
+    if np.asarray(event_id).shape[0] == 0:
+        return
+    if getattr(consts.sim, 'MOD2MOD_VARIATION', False):
+        raise NotImplementedError("mod2mod variation is not built: per-module light_wvfm datasets are not written")
+    import h5py
+    with h5py.File(output_filename, 'a') as f:
+        _append(f, 'light_wvfm', np.asarray(waveforms), (None, None, None))
+        if consts.sim.MAX_MC_TRUTH_IDS > 0:
+            truth = zero_suppress_waveform_truth(waveforms_true_track_id, waveforms_true_photons, event_id[0], i_trig, i_mod)
+            if truth.shape[0] > 0:
+                _append(f, 'light_wvfm_mc_assn', truth, (None,))
+
+
+def export_to_hdf5(event_id, start_times, trigger_idx, op_channel_idx, waveforms, output_filename, event_times,
+                   waveforms_true_track_id, waveforms_true_photons, i_trig, i_mod=-1):
+    export_light_trig_to_hdf5(event_id, start_times, trigger_idx, op_channel_idx, output_filename, event_times)
+    export_light_wvfm_to_hdf5(event_id, waveforms, output_filename, waveforms_true_track_id, waveforms_true_photons, i_trig,
+                              i_mod)

@@ -735,6 +735,100 @@ def gen_light_wvfm():
         np.savez_compressed(os.path.join(GOLD, f"light_wvfm_{cfg}_{icase}.npz"), **out)
 
 
+def gen_light_export():
+    """light_sim.export_to_hdf5 / export_light_trig_to_hdf5 / export_light_wvfm_to_hdf5 / zero_suppress_waveform_truth
+    (light_sim.py:621-757) with h5py.File replaced by an in-memory sink: what lands in light_trig, light_wvfm and
+    light_wvfm_mc_assn after two appending calls (trigger mode 0) and after the separate calls of trigger mode 1."""
+    class _DS:
+        def __init__(self, data):
+            self.a = np.array(data)
+
+        shape = property(lambda self: self.a.shape)
+
+        def resize(self, n, axis=0):
+            assert axis == 0
+            self.a = np.concatenate([self.a, np.zeros((n - self.a.shape[0],) + self.a.shape[1:], dtype=self.a.dtype)])
+
+        def __setitem__(self, k, v):
+            self.a[k] = v
+
+        def __getitem__(self, k):
+            return self.a[k]
+
+    class _File:
+        store = {}
+
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __contains__(self, name):
+            return name in self.store
+
+        def create_dataset(self, name, data=None, **k):
+            self.store[name] = _DS(data)
+
+        def __getitem__(self, name):
+            return self.store[name]
+
+    for cfg, seed in (("module0", 81), ("2x2_no_modvar", 82)):
+        ref = Ref(cfg)
+        ls, light, sim = ref.light_sim, ref.light, ref.sim
+        sim.MAX_MC_TRUTH_IDS = 3
+        sim.MOD2MOD_VARIATION = False            # the driver sets it (cli/simulate_pixels.py:387)
+        ls.h5py = types.SimpleNamespace(File=_File)
+        _File.store = {}
+        rng = np.random.default_rng(seed)
+        all_ch = light.TPC_TO_OP_CHANNEL[:].ravel()
+        ndm = 96 if light.LIGHT_TRIG_MODE == 0 else all_ch.shape[0]
+        ns, Mt = 24, 3
+        out = dict(light_trig_mode=light.LIGHT_TRIG_MODE)
+        event_times = np.array([1000.5, 3.3e5, 1.21e6, 2.6e6])
+        calls = []
+        for icall, ntrig in enumerate((2, 1)):
+            ev = np.full(ntrig, 1 + icall)
+            start = np.full(ntrig, 0.25 * icall - 1.0)
+            tidx = np.sort(rng.integers(0, 9000, ntrig))
+            opc = np.stack([all_ch[:ndm]] * ntrig)
+            wv = (rng.integers(-2000, 50, (ntrig, ndm, ns)) * 4).astype('f8')
+            tid = np.full((ntrig, ndm, ns, Mt), -1, dtype='i8'); tph = np.zeros((ntrig, ndm, ns, Mt))
+            hit = rng.random((ntrig, ndm, ns)) < 0.02
+            for it, ic, isamp in zip(*np.nonzero(hit)):
+                k = int(rng.integers(1, Mt + 1))
+                tid[it, ic, isamp, :k] = rng.integers(0, 500, k)
+                tph[it, ic, isamp, :k] = rng.uniform(0.1, 30.0, k)
+            uniq_times = event_times[np.unique(ev) % sim.MAX_EVENTS_PER_FILE]
+            i_trig = 5 + icall
+            if light.LIGHT_TRIG_MODE == 0:
+                ls.export_to_hdf5(ev, start, tidx, opc, wv, "x.h5", uniq_times, tid, tph, i_trig, -1)
+            else:
+                ls.export_light_wvfm_to_hdf5(ev, wv, "x.h5", tid, tph, i_trig, -1)
+            calls.append(dict(event_id=ev, start_times=start, trigger_idx=tidx, op_channel_idx=opc, waveforms=wv,
+                              true_track_id=tid.astype('i4'), true_photons=tph, event_times=uniq_times, i_trig=i_trig))
+        if light.LIGHT_TRIG_MODE == 1:          # the once-per-file call, cli/simulate_pixels.py:1252-1259
+            lev = np.array([0, 1, 3])
+            ls.export_light_trig_to_hdf5(lev, np.full(3, 0), np.full(3, 0), all_ch, "x.h5", lev * sim.SPILL_PERIOD)
+            out.update(trig1_event_id=lev, trig1_event_times=lev * sim.SPILL_PERIOD)
+        for i, c in enumerate(calls):
+            for k, v in c.items():
+                out[f"call{i}_{k}"] = v
+        trig = _File.store["light_trig"].a
+        out.update(light_trig_op_channel=trig["op_channel"], light_trig_ts_s=trig["ts_s"], light_trig_ts_sync=trig["ts_sync"],
+                   light_wvfm=_File.store["light_wvfm"].a)
+        assn = _File.store["light_wvfm_mc_assn"].a
+        for f in assn.dtype.names:
+            out["assn_" + f] = assn[f]
+        out["assn_dtype"] = np.array(str(assn.dtype.descr))
+        np.savez_compressed(os.path.join(GOLD, f"light_export_{cfg}.npz"), **out)
+        print("light_export", cfg, "mode", light.LIGHT_TRIG_MODE, "light_trig", trig.shape, trig.dtype, "wvfm",
+              _File.store["light_wvfm"].a.shape, "assn", assn.shape)
+
+
 def gen_packets():
     """fee.export_to_hdf5 (fee.py:84-356) on the golden chain's ADC arrays, replicated over events.  larpix-control is a
     third-party package that is not installed: its packet classes are replaced by attribute bags that record what the
@@ -878,7 +972,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     for s in a.sets.split(","):
         {"consts": gen_consts, "qd": gen_qd, "pixels": gen_pixels, "light": gen_light, "light_response": gen_light_response,
-         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs), "packets": gen_packets, "light_wvfm": gen_light_wvfm}[s]()
+         "sampled": lambda: gen_sampled(a.jobs), "chain": lambda: gen_chain(a.jobs), "packets": gen_packets, "light_wvfm": gen_light_wvfm, "light_export": gen_light_export}[s]()
     return 0
 
 

@@ -304,3 +304,39 @@ def test_config_keyword_resolution():
     # the resolved files load through the package's own YAML loader
     consts.load_properties(c["DET_PROPERTIES"], c["PIXEL_LAYOUT"], c["SIM_PROPERTIES"])
     assert consts.detector.TPC_BORDERS.shape == (8, 3, 2) and len(consts.detector.PIXEL_CONNECTION_DICT) == 4900
+
+
+@pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
+def test_light_output_datasets_golden(cfg):
+    """light_trig rows, light_wvfm and light_wvfm_mc_assn rows against what the reference's exporters (light_sim.py:621-757)
+    left in an in-memory h5py sink after their appending calls (oracle/gen_golden.py gen_light_export)."""
+    import helpers as H
+    from larndsim_amd import consts, light_sim
+    H.load_cfg(cfg)
+    consts.sim.MAX_MC_TRUTH_IDS = 3
+    g = H.gold(f"light_export_{cfg}.npz")
+    assert int(g["light_trig_mode"]) == consts.light.LIGHT_TRIG_MODE
+    trig, wv, assn = [], [], []
+    for i in range(2):
+        c = {k: g[f"call{i}_{k}"] for k in ("event_id", "start_times", "trigger_idx", "op_channel_idx", "waveforms",
+                                              "true_track_id", "true_photons", "event_times", "i_trig")}
+        if consts.light.LIGHT_TRIG_MODE == 0:
+            trig.append(light_sim.build_light_trig(c["event_id"], c["start_times"], c["trigger_idx"], c["op_channel_idx"],
+                                                   c["event_times"]))
+        wv.append(c["waveforms"])
+        assn.append(light_sim.zero_suppress_waveform_truth(c["true_track_id"].astype('i8'), c["true_photons"],
+                                                           c["event_id"][0], int(c["i_trig"]), -1))
+    if consts.light.LIGHT_TRIG_MODE == 1:
+        lev = g["trig1_event_id"]
+        trig.append(light_sim.build_light_trig(lev, np.full(3, 0), np.full(3, 0), consts.light.TPC_TO_OP_CHANNEL[:].ravel(),
+                                               g["trig1_event_times"]))
+    trig = np.concatenate(trig); assn = np.concatenate(assn)
+    assert trig.dtype["op_channel"].shape == g["light_trig_op_channel"].shape[1:]
+    assert np.array_equal(trig["op_channel"], g["light_trig_op_channel"])
+    assert np.array_equal(trig["ts_s"], g["light_trig_ts_s"]) and np.array_equal(trig["ts_sync"], g["light_trig_ts_sync"])
+    assert trig["ts_sync"].dtype == np.uint64
+    assert np.array_equal(np.concatenate(wv), g["light_wvfm"])
+    assert str(assn.dtype.descr) == str(g["assn_dtype"])
+    for f in assn.dtype.names:
+        assert np.array_equal(assn[f], g["assn_" + f]), f
+    assert len(assn) > 100 and len(np.unique(assn["trigger_id"])) > 2

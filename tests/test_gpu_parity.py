@@ -1489,6 +1489,25 @@ def test_cli_light_leg(tmp_path):
     assert (dat["n_photons_det"] > 0).any() and np.array_equal(dat["segment_id"][:, 0], out["segments"]["segment_id"])
     inc = out["light_sample_inc"]
     assert inc.shape[0] == res["n_batches"] and inc.sum() > 0
+    # the waveform chain: one light_wvfm row per trigger (threshold mode: also one light_trig row), LSB-quantised samples;
+    # (event, TPC group) combinations without segments contribute the reference's "null" waveform of an empty response
+    light = consts.light
+    wv, trig = out["light_wvfm"], out["light_trig"]
+    ns = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING))
+    assert wv.shape[1:] == (light.N_OP_CHANNEL, ns) and wv.shape[0] == res["n_light_triggers"] == trig.shape[0] >= 2
+    lsb = 2.0 ** (16 - light.LIGHT_NBIT)
+    assert np.array_equal(wv, np.round(wv / lsb) * lsb) and (wv != 0).any()
+    assert trig["op_channel"].shape == (wv.shape[0], light.N_OP_CHANNEL) and (np.diff(trig["ts_s"]) >= 0).all()
+    # with a detector-noise spectrum file every sample carries noise, reproducibly for a seed
+    noise = np.abs(np.random.default_rng(3).normal(0, 4000.0, (light.N_OP_CHANNEL, 65)))
+    np.save(tmp_path / "noise.npy", noise)
+    runs = []
+    for i in range(2):
+        cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / f"outn{i}.npz"), config="module0", rand_seed=1,
+                           light_lut_filename=str(tmp_path / "lut.npz"), light_det_noise_filename=str(tmp_path / "noise.npy"))
+        runs.append(np.load(tmp_path / f"outn{i}.npz")["light_wvfm"])
+    assert np.array_equal(runs[0], runs[1]) and runs[0].shape == wv.shape
+    assert (runs[0] != 0).mean() > 0.5 and (runs[0] - wv).std() > 4 * lsb
 
 
 def test_cli_pixel_threshold_and_gain_files(tmp_path):
