@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "ldsim_dev.h"
@@ -43,7 +44,6 @@ int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
 int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
                      int32_t*, int64_t*, int64_t);
 int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
-int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*);
 int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
                       const double*, int, int64_t, int32_t*);
 // chain glue implemented in chain.hip (needs the kernel argument structs)
@@ -143,6 +143,15 @@ static int make_gl_tables(ldsim_ctx* ctx, int nmax) {
 }
 
 // ---- context ------------------------------------------------------------------------------------------------------
+static int ctx_init(ldsim_ctx* ctx, const LdsimConsts* consts) {
+  HIPCHK(hipStreamCreate(&ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
+  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->evl[i]));
+  CK(make_gl_tables(ctx, 256));
+  return ldsim_set_consts(ctx, consts);
+}
+
 extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx** out) {
   NEED(consts && out, "null argument");
   int n = 0;
@@ -151,16 +160,18 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
     return LDSIM_ENODEV;
   }
   NEED(device >= 0 && device < n, "device index out of range");
+  *out = nullptr;
   HIPCHK(hipSetDevice(device));
-  ldsim_ctx* ctx = new ldsim_ctx();
+  ldsim_ctx* ctx = new (std::nothrow) ldsim_ctx();
+  NEED(ctx, "out of host memory");
   ctx->device = device;
-  HIPCHK(hipStreamCreate(&ctx->stream));
-  HIPCHK(hipMalloc((void**)&ctx->d_consts, sizeof(LdsimConsts)));
-  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
-  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->evl[i]));
-  CK(make_gl_tables(ctx, 256));
+  const int rc = ctx_init(ctx, consts);
+  if (rc) {                                  // nothing half-built is handed out or left behind
+    (void)ldsim_ctx_destroy(ctx);
+    return rc;
+  }
   *out = ctx;
-  return ldsim_set_consts(ctx, consts);
+  return 0;
 }
 
 extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
@@ -178,7 +189,7 @@ extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
 extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
                   ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p,  ctx->d_pix_thr, ctx->d_pix_gain,
                   ctx->d_glx, ctx->d_glw};
@@ -191,7 +202,9 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   for (int i = 0; i < 4; i++)
     if (ctx->evl[i]) (void)hipEventDestroy(ctx->evl[i]);
   for (DevBuf* b : {&ctx->light_nph, &ctx->light_t0, &ctx->light_vox, &ctx->light_out, &ctx->light_tid, &ctx->light_tph,
-                    &ctx->light_opc, &ctx->light_trk})
+                    &ctx->light_opc, &ctx->light_trk, &ctx->light_scint, &ctx->light_scint_tid, &ctx->light_scint_tph,
+                    &ctx->light_disc, &ctx->light_resp, &ctx->light_resp_tid, &ctx->light_resp_tph, &ctx->light_w[0],
+                    &ctx->light_w[1], &ctx->light_gain})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);
@@ -199,7 +212,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   if (ctx->d_rng.p) (void)hipFree(ctx->d_rng.p);
   for (DevBuf* b : {&ctx->comm_tmp, &ctx->hits_acc, &ctx->hits_all})
     if (b->p) (void)hipFree(b->p);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
 }

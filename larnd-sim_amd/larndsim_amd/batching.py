@@ -37,43 +37,9 @@ def select_active_volume(track_seg, tpc_borders, i_module=-1):
     return np.nonzero(mask)[0]
 
 
-class TPCBatcher:
-    """Iterator of (event_id, bool mask) -- same sequence as the reference's TPCBatcher, empty masks included."""
-
-    def __init__(self, all_track_seg, track_seg, event_separator, tpc_batch_size=1, tpc_borders=None):
-        self.track_seg = track_seg
-        self.sep = event_separator
-        self.tpc_batch_size = tpc_batch_size
-        self.tpc_borders = np.sort(np.asarray(tpc_borders), axis=-1)
-        self._simulated = np.zeros(track_seg.shape[0], dtype=bool)
-        self._events = np.unique(all_track_seg[event_separator])
-        self._curr_event = 0
-        self._curr_tpc = 0
-
-    def __len__(self):
-        return len(self._events) * int(np.ceil(self.tpc_borders.shape[0] / self.tpc_batch_size))
-
-    def __iter__(self):
-        return self
-
-    def __next__(self):
-        if self._curr_tpc >= self.tpc_borders.shape[0]:
-            self._curr_event += 1
-            self._curr_tpc = 0
-        if self._curr_event >= len(self._events):
-            raise StopIteration
-        mask = ~self._simulated & (self.track_seg[self.sep] == self._events[self._curr_event])
-        tpc_mask = np.zeros_like(mask)
-        hi = min(self._curr_tpc + self.tpc_batch_size, self.tpc_borders.shape[0])
-        tpc_mask[select_active_volume(self.track_seg, self.tpc_borders[self._curr_tpc:hi])] = True
-        self._curr_tpc += self.tpc_batch_size
-        mask &= tpc_mask
-        self._simulated |= mask
-        return self._events[self._curr_event], mask
-
-
 def assign_batches(tracks, tpc_borders=None, event_separator=None, tpc_batch_size=None, batch_size=None):
-    """Vectorised equivalent of iterating TPCBatcher + the BATCH_SIZE sub-batch loop.
+    """Vectorised equivalent of iterating the reference's TPCBatcher (larndsim/util/batching.py:17-67) + the BATCH_SIZE
+    sub-batch loop (tests/helpers.py holds the loop form it is checked against).
 
     Returns (batch_id int32[n], order int64[n], table) where ``batch_id[i]`` is the index of the
     non-empty (event, TPC-group, sub-batch) batch segment i is simulated in (-1 if in no batch),

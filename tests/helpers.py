@@ -115,3 +115,20 @@ def det_phases(shape, seed):
     h ^= h >> np.uint64(15)
     h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
     return h.astype(np.float64) / 4294967296.0
+
+
+def batch_sequence(all_seg, seg, separator, tpc_batch_size, tpc_borders):
+    """(event id, bool mask) in the order the reference's batch loop visits them (larndsim/util/batching.py:40-67): events
+    ascending, TPC groups in index order, a segment belongs to the first group that holds one of its end points; empty
+    masks included.  The checker of batching.assign_batches."""
+    from larndsim_amd import batching
+    borders = np.sort(np.asarray(tpc_borders), axis=-1)
+    taken = np.zeros(seg.shape[0], dtype=bool)
+    for ev in np.unique(all_seg[separator]):
+        in_event = seg[separator] == ev
+        for first in range(0, borders.shape[0], tpc_batch_size):
+            inside = np.zeros(seg.shape[0], dtype=bool)
+            inside[batching.select_active_volume(seg, borders[first:first + tpc_batch_size])] = True
+            mask = in_event & inside & ~taken
+            taken |= mask
+            yield ev, mask

@@ -17,6 +17,24 @@ def _free_port():
     return p
 
 
+def _allgather_rows(rows):
+    """CPU rehearsal of csrc/comm.hip's all-gather-v: the row counts first, then the payload of every rank; returns the
+    rows of rank 0, 1, .. back to back and the counts."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    parts = []
+    for r in range(world):                                      # one broadcast per rank, as the grouped ncclBroadcasts do
+        buf = rows.clone() if r == dist.get_rank() else torch.zeros((counts[r], rows.shape[1]), dtype=rows.dtype)
+        dist.broadcast(buf, src=r)
+        parts.append(buf)
+    return torch.cat(parts, dim=0), counts
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(REPO, "larnd-sim_amd"))
     import torch
@@ -34,7 +52,7 @@ def _worker(rank, world, port, q):
     rows = torch.zeros((len(idx), 6), dtype=torch.int32)
     rows[:, 0] = torch.from_numpy(my_bid.astype(np.int32))
     rows[:, 1] = torch.from_numpy(idx.astype(np.int32))
-    gathered, counts = ldist.allgather_rows(rows)
+    gathered, counts = _allgather_rows(rows)
     t = torch.tensor([float(len(idx))], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     q.put((rank, idx, gathered.numpy(), counts, float(t.item()), int((bid >= 0).sum())))

@@ -96,7 +96,7 @@ def test_snapshot_values_appendix_b():
     assert c.n_tpc == 70 and c.n_time_ticks == 3201 and c.tpc_borders[69][2][0] == consts.detector.TPC_BORDERS[69][2][0]
 
 
-def test_batching_matches_tpcbatcher_iteration():
+def test_batching_matches_the_reference_batch_loop():
     consts.load_snapshot("2x2_no_modvar")
     seg = synth.make_segments(6000, seed=4, segs_per_event=1500, spill=True)
     # a few segments outside every TPC and one straddling two TPC groups
@@ -106,8 +106,7 @@ def test_batching_matches_tpcbatcher_iteration():
         bid, order, table = batching.assign_batches(seg, tpc_batch_size=tbs, batch_size=bs)
         ref = np.full(len(seg), -1)
         k = 0
-        for ev, mask in batching.TPCBatcher(seg, seg, "event_id", tpc_batch_size=tbs,
-                                            tpc_borders=consts.detector.TPC_BORDERS):
+        for ev, mask in H.batch_sequence(seg, seg, "event_id", tbs, consts.detector.TPC_BORDERS):
             idx = np.flatnonzero(mask)
             for o in range(0, len(idx), bs):
                 ref[idx[o:o + bs]] = k

@@ -5,6 +5,8 @@ GPU parity: the HIP path (through the C-ABI, via the reference-named Python wrap
 Integer / index outputs bit-exact; f64 per-segment outputs to 1e-13; induced current and ADC
 values within 1e-5 relative (tolerance of BASELINE.json's north_star) + 1e-7 of the waveform peak.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -38,9 +40,9 @@ def test_quench_drift_golden(cfg):
             H.round_f4(r, ["n_photons"])
             drifting.drift[4, 256](r)
             assert np.array_equal(r["pixel_plane"], g["drift_pixel_plane"])
-            # lifetime exp() is ocml vs libm: allow a 1-electron truncation flip on at most a few segments
-            d = np.abs(r["n_electrons"].astype(np.int64) - g["drift_n_electrons"].astype(np.int64))
-            assert d.max() <= 1 and (d != 0).sum() <= 2
+            # exact: the lifetime factor exp() is ocml here and libm in the reference, but an ulp of it moves
+            # n_e * exp(..) (~1e4..1e5) by ~1e-11, so the u4 truncation flips for about one segment in 1e11
+            assert np.array_equal(r["n_electrons"], g["drift_n_electrons"])
             for f in ("long_diff", "tran_diff", "t", "t_start", "t_end"):
                 np.testing.assert_allclose(r[f], g["drift_" + f], rtol=1e-13, atol=0, err_msg=f)
 
@@ -57,8 +59,7 @@ def test_quench_drift_152B_schema_vs_oracle(cfg):
     O.quench(b, consts.physics.BIRKS)
     O.drift(b)
     assert np.array_equal(a["pixel_plane"], b["pixel_plane"])
-    d = np.abs(a["n_electrons"].astype(np.int64) - b["n_electrons"].astype(np.int64))
-    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert np.array_equal(a["n_electrons"], b["n_electrons"])          # u4 truncation included (see the golden test)
     for f in ("n_photons", "long_diff", "tran_diff", "t", "t_start", "t_end"):
         np.testing.assert_allclose(a[f], b[f], rtol=2e-7, atol=0, err_msg=f)   # f4 fields: <= 1 ulp
     for f in seg.dtype.names:
@@ -983,6 +984,43 @@ def test_resident_light_waveform_chain_vs_oracle():
     assert np.array_equal(d_h, d)
     ms = ch.light_response_ms()
     assert all(v > 0 for v in ms.values())
+
+
+def test_compact_hit_rows_decode_to_the_downloaded_arrays():
+    """The 24-byte rows the multi-GPU exchange moves ({batch, pixel, adc, slot, tick}: ldsim_chain_compact_hits ->
+    ldsim_hits_accumulate -> ldsim_comm_allgather_hits -> ldsim_comm_gathered_download, here through a one-rank RCCL
+    communicator) hold exactly the written slots of ldsim_chain_download, over two chain launches."""
+    from larndsim_amd.comm import Communicator
+    H.load_cfg("module0")
+    seg = synth.make_segments(600, seed=31, segs_per_event=200)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    nsim = int((bid >= 0).sum())
+    ch = ChargeChain(synth.make_response("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    cm = Communicator(ch.ctx, 0, 1)
+    try:
+        cut = int(np.searchsorted(bid[:nsim], 2))
+        want = []
+        for i, (b0, b1) in enumerate(((0, cut), (cut, nsim))):
+            ch.run(b0, b1)
+            res = ch.download()
+            assert ch.compact_hits()[1] == int((res["adc_list"] != 0).sum()) and ch.compact_hits()[2] == 24
+            cm.accumulate_hits(reset=(i == 0))
+            u, h = np.nonzero(res["adc_list"] != 0)
+            want.append(np.stack([res["batch"][u], res["unique_pix"][u], res["adc_digit"][u, h].astype(np.int64), h,
+                                  res["adc_ticks_list"][u, h].view(np.int64)], axis=1))
+        want = np.concatenate(want)
+        total, counts, rows = cm.allgather_hits(download=True)
+        assert total == len(want) == counts[0] and total > 50
+        got = np.stack([rows["batch"], rows["pixel"], rows["adc"], rows["slot"], rows["tick"].view(np.int64)], axis=1)
+        assert np.array_equal(got, want)
+        assert cm.allreduce(3.5, "max") == 3.5 and cm.allreduce(2.0) == 2.0
+    finally:
+        cm.destroy()
 
 
 def test_stage_call_between_upload_and_run_is_refused():
