@@ -22,7 +22,7 @@
 #define Q_CELLS 512       // response cells per group
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 3) qweights_kernel(SplitArgs S, const PairParams* __restrict__ pp,
+__global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, const PairParams* __restrict__ pp,
                                                                   const double* __restrict__ glx,
                                                                   const double* __restrict__ glw) {
   const CurArgs& A = S.c;

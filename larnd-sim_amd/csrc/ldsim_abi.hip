@@ -204,7 +204,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   for (DevBuf* b : {&ctx->light_nph, &ctx->light_t0, &ctx->light_vox, &ctx->light_out, &ctx->light_tid, &ctx->light_tph,
                     &ctx->light_opc, &ctx->light_trk, &ctx->light_scint, &ctx->light_scint_tid, &ctx->light_scint_tph,
                     &ctx->light_disc, &ctx->light_resp, &ctx->light_resp_tid, &ctx->light_resp_tph, &ctx->light_w[0],
-                    &ctx->light_w[1], &ctx->light_gain})
+                    &ctx->light_w[1], &ctx->light_gain, &ctx->resp_pad})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);
@@ -236,6 +236,10 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     if (!(value == 0 || value == 1)) { ldsim_set_error("weights_mode must be 0 or 1"); return LDSIM_EINVAL; }
     ctx->weights_mode = (int)value;
     ctx->wbuf_learned = 0;
+  }
+  else if (!strcmp(name, "mac_mode")) {
+    if (!(value == 0 || value == 1)) { ldsim_set_error("mac_mode must be 0 or 1"); return LDSIM_EINVAL; }
+    ctx->mac_mode = (int)value;
   }
   else if (!strcmp(name, "numba_f32")) ctx->numba_f32 = value != 0;
   else if (!strcmp(name, "mc_current")) ctx->mc_current = value != 0;
@@ -318,6 +322,7 @@ extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_
   if (last < first) { first = 0; last = -1; }
   ctx->resp_k_first = first;
   ctx->resp_k_last = last;
+  ctx->resp_pad_hi = -2;                     // the padded copy of mac_shift_kernel is rebuilt on the next launch
   return 0;
 }
 

@@ -31,5 +31,10 @@ struct SplitArgs {
   double* wbuf;           // weight arena
   unsigned long long wbuf_cap;   // doubles
   unsigned long long* cursor;    // bump allocator (doubles)
+  // response rows with RESP_PAD zeros on either side and zeros outside the staged range [k_lo, k_hi] (mac_shift_kernel):
+  // element k of cell c sits at resp_pad[c * nkp + RESP_PAD + k], so a row window needs no range checks
+  const double* resp_pad;
+  int32_t nkp, k_lo, k_hi;
 };
+#define RESP_PAD 640
 

@@ -1280,7 +1280,7 @@ def _two_event_set(cfg, seed, n=1200):
 
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 1), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
-                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0)):
+                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0), ("mac_mode", 1)):
         lib.set_option(name, v)
 
 
@@ -1330,6 +1330,32 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
         assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
         assert np.array_equal(a["adc_digit"], b["adc_digit"])
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("kind", ["survey", "dense"])
+def test_mac_shift_kernel_is_bitwise_the_lds_kernel(kind):
+    """mac_shift_kernel (M = 1 default: window slid through the wave with DPP shifts, weights through the scalar cache,
+    zero-padded response rows) against mac_kernel<1> (rows staged in LDS): same products in the same order, so every
+    output is bit-identical -- incl. waveform windows that hang over either end of the response support (survey table:
+    support narrower than a tile) and pairs whose items fill all 8 blocks."""
+    H.load_cfg("module0")
+    seg, bid = _two_event_set("module0", 35)
+    ch = ChargeChain(H.response_for(kind))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    res = {}
+    try:
+        for mode in (1, 0):
+            lib.set_option("mac_mode", mode)
+            ch.run(0, len(seg), want_fractions=True)
+            res[mode] = ch.download()
+    finally:
+        lib.set_option("mac_mode", 1)
+    assert (res[1]["adc_list"] != 0).sum() > 100
+    for k in res[1]:
+        assert np.array_equal(res[1][k], res[0][k]), k
+    with pytest.raises(lib.LdsimError, match="mac_mode"):
+        lib.set_option("mac_mode", 2)
 
 
 @pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("ndlar", "golden")])
