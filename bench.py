@@ -250,13 +250,14 @@ def main():
         value = n_job * a.steps / elapsed
         split = acc["w_ms"] > 0
         M = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
+        mac_name = "mac_shift_kernel" if M == 1 else f"mac_kernel<{M}>"       # csrc/kernels_macshift.hip / kernels_split.hip
         # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
         elif acc["w_ms"] >= acc["m_ms"]:
             dom_name, dom_ms = f"qweights_kernel<{M}>", acc["w_ms"]
         else:
-            dom_name, dom_ms = f"mac_kernel<{M}>", acc["m_ms"]
+            dom_name, dom_ms = mac_name, acc["m_ms"]
         dom_s = dom_ms * 1e-3
         achieved = acc["bytes"] / dom_s / 1e9 if dom_s > 0 else 0.0
         mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
@@ -297,7 +298,7 @@ def main():
                                            "current_kernel_ms_avg": acc["f_ms"] / nl,
                                            "pixel_adc_kernel_ms_avg": acc["adc_ms"] / nl,
                                            "quadrature_nodes_per_pair": acc["samples"] / max(acc["pairs"], 1)},
-                         "valu_f64": {"kernel": f"mac_kernel<{M}>" if split else f"current_kernel<{M}>",
+                         "valu_f64": {"kernel": mac_name if split else f"current_kernel<{M}>",
                                       "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                                       "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},

@@ -171,6 +171,162 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift_kernel(SplitArgs S) 
   if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
 }
 
+// ---- M = 2 (TIME_SAMPLING = 2 RESPONSE_SAMPLING, ndlar): tick t of lane L reads R[kb + 16L + 2j + u] -------------------------
+// Chunks of 8 row elements c_k(L) = R[kb + 16L + 8k ..]; block b needs c_b ++ c_{b+1} ++ c_{b+2} and the next chunk is
+// c_{b+3}(L) = c_{b+1}(L + 1): the same whole-wave shift, four register sets in rotation.  The first two chunks of an item
+// are loaded (the lane's own 16 elements, one coalesced 8 KB read per wave), c_2 is the first shift.  Item descriptors are
+// read through the scalar cache straight from HBM (the list is up to 32 KB per pair at M = 2, too much LDS).
+typedef const Item __attribute__((address_space(4)))* iconst_ptr;
+
+__global__ void __launch_bounds__(CUR_THREADS, 3) mac_shift2_kernel(SplitArgs S) {
+  const CurArgs& A = S.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  const int32_t* hdr = S.hdr + pair * HDR_INTS;
+  if (hdr[7]) return;                               // overflowed: the monolithic kernel writes this pair
+  float* out = A.out + pair * (int64_t)A.T;
+  const int n_items = hdr[0], n_corr = hdr[1], it0 = hdr[2], T = hdr[3], it_w0 = hdr[4], it_w1 = hdr[5];
+  if (n_items <= 0 || it_w1 <= it_w0) {
+    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
+    return;
+  }
+  __shared__ double s_out[TILE_TICKS];
+  __shared__ double s_tail[NWAVE][64 + 8];          // wave-private: row elements past the tile, for lane 63
+  iconst_ptr gitems = (iconst_ptr)(S.items + pair * (int64_t)ItemCap<2>::value);
+  unsigned long long n_blocks = 0;
+
+  for (int sup0 = it_w0; sup0 < it_w1; sup0 += TILE_TICKS) {
+    const int wlen = min(it_w1 - sup0, TILE_TICKS);
+    const int ntt = (wlen + WTILE - 1) / WTILE;
+    int my_tile, share_rank, nshare;
+    if (ntt >= 3) { my_tile = wv; share_rank = 0; nshare = 1; }
+    else if (ntt == 2) { my_tile = wv >> 1; share_rank = wv & 1; nshare = 2; }
+    else { my_tile = 0; share_rank = wv; nshare = 4; }
+    const bool tile_live = my_tile < ntt;
+    const int tb = sup0 + my_tile * WTILE;
+    double acc[TPL];
+#pragma unroll
+    for (int j = 0; j < TPL; j++) acc[j] = 0;
+
+    if (tile_live) {
+      double* tl = s_tail[wv];
+      auto descriptor = [&](int li) {
+        Item d;
+        d.cell_nblk = gitems[li].cell_nblk;
+        d.sbase = gitems[li].sbase;
+        d.woff_lo = gitems[li].woff_lo;
+        d.woff_hi = gitems[li].woff_hi;
+        return d;
+      };
+      auto fetch = [&](const Item& itx, double (&c0)[8], double (&c1)[8], double& ct) {
+        const int nblk = (itx.cell_nblk >> 16) & 0xFF;
+        int kb = 2 * tb + itx.sbase;
+        kb = max(-RESP_PAD, min(kb, S.nkp - RESP_PAD - (2 * WTILE + 64)));       // see mac_shift_kernel
+        const int cell = (A.debug_phases & 0x4000) ? 0 : (itx.cell_nblk & 0xFFFF);       // 0x4000: timing tools
+        const double* src = S.resp_pad + (int64_t)cell * S.nkp + (RESP_PAD + kb);
+#pragma unroll
+        for (int q = 0; q < 8; q++) c0[q] = src[16 * lane + q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) c1[q] = src[16 * lane + 8 + q];
+        ct = (lane < nblk * 8) ? src[2 * WTILE + lane] : 0.0;
+      };
+      // one 8-shift block on the window lo ++ mid ++ hi (tick j, shift u reads element 2j + u); with `more`, dst becomes
+      // the chunk after hi = the next lane's chunk `mid`
+      auto block = [&](double (&lo)[8], double (&mid)[8], double (&hi)[8], double (&dst)[8], wconst_ptr w, const double* tnext,
+                       bool more) {
+#pragma unroll
+        for (int du = 0; du < 8; du++) {
+          const double av = w[du];
+#pragma unroll
+          for (int j = 0; j < TPL; j++) {
+            const int e = 2 * j + du;
+            acc[j] = fma(av, e < 8 ? lo[e] : (e < 16 ? mid[e - 8] : hi[e - 16]), acc[j]);
+          }
+        }
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) dst[q] = wave_shl1(tnext[q], mid[q]);
+        }
+      };
+      Item d_cur{}, d_next{};
+      double p0[8], p1[8], n0[8], n1[8], t0 = 0, t1 = 0;
+      auto run_item = [&](double (&a)[8], double (&b)[8], double& tcur, double (&na)[8], double (&nb)[8], double& tnxt, int li) {
+        const int nblk = (d_cur.cell_nblk >> 16) & 0xFF;
+        const unsigned long long wo = ((unsigned long long)d_cur.woff_hi << 32) | (unsigned long long)d_cur.woff_lo;
+        wconst_ptr w = (wconst_ptr)(S.wbuf + wo);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        tl[lane] = tcur;                                       // tl[l] = row element 1024 + l; chunk k of lane 63 = tl[8(k-2) ..]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (li + nshare < n_items) fetch(d_next, na, nb, tnxt);
+        d_cur = d_next;
+        if (li + 2 * nshare < n_items) d_next = descriptor(li + 2 * nshare);
+        double c[8], d[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) c[q] = wave_shl1(tl[q], a[q]);          // chunk 2 = the next lane's chunk 0
+        int blk = 0;
+        // block blk shifts in chunk blk + 3 = tl[8(blk+1) ..] for lane 63
+        for (; blk + 3 < nblk; blk += 4) {
+          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
+          block(b, c, d, a, w + 8 * (blk + 1), tl + 8 * (blk + 2), true);
+          block(c, d, a, b, w + 8 * (blk + 2), tl + 8 * (blk + 3), true);
+          block(d, a, b, c, w + 8 * (blk + 3), tl + 8 * (blk + 4), blk + 4 < nblk);
+        }
+        const int rem = nblk - blk;
+        if (rem == 1) {
+          block(a, b, c, d, w + 8 * blk, tl, false);
+        } else if (rem == 2) {
+          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
+          block(b, c, d, a, w + 8 * (blk + 1), tl, false);
+        } else if (rem == 3) {
+          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
+          block(b, c, d, a, w + 8 * (blk + 1), tl + 8 * (blk + 2), true);
+          block(c, d, a, b, w + 8 * (blk + 2), tl, false);
+        }
+        n_blocks += nblk;
+      };
+      if (share_rank < n_items) {
+        d_cur = descriptor(share_rank);
+        fetch(d_cur, p0, p1, t0);
+      }
+      if (share_rank + nshare < n_items) d_next = descriptor(share_rank + nshare);
+      for (int li = share_rank; li < n_items; li += 2 * nshare) {
+        run_item(p0, p1, t0, n0, n1, t1, li);
+        if (li + nshare < n_items) run_item(n0, n1, t1, p0, p1, t0, li + nshare);
+      }
+    }
+    // ---- combine waves sharing a tile, window-edge corrections, mask, f32 store (as mac_kernel) -------------------------
+    for (int rnk = 0; rnk < nshare; rnk++) {
+      __syncthreads();
+      if (tile_live && share_rank == rnk) {
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+          const int idx = my_tile * WTILE + TPL * lane + j;
+          s_out[idx] = (rnk == 0) ? acc[j] : s_out[idx] + acc[j];
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const Corr* cr = S.corr + pair * CMAX;
+      for (int k = tid; k < n_corr; k += CUR_THREADS) {
+        int i = cr[k].tick - sup0;
+        if (i >= 0 && i < wlen) atomicAdd(&s_out[i], -cr[k].val);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < wlen; i += CUR_THREADS) {
+      int it = sup0 + i;
+      if (it < A.T) out[it] = (it >= it0 && it < T) ? (float)s_out[i] : 0.f;
+    }
+    __syncthreads();
+  }
+  for (int it = tid; it < A.T; it += CUR_THREADS)
+    if (it < it_w0 || it >= it_w1) out[it] = 0.f;
+  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+}
+
 // rows of the response table with RESP_PAD zeros in front and behind, and zeros where mac_kernel's staging would put them
 // (outside [k_lo, k_hi]: the part of the table's support a tick of the window can meet)
 __global__ void __launch_bounds__(256) pad_response_kernel(const double* __restrict__ resp, int64_t n_cells, int nk, int nkp,
@@ -182,7 +338,7 @@ __global__ void __launch_bounds__(256) pad_response_kernel(const double* __restr
   out[i] = (k >= k_lo && k <= k_hi && k >= 0 && k < nk) ? resp[c * nk + k] : 0.0;
 }
 
-extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S) {
+extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S, int M) {
   const CurArgs& A = S.c;
   const LdsimConsts& h = ctx->h_consts;
   // the staged range of mac_kernel (kernels_split.hip): response support met by the window, incl. the partially valid edges
@@ -214,7 +370,8 @@ extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S) {
   S.nkp = nkp;
   S.k_lo = k_lo;
   S.k_hi = k_hi;
-  hipLaunchKernelGGL(mac_shift_kernel, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
+  if (M == 2) hipLaunchKernelGGL(mac_shift2_kernel, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
+  else hipLaunchKernelGGL(mac_shift_kernel, dim3((unsigned)S.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -714,7 +714,7 @@ static SplitArgs split_args(const CurArgs& args, void* items, void* hdr, void* c
   return S;
 }
 
-extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S);
+extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S, int M);
 
 // returns 0 = launched, 1 = not covered by the split path, < 0 = error
 extern "C++" int split_launch_weights(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr, void* corr, double* wbuf,
@@ -740,7 +740,7 @@ extern "C++" int split_launch_mac(ldsim_ctx* ctx, const CurArgs& args, void* ite
   const int M = split_M(ctx, args);
   if (!M) return 1;
   SplitArgs S = split_args(args, items, hdr, corr, wbuf, wbuf_cap, cursor);
-  if (M == 1 && ctx->mac_mode) return mac_shift_launch(ctx, S);      // kernels_macshift.hip
+  if (ctx->mac_mode) return mac_shift_launch(ctx, S, M);            // kernels_macshift.hip
   if (M == 1) hipLaunchKernelGGL(mac_kernel<1>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   else hipLaunchKernelGGL(mac_kernel<2>, dim3((unsigned)args.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, S);
   HIPCHK(hipGetLastError());

@@ -36,5 +36,5 @@ struct SplitArgs {
   const double* resp_pad;
   int32_t nkp, k_lo, k_hi;
 };
-#define RESP_PAD 640
+#define RESP_PAD 1280       // >= M * WTILE + 64 + slack for M <= 2
 

@@ -1332,14 +1332,14 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("kind", ["survey", "dense"])
-def test_mac_shift_kernel_is_bitwise_the_lds_kernel(kind):
-    """mac_shift_kernel (M = 1 default: window slid through the wave with DPP shifts, weights through the scalar cache,
-    zero-padded response rows) against mac_kernel<1> (rows staged in LDS): same products in the same order, so every
-    output is bit-identical -- incl. waveform windows that hang over either end of the response support (survey table:
-    support narrower than a tile) and pairs whose items fill all 8 blocks."""
-    H.load_cfg("module0")
-    seg, bid = _two_event_set("module0", 35)
+@pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("module0", "dense"), ("ndlar", "golden"), ("ndlar", "dense")])
+def test_mac_shift_kernel_is_bitwise_the_lds_kernel(cfg, kind):
+    """mac_shift_kernel / mac_shift2_kernel (default: window slid through the wave with DPP shifts, weights through the
+    scalar cache, zero-padded response rows) against mac_kernel<M> (rows staged in LDS), M = 1 (module0) and M = 2 (ndlar):
+    same products in the same order, so every output is bit-identical -- incl. waveform windows that hang over either end
+    of the response support (survey table: support narrower than a tile) and pairs whose items fill all 8 blocks."""
+    H.load_cfg(cfg)
+    seg, bid = _two_event_set(cfg, 35)
     ch = ChargeChain(H.response_for(kind))
     ch.upload(seg, bid)
     ch.quench_drift()

@@ -21,7 +21,7 @@ ch.quench_drift()
 ch.run(0, len(seg), want_fractions=True)
 for mode in (1, 0):
     lib.set_option("mac_mode", mode)
-    for mask in (15, 15 | 0x1000, 15 | 0x2000, 15 | 0x4000, 15 | 0x5000, 15):
+    for mask in ((15, 15 | 0x1000, 15 | 0x2000, 15 | 0x4000, 15 | 0x5000, 15) if mode else (15,)):
         lib.set_option("debug_phases", mask)
         ch.run(0, len(seg), want_fractions=True)
         ms = ch.kernel_ms()
