@@ -65,6 +65,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   __shared__ unsigned long long s_base64;
 
   // ---- sample -> response cell maps; member lists ordered by response index (x: wave 0, y: wave 1) ----------------
+  // (lane values are fetched with v_readlane -- the lane index is the loop counter, wave-uniform -- not with a shuffle through
+  // the LDS crossbar, whose latency a non-unrolled loop pays on every iteration)
   if (wv == 0) {
     int i = -1;
     double ddx = 0;
@@ -81,14 +83,14 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     }
     int leader = lane;
     for (int q = 0; q < NS; q++) {
-      int iq = __shfl(i, q);
+      int iq = __builtin_amdgcn_readlane(i, q);
       if (q < leader && iq == i) leader = q;
     }
     bool is_leader = (lane < NS) && (i >= 0) && (leader == lane);
     int slot = 0;   // rank of this column's i among the distinct i  -> cells come out sorted by (i, j)
     for (int q = 0; q < NS; q++) {
-      int iq = __shfl(i, q);
-      bool lq = __shfl((int)is_leader, q);
+      int iq = __builtin_amdgcn_readlane(i, q);
+      bool lq = __builtin_amdgcn_readlane((int)is_leader, q);
       if (lq && iq < i) slot++;
     }
     int myslot = (i < 0 || lane >= NS) ? -1 : slot;
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     if (is_leader) s_coli[slot] = (short)i;
     int posn = 0;
     for (int q = 0; q < NS; q++) {
-      int sq = __shfl(myslot, q);
+      int sq = __builtin_amdgcn_readlane(myslot, q);
       if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
     }
     if (myslot >= 0) s_ixord[posn] = (unsigned char)lane;
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     // members of one j are contiguous in s_iyord; s_jstart[j'] = number of valid samples with j < jmin + j'
     int posn = 0, below = 0;
     for (int q = 0; q < NS; q++) {
-      int jq = __shfl(j, q);
+      int jq = __builtin_amdgcn_readlane(j, q);
       if (jq >= 0 && j >= 0 && (jq < j || (jq == j && q < lane))) posn++;
       if (jq >= 0 && jq < jmin + lane) below++;
     }
@@ -221,11 +223,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
       unsigned long long fm = __ballot(fits);
       int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
-      int lo = __shfl(pmin, n - 1), hi = __shfl(pmax, n - 1);
+      int lo = __builtin_amdgcn_readlane(pmin, n - 1), hi = __builtin_amdgcn_readlane(pmax, n - 1);
       // slices of the chunk ordered by shift (|z - z_anode| need not be monotone in iz): s_zord, s_ustart[u]
       int posn = 0, below = 0, anyinv = 0;
       for (int q = 0; q < n; q++) {
-        int sq = __shfl(sh, q);
+        int sq = __builtin_amdgcn_readlane(sh, q);
         if (lane < n && (sq < sh || (sq == sh && q < lane))) posn++;
         if (sq < lo + lane) below++;
       }
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
             s_boff[cell] = (unsigned short)(nblk_tot + sc - nb8);
           }
           nact += __popcll(am);
-          nblk_tot += __shfl(sc, 63);
+          nblk_tot += __builtin_amdgcn_readlane(sc, 63);
         }
         if (lane == 0) {
           s_misc[6] = nact;
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
           const int item_cap = (A.split_max_items > 0 && A.split_max_items < IMAX) ? A.split_max_items : IMAX;
           bool ok = (have + nact <= item_cap) && !s_misc[18];
           if (ok && need) {
-            base = atomicAdd(S.cursor, need);
+            base = atomicAdd(S.cursor, need);        // (its round trip is not what the kernel waits for: measured, < 1 %)
             if (base + need > S.wbuf_cap) ok = false;
           }
           if (!ok) s_misc[18] = 1;

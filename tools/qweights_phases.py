@@ -18,7 +18,7 @@ ch.upload(seg, bid)
 ch.quench_drift()
 lib.set_option("weights_mode", 1)
 ch.run(0, len(seg), want_fractions=True)
-for mask in (15, 0x100, 0x200, 0, 1, 2, 4, 8, 3, 7, 11, 15):
+for mask in (15, 0x100, 0x200, 0x400, 0, 1, 2, 4, 8, 3, 7, 11, 15):
     lib.set_option("debug_phases", mask)
     ch.run(0, len(seg), want_fractions=True)
     ms = ch.kernel_ms()
