@@ -10,8 +10,10 @@ triggers -> digitised waveforms with detector noise] -> charge chain with FEE no
 batch -> output file (HDF5 when h5py is importable, else .npz with the same dataset names) with the updated segments,
 light_dat, light_trig, light_wvfm, light_wvfm_mc_assn and the truth datasets of the input passed through.
 
-Not built (a flag that only concerns them is accepted and reported): module-to-module variation, bad-channel lists by id,
-memory logging.
+Module-to-module variation (--mod2mod_variation or a keyword with MOD2MOD_VARIATION, e.g. `2x2`): the driver's module loop --
+per-module constants, pixel layout, response, light LUT, thresholds and gains; per-module light datasets merged at the end.
+
+Not built (a flag that only concerns them is accepted and reported): bad-channel lists by id, memory logging.
 """
 import argparse
 import os
@@ -112,6 +114,29 @@ class _Output:
         else:
             self.parts.setdefault(name, []).append(data)
 
+    def merge_module_waveforms(self, module_indices):
+        """light_sim.merge_module_light_wvfm_same_trigger (light_sim.py:759-775): the per-module waveform datasets side by side
+        along the channel axis as `light_wvfm`."""
+        names = [f"light_wvfm/light_wvfm_mod{i}" for i in module_indices]
+        if self.h5py is not None:
+            with self.h5py.File(self.filename, "a") as f:
+                if not all(n in f for n in names):
+                    return
+                parts = [np.array(f[n]) for n in names]
+                if len({p.shape[0] for p in parts}) != 1:
+                    raise ValueError("The number of triggers should be the same in each module with light trigger mode 1 "
+                                     "(light waveform).")
+                del f["light_wvfm"]
+                f.create_dataset("light_wvfm", data=np.concatenate(parts, axis=1), maxshape=(None, None, None))
+            return
+        if not all(n in self.parts for n in names):
+            return
+        parts = [np.concatenate(self.parts.pop(n)) for n in names]
+        if len({p.shape[0] for p in parts}) != 1:
+            raise ValueError("The number of triggers should be the same in each module with light trigger mode 1 "
+                             "(light waveform).")
+        self.parts["light_wvfm"] = [np.concatenate(parts, axis=1)]
+
     def put(self, name, data, attrs=None):
         if self.h5py is not None:
             with self.h5py.File(self.filename, "a") as f:
@@ -127,11 +152,18 @@ class _Output:
             np.savez_compressed(self.filename, **out)
 
 
+def _as_list(v):
+    """a flag given as 'a,b,c' (argparse) or a list (fire-style call) -> list; a plain value stays"""
+    if isinstance(v, str) and "," in v:
+        return [x.strip() for x in v.split(",") if x.strip()]
+    return v
+
+
 def run_simulation(input_filename, output_filename, config="module0", mod2mod_variation=None, pixel_layout=None,
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
-                   light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None, pixel_thresholds_file=None,
-                   pixel_gains_file=None, rand_seed=None, config_root=None, tracks_current_mc=False, chunk_segments=50000,
-                   raw_arrays=False, **ignored):
+                   light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None,
+                   pixel_thresholds_file=None, pixel_gains_file=None, rand_seed=None, config_root=None,
+                   tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, **ignored):
     if not os.path.exists(input_filename):
         raise Exception(f"Input file {input_filename} does not exist.")
     if os.path.exists(output_filename):
@@ -139,42 +171,66 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     for k, v in ignored.items():
         if v is not None:
             print(f"[simulate_pixels] --{k} concerns a stage that is not built and is ignored")
+    from larndsim_amd import lib
 
     # ---- configuration (cli/simulate_pixels.py:269-384) ------------------------------------------------------------------
     cfg = cfgmod.get_config(config, config_root)
-    cfgmod.check_single_configuration(config, cfg, mod2mod_variation)
-    one = lambda v: v[0] if isinstance(v, (list, tuple)) else v          # noqa: E731  single-configuration lists
-    pixel_layout = pixel_layout or (one(cfg.get("PIXEL_LAYOUT")) if "SNAPSHOT" not in cfg else None)
-    detector_properties = detector_properties or (cfg.get("DET_PROPERTIES") if "SNAPSHOT" not in cfg else None)
-    simulation_properties = simulation_properties or (cfg.get("SIM_PROPERTIES") if "SNAPSHOT" not in cfg else None)
-    if detector_properties and pixel_layout and simulation_properties:
-        consts.load_properties(detector_properties, pixel_layout, simulation_properties)
-    elif "SNAPSHOT" in cfg and not (detector_properties or pixel_layout or simulation_properties):
-        consts.load_snapshot(cfg["SNAPSHOT"])
+    snapshot = cfg.get("SNAPSHOT")                                  # built-in keyword: numbers-only constants, no YAML files
+    pixel_layout, response_file, light_lut_filename, pixel_thresholds_file, pixel_gains_file = (
+        _as_list(v) for v in (pixel_layout, response_file, light_lut_filename, pixel_thresholds_file, pixel_gains_file))
+    explicit_files = bool(detector_properties or pixel_layout or simulation_properties)
+    if snapshot is None or explicit_files:
+        pixel_layout = pixel_layout or cfg.get("PIXEL_LAYOUT")
+        detector_properties = detector_properties or cfg.get("DET_PROPERTIES")
+        simulation_properties = simulation_properties or cfg.get("SIM_PROPERTIES")
+        if not (detector_properties and pixel_layout and simulation_properties) or snapshot is not None and not all(
+                os.path.isfile(f) for f in [detector_properties, simulation_properties] + list(np.atleast_1d(pixel_layout))):
+            raise AssertionError("pixel_layout, detector_properties and simulation_properties (files) must all be specified")
+        snapshot = None
+        n_modules = len(consts.get_n_modules(detector_properties))
     else:
-        raise AssertionError("pixel_layout, detector_properties and simulation_properties (files) must all be specified")
-    det, sim, light = consts.detector, consts.sim, consts.light
-    if response_file is None and "SNAPSHOT" not in cfg:
-        response_file = one(cfg.get("RESPONSE"))
-    if response_file and os.path.isfile(response_file):
-        response = np.load(response_file)
-    else:
-        warnings.warn(f"response file {response_file!r} not available (the reference checkout ships none): using the "
-                      f"synthetic survey response table")
-        response = synth.make_response("survey", response_sampling=det.RESPONSE_SAMPLING)
+        n_modules = len(snapshot) if isinstance(snapshot, list) else 1
+    if response_file is None and snapshot is None:
+        response_file = cfg.get("RESPONSE")
     if light_simulated is None:
         light_simulated = bool(cfg.get("LIGHT_SIMULATED", True))
-    light_simulated = bool(light_simulated) and bool(light.LIGHT_SIMULATED) and light.N_OP_CHANNEL > 0
-    lut = None
-    if light_simulated:
-        light_lut_filename = light_lut_filename or one(cfg.get("LIGHT_LUT"))
-        if light_lut_filename and os.path.isfile(light_lut_filename):
-            lut = np.load(light_lut_filename)["arr"]
-            mask = lut["vis"] > 0                                   # no voxel with 0 visibility (cli/simulate_pixels.py:770-771)
-            lut["vis"][~mask] = lut["vis"][mask].min()
+    if light_simulated and light_lut_filename is None:
+        light_lut_filename = cfg.get("LIGHT_LUT")
+    m2m = cfgmod.module_variation_active(cfg, n_modules, mod2mod_variation,
+                                         snapshot if snapshot is not None else pixel_layout, response_file, light_lut_filename)
+    if m2m:                                                         # one entry per module (:374-384)
+        if snapshot is None:
+            pixel_layout = cfgmod.module_files(cfg, pixel_layout, "PIXEL_LAYOUT_ID", n_modules, "pixel layout")
+        response_file = cfgmod.module_files(cfg, response_file, "RESPONSE_ID", n_modules, "response files")
+        pixel_thresholds_file = cfgmod.module_files(cfg, pixel_thresholds_file, "PIXEL_THRESHOLD_ID", n_modules, "pixel threshold files")
+        pixel_gains_file = cfgmod.module_files(cfg, pixel_gains_file, "PIXEL_GAIN_ID", n_modules, "pixel gain files")
+        light_lut_filename = cfgmod.module_files(cfg, light_lut_filename, "LIGHT_LUT_ID", n_modules, "light LUT")
+    else:
+        if isinstance(snapshot, list):
+            snapshot = snapshot[0]
+        pixel_layout = cfgmod.single_file(pixel_layout, "pixel layout file")
+        response_file = cfgmod.single_file(response_file, "response file")
+        pixel_thresholds_file = cfgmod.single_file(pixel_thresholds_file, "pixel threshold file")
+        pixel_gains_file = cfgmod.single_file(pixel_gains_file, "pixel gain file")
+        light_lut_filename = cfgmod.single_file(light_lut_filename, "light lookup table")
+
+    def load_constants(i_mod):
+        """module i_mod's constants (i_mod = -1: the one configuration of all modules), :452-464, 678-682"""
+        if snapshot is not None:
+            consts.load_snapshot(snapshot[i_mod - 1] if m2m else snapshot)
         else:
-            print("light_lut_filename is not provided (required if light_simulated is True): light is not simulated")
-            light_simulated = False
+            consts.load_properties(detector_properties, pixel_layout, simulation_properties, i_module=i_mod if m2m else -1)
+        consts.sim.MOD2MOD_VARIATION = bool(m2m)
+
+    def per_module(value, i_mod):
+        return value[i_mod - 1] if (m2m and isinstance(value, (list, tuple))) else value
+
+    load_constants(1 if m2m else -1)                               # geometry: any module's pixel layout will do (:657-661)
+    det, sim, light = consts.detector, consts.sim, consts.light
+    light_simulated = bool(light_simulated) and bool(light.LIGHT_SIMULATED) and light.N_OP_CHANNEL > 0
+    if light_simulated and not all(f and os.path.isfile(f) for f in np.atleast_1d(light_lut_filename if light_lut_filename is not None else "")):
+        print("light_lut_filename is not provided (required if light_simulated is True): light is not simulated")
+        light_simulated = False
     if not rand_seed:
         rand_seed = SEED
     print("Random seed:", rand_seed)
@@ -197,170 +253,256 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     num_evids = int(tracks[sim.EVENT_SEPARATOR].max() % sim.MAX_EVENTS_PER_FILE) + 1
     host_rng = np.random.default_rng(rand_seed)
     event_times = (np.arange(num_evids) * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else gen_event_times(num_evids, host_rng))
-    tracks = tracks[batching.select_active_volume(tracks, det.TPC_BORDERS)]
-    bid, order, table = batching.assign_batches(tracks)
-    tracks, bid = np.ascontiguousarray(tracks[order]), bid[order]
-    nsim = int((bid >= 0).sum())
-    traj_field = "file_traj_id" if "file_traj_id" in tracks.dtype.names else "traj_id"
+    all_tracks = tracks[batching.select_active_volume(tracks, det.TPC_BORDERS)]            # :664-668
+    all_events = np.unique(all_tracks[sim.EVENT_SEPARATOR])
+    traj_field = "file_traj_id" if "file_traj_id" in all_tracks.dtype.names else "traj_id"
+    mod_ids = list(det.MOD_IDS) if m2m else [-1]
 
-    # ---- device-resident simulation ---------------------------------------------------------------------------------------------
-    chain = ChargeChain(response)
-    chain.clear_pixel_tables()
-    chain.seed_rng(rand_seed)                                       # create_xoroshiro128p_states(1024*256, seed) (:396)
-    if pixel_thresholds_file is not None:                          # :439-443, 1079-1084
-        print("Pixel thresholds file:", pixel_thresholds_file)
-        chain.set_pixel_thresholds(*fee.load_pixel_table(pixel_thresholds_file))
-    if pixel_gains_file is not None:                               # :445-449, 1097-1100
-        print("Pixel gains file:", pixel_gains_file)
-        chain.set_pixel_gains(*fee.load_pixel_table(pixel_gains_file))
-    from larndsim_amd import lib
-    lib.set_option("mc_current", 1 if tracks_current_mc else 0)
     out = _Output(output_filename)
+    totals = dict(n_segments=0, n_batches=0, n_hits=0, n_packets=0, n_light_triggers=0)
+    kept_tracks, light_dat = [], {}
+    rng_seeded = False
+    lib.set_option("mc_current", 1 if tracks_current_mc else 0)
     try:
-        chain.upload(tracks, bid)
-        chain.quench_drift(consts.physics.BIRKS)
-        chain.download_segments(tracks)
-        edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
-        light_trig_of = {}                                           # (event, TPC group) -> trigger arrays for the packet stream
-        n_light_trig = 0
-        if light_simulated:
-            chain.light_incidence(lut)
-            op_channel = light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32)
-            n_det = op_channel.shape[0]
-            light_det_noise_filename = light_det_noise_filename or one(cfg.get("LIGHT_DET_NOISE"))
-            if light_det_noise_filename and os.path.isfile(light_det_noise_filename):
-                print("Light detector noise: ", light_det_noise_filename)
-                light_noise = np.load(light_det_noise_filename)
+        for i_mod in mod_ids:                                       # convention: module ids count from 1 (:676-715)
+            if m2m:
+                print(f"Simulating module {i_mod - 1}")
+                load_constants(i_mod)
+                det, sim, light = consts.detector, consts.sim, consts.light
+                det_borders = det.TPC_BORDERS[(i_mod - 1) * 2: i_mod * 2]
+                tracks = all_tracks[batching.select_active_volume(all_tracks, det_borders)]
             else:
-                print("light_det_noise_filename is not provided (required if light_simulated is True): no detector noise")
-                light_noise = None
-            digit_samples = ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING)
-            # group thresholds of the active channels (:1183-1185)
-            thr = np.repeat(np.array(light.LIGHT_TRIG_THRESHOLD)[..., np.newaxis], light.OP_CHANNEL_PER_TRIG, axis=-1)
-            thr = thr.ravel()[op_channel].copy().reshape(-1, light.OP_CHANNEL_PER_TRIG)[..., 0]
-            n_groups = int(np.ceil(det.TPC_BORDERS.shape[0] / sim.EVENT_BATCH_SIZE))
-            batch_of = {}
-            for ib, (ev, grp, sub, _n) in enumerate(table):
-                batch_of.setdefault((int(ev), int(grp)), []).append(ib)
-            light_rows, i_trig = [], 0
-            null_wvfm = None
-            for ev in np.unique(tracks[sim.EVENT_SEPARATOR]):       # the reference's loop order: events, TPC groups (:864)
-                ev_time = np.array([event_times[int(ev) % sim.MAX_EVENTS_PER_FILE]])
-                for grp in range(n_groups):
-                    acc = dict(start=[], idx=[], typ=[], opc=[], wv=[], tid=[], tph=[])
-                    ibs = batch_of.get((int(ev), grp), [])
-                    if not ibs:
-                        # nothing to simulate in this module group: waveforms of an empty response (:805-841, 894-899)
-                        if null_wvfm is None:
-                            nt0 = int((light.LIGHT_WINDOW[1] + light.LIGHT_WINDOW[0]) / light.LIGHT_TICK_SIZE)
-                            zero = np.zeros((n_det, nt0), dtype=np.float32)
-                            mt = sim.MAX_MC_TRUTH_IDS
-                            null_wvfm = light_sim.sim_triggers(
-                                None, None, zero, op_channel, np.full((n_det, nt0, mt), -1, dtype=np.int64),
-                                np.zeros((n_det, nt0, mt)), np.array([0]), op_channel[None, :], digit_samples, light_noise)
-                        acc["start"].append(np.full(1, 0.0)); acc["idx"].append(np.array([0]))
-                        acc["typ"].append(np.full(1, light.LIGHT_TRIG_MODE)); acc["opc"].append(op_channel[None, :])
-                        for k, v in zip(("wv", "tid", "tph"), null_wvfm):
-                            acc[k].append(v)
-                    for ib in ibs:                                  # sub-batches of BATCH_SIZE segments (:902-905, 1120-1205)
-                        b0, b1 = int(edges[ib]), int(edges[ib + 1])
-                        n_ticks, t_start = chain.sum_light(b0, b1, op_channel,
-                                                           segment_track_id=tracks["segment_id"][b0:b1].astype(np.int64))
-                        if raw_arrays:
-                            light_rows.append(chain.download_light(truth=False)[0])
-                        chain.extend_rng(n_det * (-(-int(n_ticks) // 64)) * 64, rand_seed + int(ev) + table[ib][2] * sim.BATCH_SIZE)
-                        chain.light_response(fluctuate=True)
-                        t_idx, t_opc, t_type = light_sim.get_triggers(None, thr, op_channel, table[ib][2])
-                        wv = light_sim.sim_triggers(None, None, None, op_channel, None, None, t_idx, t_opc, digit_samples,
-                                                    light_noise)
-                        acc["start"].append(np.full(t_idx.shape[0], t_start)); acc["idx"].append(t_idx)
-                        acc["typ"].append(t_type); acc["opc"].append(t_opc)
-                        for k, v in zip(("wv", "tid", "tph"), wv):
-                            acc[k].append(v)
-                    if not any(len(a) for a in acc["idx"]):
-                        continue
-                    cat = {k: np.concatenate(v, axis=0) for k, v in acc.items()}
-                    ntr = cat["idx"].shape[0]
-                    lev = np.full(ntr, ev)
-                    if light.LIGHT_TRIG_MODE == 0:
-                        out.append("light_trig", light_sim.build_light_trig(lev, cat["start"], cat["idx"], cat["opc"], ev_time))
-                    out.append("light_wvfm", cat["wv"])
-                    if sim.MAX_MC_TRUTH_IDS > 0:
-                        out.append("light_wvfm_mc_assn",
-                                   light_sim.zero_suppress_waveform_truth(cat["tid"], cat["tph"], lev[0], i_trig, -1))
-                    i_trig += 1
-                    n_light_trig += ntr
-                    if ibs:
-                        mods = (cat["typ"] if light.LIGHT_TRIG_MODE == 1 else
-                                np.array([det.TPC_TO_MODULE[int(t)] for t in light.OP_CHANNEL_TO_TPC[cat["opc"]][:, 0]]))
-                        light_trig_of[(int(ev), grp)] = (cat["start"] + cat["idx"] * light.LIGHT_TICK_SIZE, lev, mods)
-            inc, _ = chain.download_light_incidence(0, len(tracks))
-            inc["segment_id"] = tracks["segment_id"][:, None]
-            out.put("light_dat/light_dat_allmodules", inc)
-            if raw_arrays and light_rows:
-                nt_max = max(r.shape[1] for r in light_rows)       # the tick count follows each batch's arrival times
-                out.put("light_sample_inc", np.stack([np.pad(r, ((0, 0), (0, nt_max - r.shape[1]))) for r in light_rows]))
-        parts, n_hits, n_packets = [], 0, 0
-        b = 0
-        for e in edges[1:]:
-            if not (e - b >= chunk_segments or e == nsim):
-                continue
-            st = chain.run(int(b), int(e), want_fractions=True)
-            res = chain.download()
-            # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
-            for bb in np.unique(res["batch"]):
-                m = res["batch"] == bb
-                lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
-                seg_ids = tracks["segment_id"][lo:].astype(np.int64)
-                trj_ids = tracks[traj_field][lo:].astype(np.int64)
-                tpm = res["track_pixel_map"][m]
-                track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
-                traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
-                event = table[int(bb)][0]
-                ev_ids = np.full(res["adc_digit"][m].shape, event)
-                ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
-                # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger
-                lt_times, lt_events, lt_mods = light_trig_of.get((int(event), int(table[int(bb)][1])),
-                                                                 (np.zeros(1), np.array([event]), np.ones(1)))
-                pk, assn = packets.build_packets(ev_ids, res["adc_digit"][m], res["adc_ticks_list"][m], res["unique_pix"][m],
-                                                 res["current_fractions"][m], track_ids, traj_ids, ev_time,
-                                                 light_trigger_times=lt_times, light_trigger_event_id=lt_events,
-                                                 light_trigger_modules=lt_mods, bad_channels=bad_list)
-                out.append_packets(pk, assn)
-                n_packets += len(pk)
-            n_hits += int((res["adc_list"] != 0).sum())
-            if raw_arrays:
-                res["event_id"] = np.array([t[0] for t in table])[res["batch"]]
-                parts.append(res)
-            b = e
-        if raw_arrays and parts:
-            for k in parts[0]:
-                out.put("raw/" + k, np.concatenate([p[k] for p in parts]))
-        if light_simulated and light.LIGHT_TRIG_MODE == 1:          # one beam trigger per spill / event (:1252-1259)
-            ev_all = tracks[sim.EVENT_SEPARATOR]
-            lev = np.unique(ev_all - (ev_all // sim.MAX_EVENTS_PER_FILE) * sim.MAX_EVENTS_PER_FILE) if sim.IS_SPILL_SIM \
-                else (truth["vertices"]["event_id"] if "vertices" in truth else np.unique(ev_all))
-            lt = lev * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else event_times
-            out.append("light_trig", light_sim.build_light_trig(lev, np.full(len(lev), 0), np.full(len(lev), 0),
-                                                                light.TPC_TO_OP_CHANNEL[:].ravel(), lt))
-        # ---- truth pass-through (:1226-1297): true timing structure restored, edep-sim coordinate convention ---------------------------
-        out_tracks = tracks.copy()
+                det_borders = det.TPC_BORDERS
+                tracks = all_tracks
+            rf = per_module(response_file, i_mod)
+            if rf and os.path.isfile(rf):
+                response = np.load(rf)
+            else:
+                warnings.warn(f"response file {rf!r} not available (the reference checkout ships none): using the "
+                              f"synthetic survey response table")
+                response = synth.make_response("survey", response_sampling=det.RESPONSE_SAMPLING)
+            chain = ChargeChain(response)
+            chain.clear_pixel_tables()
+            if not rng_seeded:
+                chain.seed_rng(rand_seed)                           # create_xoroshiro128p_states(1024*256, seed) (:396), once
+                rng_seeded = True
+            thr_file, gain_file = per_module(pixel_thresholds_file, i_mod), per_module(pixel_gains_file, i_mod)
+            if thr_file is not None:                                # :439-443, 698-706, 1079-1084
+                print("Pixel thresholds file:", thr_file)
+                chain.set_pixel_thresholds(*fee.load_pixel_table(thr_file))
+            if gain_file is not None:                               # :445-449, 1097-1100
+                print("Pixel gains file:", gain_file)
+                chain.set_pixel_gains(*fee.load_pixel_table(gain_file))
+            res = _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, event_times, rand_seed, traj_field,
+                                   per_module(light_lut_filename, i_mod) if light_simulated else None, light_det_noise_filename,
+                                   cfg, len(mod_ids), bad_list, chunk_segments, raw_arrays)
+            for k in totals:
+                totals[k] += res[k]
+            kept_tracks.append(res["tracks"])
+            if res["light_dat"] is not None:
+                light_dat[i_mod] = res["light_dat"]
+        # ---- end of file (:1226-1297) --------------------------------------------------------------------------------------------------
+        out_tracks = np.concatenate(kept_tracks) if len(kept_tracks) > 1 else kept_tracks[0].copy()
         if sim.IS_SPILL_SIM:
             ev = out_tracks[sim.EVENT_SEPARATOR]
             local = ev - (ev // sim.MAX_EVENTS_PER_FILE) * sim.MAX_EVENTS_PER_FILE
             for f in ("t0_start", "t0_end", "t0"):
                 out_tracks[f] = out_tracks[f] + local * sim.SPILL_PERIOD
+        if light_simulated and light.LIGHT_TRIG_MODE == 1:          # one beam trigger per spill / event (:1252-1259)
+            ev_all = out_tracks[sim.EVENT_SEPARATOR]
+            lev = np.unique(ev_all - (ev_all // sim.MAX_EVENTS_PER_FILE) * sim.MAX_EVENTS_PER_FILE) if sim.IS_SPILL_SIM \
+                else (truth["vertices"]["event_id"] if "vertices" in truth else np.unique(ev_all))
+            lt = lev * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else event_times
+            out.append("light_trig", light_sim.build_light_trig(lev, np.full(len(lev), 0), np.full(len(lev), 0),
+                                                                light.TPC_TO_OP_CHANNEL[:].ravel(), lt))
+        if light_simulated and m2m and light.LIGHT_TRIG_MODE == 1:  # merge_module_light_wvfm_same_trigger (:759-775)
+            out.merge_module_waveforms([m - 1 for m in mod_ids])
         batching.swap_coordinates(out_tracks)
         out.put(sim.TRACKS_DSET_NAME, out_tracks, attrs={"zbeam": True})
+        for i_mod, dat in light_dat.items():
+            out.put(f"light_dat/light_dat_module{i_mod - 1}" if m2m else "light_dat/light_dat_allmodules", dat)
         for k, v in truth.items():
             out.put(k, v)
         out.close()
     finally:
         lib.set_option("mc_current", 0)
-    print(f"simulated {nsim} segments in {len(table)} batches -> {n_hits} hits, {n_packets} packets"
-          + (f", {n_light_trig} light triggers" if light_simulated else ""))
+    print(f"simulated {totals['n_segments']} segments in {totals['n_batches']} batches -> {totals['n_hits']} hits, "
+          f"{totals['n_packets']} packets" + (f", {totals['n_light_triggers']} light triggers" if light_simulated else ""))
     print("Output saved in:", output_filename)
-    return dict(n_segments=nsim, n_batches=len(table), n_hits=n_hits, n_packets=n_packets, n_light_triggers=n_light_trig)
+    return totals
+
+
+def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, event_times, rand_seed, traj_field, light_lut,
+                     light_det_noise_filename, cfg, n_mod_ids, bad_list, chunk_segments, raw_arrays):
+    """One pass of the driver's module loop body (cli/simulate_pixels.py:717-1232) on the device-resident chain: quench + drift,
+    light leg, charge chain, packets.  ``tracks``: the module's active segments (all active segments without module
+    variation); ``all_events``: event ids of every active segment (a module without segments in an event still reads out)."""
+    det, sim, light = consts.detector, consts.sim, consts.light
+    one = lambda v: v[0] if isinstance(v, (list, tuple)) else v          # noqa: E731
+    bid, order, table = batching.assign_batches(tracks, tpc_borders=det_borders)
+    tracks, bid = np.ascontiguousarray(tracks[order]), bid[order]
+    nsim = int((bid >= 0).sum())
+    res = dict(n_segments=nsim, n_batches=len(table), n_hits=0, n_packets=0, n_light_triggers=0, light_dat=None)
+    if len(tracks):                                                 # a module may hold no segment at all: it still reads out
+        chain.upload(tracks, bid)
+        chain.quench_drift(consts.physics.BIRKS)
+        chain.download_segments(tracks)
+    res["tracks"] = tracks
+    edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
+    n_groups = int(np.ceil(np.asarray(det_borders).shape[0] / sim.EVENT_BATCH_SIZE))
+    batch_of = {}
+    for ib, (ev, grp, sub, _n) in enumerate(table):
+        batch_of.setdefault((int(ev), int(grp)), []).append(ib)
+    light_trig_of = {}                                              # (event, TPC group) -> trigger arrays for the packet stream
+    if light_lut is not None:
+        lut = np.load(light_lut)["arr"]
+        mask = lut["vis"] > 0                                       # no voxel with 0 visibility (:778-780)
+        lut["vis"][~mask] = lut["vis"][mask].min()
+        n_light_channel = int(light.N_OP_CHANNEL / n_mod_ids) if m2m else light.N_OP_CHANNEL        # :750
+        if len(tracks):
+            chain.light_incidence(lut, n_out=n_light_channel)
+        # in the module-variation case the channel indices of the first module stand for every module's (:1127-1131)
+        op_channel = (light.TPC_TO_OP_CHANNEL[:2].ravel() if m2m else light.TPC_TO_OP_CHANNEL[:].ravel()).astype(np.int32)
+        n_det = op_channel.shape[0]
+        noise_file = light_det_noise_filename or one(cfg.get("LIGHT_DET_NOISE"))
+        if noise_file and os.path.isfile(noise_file):
+            print("Light detector noise: ", noise_file)
+            light_noise = np.load(noise_file)
+            if m2m:
+                light_noise = light_noise[n_light_channel * (i_mod - 1): n_light_channel * i_mod]          # :789-790
+        else:
+            print("light_det_noise_filename is not provided (required if light_simulated is True): no detector noise")
+            light_noise = None
+        digit_samples = ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING)
+        # group thresholds of the active channels (:1183-1185)
+        thr = np.repeat(np.array(light.LIGHT_TRIG_THRESHOLD)[..., np.newaxis], light.OP_CHANNEL_PER_TRIG, axis=-1)
+        thr = thr.ravel()[op_channel].copy().reshape(-1, light.OP_CHANNEL_PER_TRIG)[..., 0]
+        wvfm_name = f"light_wvfm/light_wvfm_mod{i_mod - 1}" if (m2m and light.LIGHT_TRIG_MODE == 1) else "light_wvfm"
+        light_rows, i_trig = [], 0
+        null_wvfm = None
+        for ev in all_events:                                       # the reference's loop order: events, TPC groups (:864)
+            ev_time = np.array([event_times[int(ev) % sim.MAX_EVENTS_PER_FILE]])
+            for grp in range(n_groups):
+                acc = dict(start=[], idx=[], typ=[], opc=[], wv=[], tid=[], tph=[])
+                ibs = batch_of.get((int(ev), grp), [])
+                if not ibs:
+                    # nothing to simulate in this module group: waveforms of an empty response (:805-841, 894-899)
+                    if null_wvfm is None:
+                        nt0 = int((light.LIGHT_WINDOW[1] + light.LIGHT_WINDOW[0]) / light.LIGHT_TICK_SIZE)
+                        zero = np.zeros((n_det, nt0), dtype=np.float32)
+                        mt = sim.MAX_MC_TRUTH_IDS
+                        null_wvfm = light_sim.sim_triggers(
+                            None, None, zero, op_channel, np.full((n_det, nt0, mt), -1, dtype=np.int64),
+                            np.zeros((n_det, nt0, mt)), np.array([0]), op_channel[None, :], digit_samples, light_noise)
+                    acc["start"].append(np.full(1, 0.0)); acc["idx"].append(np.array([0]))
+                    acc["typ"].append(np.full(1, light.LIGHT_TRIG_MODE)); acc["opc"].append(op_channel[None, :])
+                    for k, v in zip(("wv", "tid", "tph"), null_wvfm):
+                        acc[k].append(v)
+                for ib in ibs:                                      # sub-batches of BATCH_SIZE segments (:902-905, 1120-1205)
+                    b0, b1 = int(edges[ib]), int(edges[ib + 1])
+                    n_ticks, t_start = chain.sum_light(b0, b1, op_channel,
+                                                       segment_track_id=tracks["segment_id"][b0:b1].astype(np.int64))
+                    if raw_arrays:
+                        light_rows.append(chain.download_light(truth=False)[0])
+                    chain.extend_rng(n_det * (-(-int(n_ticks) // 64)) * 64, rand_seed + int(ev) + table[ib][2] * sim.BATCH_SIZE)
+                    chain.light_response(fluctuate=True)
+                    t_idx, t_opc, t_type = light_sim.get_triggers(None, thr, op_channel, table[ib][2])
+                    wv = light_sim.sim_triggers(None, None, None, op_channel, None, None, t_idx, t_opc, digit_samples,
+                                                light_noise)
+                    acc["start"].append(np.full(t_idx.shape[0], t_start)); acc["idx"].append(t_idx)
+                    acc["typ"].append(t_type); acc["opc"].append(t_opc)
+                    for k, v in zip(("wv", "tid", "tph"), wv):
+                        acc[k].append(v)
+                if not any(len(a) for a in acc["idx"]):
+                    continue
+                cat = {k: np.concatenate(v, axis=0) for k, v in acc.items()}
+                ntr = cat["idx"].shape[0]
+                lev = np.full(ntr, ev)
+                if light.LIGHT_TRIG_MODE == 0:
+                    out.append("light_trig", light_sim.build_light_trig(lev, cat["start"], cat["idx"], cat["opc"], ev_time))
+                out.append(wvfm_name, cat["wv"])
+                if sim.MAX_MC_TRUTH_IDS > 0:
+                    out.append("light_wvfm_mc_assn",
+                               light_sim.zero_suppress_waveform_truth(cat["tid"], cat["tph"], lev[0], i_trig, i_mod))
+                i_trig += 1
+                res["n_light_triggers"] += ntr
+                if ibs:
+                    mods = (cat["typ"] if light.LIGHT_TRIG_MODE == 1 else
+                            np.array([det.TPC_TO_MODULE[int(t)] for t in light.OP_CHANNEL_TO_TPC[cat["opc"]][:, 0]]))
+                    light_trig_of[(int(ev), grp)] = (cat["start"] + cat["idx"] * light.LIGHT_TICK_SIZE, lev, mods)
+        if len(tracks):
+            inc, _ = chain.download_light_incidence(0, len(tracks))
+            inc["segment_id"] = tracks["segment_id"][:, None]
+            res["light_dat"] = inc
+        if raw_arrays and light_rows:
+            nt_max = max(r.shape[1] for r in light_rows)           # the tick count follows each batch's arrival times
+            out.put("light_sample_inc" + (f"_mod{i_mod - 1}" if m2m else ""),
+                    np.stack([np.pad(r, ((0, 0), (0, nt_max - r.shape[1]))) for r in light_rows]))
+
+    # ---- sync / timestamp / trigger packets at every new event (:866-890), then the event's charge packets ------------------
+    period = det.CLOCK_RESET_PERIOD * det.CLOCK_CYCLE
+    sync_start = event_times[0] // period * period + period
+    io_rows = np.array(list(det.MODULE_TO_IO_GROUPS.values()))
+    trig_module = int(np.argwhere(io_rows == packets.get_trig_io())[0][0]) + 1
+    announced = 0                                                   # events of all_events whose packets are out
+
+    def announce_until(event):
+        nonlocal sync_start, announced
+        while announced < len(all_events) and all_events[announced] <= event:
+            t_ev = event_times[int(all_events[announced]) % sim.MAX_EVENTS_PER_FILE]
+            if t_ev - sync_start >= 0:
+                sync_times = np.arange(sync_start, t_ev + 1, period)
+                if len(sync_times):
+                    spk = packets.build_sync_packets(np.full(sync_times.shape, period), i_mod)
+                    out.append_packets(*spk)
+                    res["n_packets"] += len(spk[0])
+                    sync_start = sync_times[-1] + period
+            if i_mod == trig_module or i_mod == -1:                 # the trigger is forwarded to one PACMAN only
+                tpk = packets.build_timestamp_trigger_packets([t_ev], i_mod)
+                out.append_packets(*tpk)
+                res["n_packets"] += len(tpk[0])
+            announced += 1
+
+    parts = []
+    b = 0
+    for e in edges[1:]:
+        if not (e - b >= chunk_segments or e == nsim):
+            continue
+        chain.run(int(b), int(e), want_fractions=True)
+        r = chain.download()
+        # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
+        for bb in np.unique(r["batch"]):
+            m = r["batch"] == bb
+            lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
+            seg_ids = tracks["segment_id"][lo:].astype(np.int64)
+            trj_ids = tracks[traj_field][lo:].astype(np.int64)
+            tpm = r["track_pixel_map"][m]
+            track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
+            traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
+            event = table[int(bb)][0]
+            announce_until(event)
+            ev_ids = np.full(r["adc_digit"][m].shape, event)
+            ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
+            # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger
+            lt_times, lt_events, lt_mods = light_trig_of.get((int(event), int(table[int(bb)][1])),
+                                                             (np.zeros(1), np.array([event]), np.ones(1)))
+            pk, assn = packets.build_packets(ev_ids, r["adc_digit"][m], r["adc_ticks_list"][m], r["unique_pix"][m],
+                                             r["current_fractions"][m], track_ids, traj_ids, ev_time,
+                                             light_trigger_times=lt_times, light_trigger_event_id=lt_events,
+                                             light_trigger_modules=lt_mods, bad_channels=bad_list, i_mod=i_mod)
+            out.append_packets(pk, assn)
+            res["n_packets"] += len(pk)
+        res["n_hits"] += int((r["adc_list"] != 0).sum())
+        if raw_arrays:
+            r["event_id"] = np.array([t[0] for t in table])[r["batch"]]
+            parts.append(r)
+        b = e
+    if len(all_events):
+        announce_until(all_events[-1])
+    if raw_arrays and parts:
+        for k in parts[0]:
+            out.put(("raw/" if not m2m else f"raw_mod{i_mod - 1}/") + k, np.concatenate([p[k] for p in parts]))
+    return res
 
 
 def main(argv=None):
@@ -371,7 +513,9 @@ def main(argv=None):
     ap.add_argument("--config_root", default=None, help="larnd-sim tree holding config/config.yaml and the YAML families "
                                                         "(default: $LARNDSIM_ROOT, else the built-in snapshot keywords)")
     tf = lambda s: s.lower() in ("1", "true", "yes")                # noqa: E731
-    ap.add_argument("--mod2mod_variation", type=tf, default=None)
+    ap.add_argument("--mod2mod_variation", type=tf, default=None,
+                    help="per-module pixel layouts / responses / light LUTs / thresholds / gains (comma-separated lists), "
+                         "default: the keyword's MOD2MOD_VARIATION")
     ap.add_argument("--light_simulated", type=tf, default=None)
     for k in ("pixel_layout", "detector_properties", "simulation_properties", "response_file", "light_lut_filename",
               "light_det_noise_filename", "bad_channels", "pixel_thresholds_file", "pixel_gains_file", *IGNORED):

@@ -23,6 +23,12 @@ CONFIG_DIR_NAMES = dict(SIM_PROPERTIES='simulation_properties', PIXEL_LAYOUT='pi
 BUILTIN = {
     'module0': dict(SNAPSHOT='module0', SIM_PROPERTIES='singles_sim.yaml', PIXEL_LAYOUT='multi_tile_layout-2.3.16.yaml',
                     DET_PROPERTIES='module0.yaml', RESPONSE='response_44.npy', LIGHT_SIMULATED=True),
+    # the reference's module-variation keyword: constants snapshots per module (2x2.yaml, layouts 2.4.16 / 2.5.16 with
+    # PIXEL_LAYOUT_ID [0, 0, 1, 0], 2x2_NuMI_sim.yaml); its response and LUT files are not part of the reference checkout
+    '2x2': dict(SNAPSHOT=['2x2_mod1', '2x2_mod2', '2x2_mod3', '2x2_mod4'], SIM_PROPERTIES='2x2_NuMI_sim.yaml',
+                PIXEL_LAYOUT=['multi_tile_layout-2.4.16.yaml', 'multi_tile_layout-2.5.16.yaml'], PIXEL_LAYOUT_ID=[0, 0, 1, 0],
+                DET_PROPERTIES='2x2.yaml', RESPONSE=['response_44_v2a_50ns.npy', 'response_38_v2b_50ns.npy'],
+                RESPONSE_ID=[0, 0, 1, 0], LIGHT_SIMULATED=True, LIGHT_LUT_ID=[0, 1, 1, 1], MOD2MOD_VARIATION=True),
     '2x2_no_modvar': dict(SNAPSHOT='2x2_no_modvar', SIM_PROPERTIES='2x2_NuMI_sim_no_modvar.yaml',
                           PIXEL_LAYOUT='multi_tile_layout-2.4.16.yaml', DET_PROPERTIES='2x2_no_modvar.yaml',
                           RESPONSE='response_44.npy', LIGHT_SIMULATED=True, MOD2MOD_VARIATION=False),
@@ -73,16 +79,37 @@ def get_config(keyname, root=None):
     return res
 
 
-def check_single_configuration(keyname, cfg, mod2mod_variation=None):
-    """The reference's mod2mod decision (cli/simulate_pixels.py:355-372) up to the point where per-module files would be
-    loaded: returns normally when every module uses one configuration, raises NotImplementedError otherwise."""
+def module_variation_active(cfg, n_modules, mod2mod_variation=None, pixel_layout=None, response_file=None, light_lut=None):
+    """The reference's decision whether per-module configurations are loaded (cli/simulate_pixels.py:355-372): the flag (or
+    the keyword's MOD2MOD_VARIATION), switched off for a one-module detector or when only a single set of pixel layout /
+    response / light LUT files is given."""
     m2m = cfg.get('MOD2MOD_VARIATION') if mod2mod_variation is None else mod2mod_variation
     if not m2m:
-        return
-    single = all(isinstance(cfg.get(k), str) or cfg.get(k) is None or len(cfg.get(k)) == 1
-                 for k in ('PIXEL_LAYOUT', 'RESPONSE', 'LIGHT_LUT'))
-    if single:
-        return      # the reference deactivates module variation with a warning in this case (:365-367)
-    raise NotImplementedError(
-        f"configuration '{keyname}' needs module-to-module variation (per-module pixel layouts / responses / light LUTs, "
-        f"cli/simulate_pixels.py:678-715), which is not built; use a *_no_modvar keyword or explicit single files")
+        return False
+    if n_modules == 1:
+        return False
+    one = lambda v: v is None or isinstance(v, str) or len(v) == 1       # noqa: E731
+    return not (one(pixel_layout) and one(response_file) and one(light_lut))
+
+
+def module_files(cfg, files, id_name, n_modules, message=""):
+    """One file per module from a list of files and the keyword's ``<X>_ID`` pointer list
+    (``load_mod2mod_variation_properties``, cli/simulate_pixels.py:106-122): ``files[ids[m]]`` for module m; without a
+    usable pointer list the files must already be one per module."""
+    if files is None:
+        return None
+    ids = cfg.get(id_name)
+    if ids is not None and isinstance(files, list) and len(ids) == n_modules and max(ids) < len(files):
+        return [files[i] for i in ids]
+    if isinstance(files, list) and len(files) != n_modules:
+        raise KeyError(f"Simulation with module variation activated, but the number of {message} is incorrect!")
+    return files
+
+
+def single_file(value, message=""):
+    """Without module variation a property may be a string or a one-element list (cli/simulate_pixels.py:403-426)."""
+    if isinstance(value, (list, tuple)):
+        if len(value) > 1:
+            raise KeyError(f"Provided more than one {message} for the simulation with no module variation.")
+        return value[0] if value else None
+    return value

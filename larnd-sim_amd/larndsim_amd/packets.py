@@ -200,6 +200,55 @@ def build_packets(event_id_list, adc_list, adc_ticks_list, unique_pix, current_f
     return packets, ds
 
 
+def _other_row(ptype, io_group, timestamp, trigger_type=0):
+    return (io_group, 0, 0, ptype, 0, 0, 1, 0, int(timestamp), 0, trigger_type, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+
+
+def _empty_assn(n):
+    """association rows of packets that carry no charge (fee.py:378-418, 441-470)"""
+    ds = np.empty(n, dtype=assn_dtype())
+    ds['event_ids'] = -1
+    ds['segment_ids'] = -1
+    ds['fraction'] = 0
+    ds['file_traj_ids'] = -1
+    ds['fraction_traj'] = 0
+    return ds
+
+
+def get_trig_io():
+    """io_group of the PACMAN the light / beam trigger is forwarded to (fee.py:30-38)"""
+    return 2 if consts.light.LIGHT_TRIG_MODE == 0 else 1
+
+
+def build_sync_packets(sync_times, i_mod=-1):
+    """``fee.export_sync_to_hdf5`` up to the file write (fee.py:361-424): one sync packet per io_group and sync time [us]."""
+    d = consts.detector
+    io_groups = np.unique(np.array(list(d.MODULE_TO_IO_GROUPS.values())))
+    io_groups = d.MODULE_TO_IO_GROUPS[i_mod] if i_mod > 0 else io_groups
+    rows = []
+    for sync_tick in np.asarray(sync_times) / d.CLOCK_CYCLE:
+        if sync_tick % d.CLOCK_RESET_PERIOD != 0:
+            sync_tick = sync_tick // d.CLOCK_RESET_PERIOD * d.CLOCK_RESET_PERIOD
+        for io_group in io_groups:
+            rows.append(_other_row(SYNC, io_group, sync_tick, trigger_type=ord('S')))
+    packets = np.array(rows, dtype=packets_dtype) if rows else np.zeros(0, dtype=packets_dtype)
+    return packets, _empty_assn(len(rows))
+
+
+def build_timestamp_trigger_packets(event_start_times, i_mod=-1):
+    """``fee.export_timestamp_trigger_to_hdf5`` up to the file write (fee.py:426-497): a timestamp packet [s] and a trigger
+    packet [ticks] on the trigger PACMAN for every event start time [us]."""
+    d, units = consts.detector, consts.units
+    rows = []
+    io_group = get_trig_io()
+    for evt_time in np.asarray(event_start_times):
+        t_trig = int(np.floor(evt_time / d.CLOCK_CYCLE)) % d.CLOCK_RESET_PERIOD
+        rows.append(_other_row(TIMESTAMP, io_group, evt_time * units.mus / units.s))
+        rows.append(_other_row(TRIGGER, io_group, t_trig, trigger_type=2))
+    packets = np.array(rows, dtype=packets_dtype) if rows else np.zeros(0, dtype=packets_dtype)
+    return packets, _empty_assn(len(rows))
+
+
 def write_hdf5(filename, packets, assn):
     """Append ``packets`` / ``mc_packets_assn`` to an HDF5 file laid out like larpix-control's (``_header`` version 2.4,
     resizable datasets) plus the ``configs`` attributes fee.export_to_hdf5 writes (fee.py:350-354).  Needs h5py."""

@@ -267,6 +267,23 @@ def gen_consts():
         with open(os.path.join(SNAP, cfg + ".json"), "w") as f:
             json.dump(snap, f)
         print("snapshot", cfg, "TPCs", np.asarray(ref.detector.TPC_BORDERS).shape[0])
+    # the module-variation configuration `2x2` of the reference's config.yaml: detector properties 2x2.yaml, pixel layouts
+    # [2.4.16, 2.5.16] with PIXEL_LAYOUT_ID [0, 0, 1, 0], 2x2_NuMI_sim.yaml -- one snapshot per module, loaded the way the
+    # driver's module loop does (cli/simulate_pixels.py:452-454, 678-682)
+    ref = Ref("2x2_no_modvar", noise_zero=False)
+    R = os.path.join(REF, "larndsim")
+    layouts = [os.path.join(R, "pixel_layouts", f) for f in ("multi_tile_layout-2.4.16.yaml", "multi_tile_layout-2.5.16.yaml")]
+    per_module = [layouts[i] for i in (0, 0, 1, 0)]
+    det = os.path.join(R, "detector_properties", "2x2.yaml")
+    for i_mod in (1, 2, 3, 4):
+        ref.consts.light.set_light_properties(det)
+        ref.consts.sim.set_simulation_properties(os.path.join(R, "simulation_properties", "2x2_NuMI_sim.yaml"))
+        ref.consts.detector.set_detector_properties(det, per_module, i_mod)
+        snap = my.snapshot_dict(ref.consts.detector, ref.consts.light, ref.consts.sim)
+        with open(os.path.join(SNAP, f"2x2_mod{i_mod}.json"), "w") as f:
+            json.dump(snap, f)
+        print("snapshot 2x2 module", i_mod, "pitch", ref.consts.detector.PIXEL_PITCH, "bin", ref.consts.detector.RESPONSE_BIN_SIZE,
+              "sampling", ref.consts.detector.RESPONSE_SAMPLING, "N_PIXELS", ref.consts.detector.N_PIXELS)
 
 
 def gen_qd():
@@ -947,7 +964,38 @@ def gen_packets():
                 r["kind"] = 6; r["timestamp"] = p.timestamp; r["io_group"] = p.io_group; r["trigger_type"] = p.sync_type[0]
             else:
                 r["kind"] = 7; r["timestamp"] = p.timestamp; r["io_group"] = p.io_group; r["trigger_type"] = p.trigger_type[0]
-        np.savez_compressed(os.path.join(GOLD, f"packets_{cfg}.npz"), event_id_list=event_id_list.astype("i4"),
+        # the driver's own packets between events (cli/simulate_pixels.py:876-890): fee.export_sync_to_hdf5 and
+        # fee.export_timestamp_trigger_to_hdf5, for all io groups (i_mod = -1) and for module 1's (i_mod = 1)
+        extra = {}
+
+        def bag_rows(pk):
+            rr = np.zeros(len(pk), dtype=[("kind", "i4"), ("io_group", "i8"), ("timestamp", "f8"), ("trigger_type", "i8")])
+            for i, p in enumerate(pk):
+                if p.kind == "timestamp":
+                    rr[i] = (4, p.chip_key.io_group, float(p.timestamp), 0)
+                elif p.kind == "sync":
+                    rr[i] = (6, p.io_group, p.timestamp, p.sync_type[0])
+                else:
+                    rr[i] = (7, p.io_group, p.timestamp, p.trigger_type[0])
+            return rr
+        period = ref.detector.CLOCK_RESET_PERIOD * ref.detector.CLOCK_CYCLE
+        sync_times = np.array([period, period, 3 * period + 17.0])       # the last one is not a multiple: floored with a warning
+        for i_mod in (-1, 1):
+            import warnings
+            saved = _File.store
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _File.store = {}
+                pk_s, as_s = fee.export_sync_to_hdf5("x.h5", sync_times, i_mod)
+            _File.store = {}
+            pk_t, as_t = fee.export_timestamp_trigger_to_hdf5("x.h5", event_times, i_mod)
+            _File.store = saved
+            extra[f"sync_rows_{i_mod}"] = bag_rows(pk_s)
+            extra[f"tt_rows_{i_mod}"] = bag_rows(pk_t)
+            extra[f"sync_assn_n_{i_mod}"] = len(as_s)
+            assert (as_s["event_ids"] == -1).all() and (as_t["segment_ids"] == -1).all() and (as_t["fraction"] == 0).all()
+        extra["sync_times"] = sync_times
+        np.savez_compressed(os.path.join(GOLD, f"packets_{cfg}.npz"), event_id_list=event_id_list.astype("i4"), **extra,
                             adc=adc, ticks=ticks, fractions=frac, unique_pix=upix, segment_ids=seg_ids, traj_ids=traj_ids,
                             event_times=event_times, trig_times=np.zeros(n_ev) + 3.0,
                             bad_key=np.array(list(bad_dict.keys())[0] if bad else ""),

@@ -271,16 +271,42 @@ def test_packets_writer_golden(cfg):
     assert np.array_equal(assn["file_traj_ids"], g["assn_file_traj_ids"])
     assert np.array_equal(assn["fraction_traj"], g["assn_fraction_traj"])
     assert packets.packets_dtype.itemsize == 36 and assn.dtype == packets.assn_dtype()
+    # the driver's packets between events: fee.export_sync_to_hdf5 / export_timestamp_trigger_to_hdf5 (fee.py:361-497), for
+    # all io groups and for one module's
+    for i_mod in (-1, 1):
+        for name, (pk2, as2) in (("sync", packets.build_sync_packets(g["sync_times"], i_mod)),
+                                 ("tt", packets.build_timestamp_trigger_packets(g["event_times"], i_mod))):
+            ref = g[f"{name}_rows_{i_mod}"]
+            assert len(pk2) == len(ref) == len(as2) and len(ref) > 0
+            assert np.array_equal(pk2["packet_type"], ref["kind"]) and np.array_equal(pk2["io_group"], ref["io_group"])
+            assert np.array_equal(pk2["timestamp"], ref["timestamp"].astype(np.uint64))
+            st = (ref["kind"] == 6) | (ref["kind"] == 7)
+            assert np.array_equal(pk2["trigger_type"][st].astype(np.int64), ref["trigger_type"][st])
+            assert (as2["event_ids"] == -1).all() and (as2["segment_ids"] == -1).all() and (as2["fraction"] == 0).all()
 
 
 def test_config_keyword_resolution():
     """config.get_config follows larndsim/config/config.py:40-69: bare names joined to their family's directory, names with
-    '/' kept, lists element by element, other keys passed through; mod2mod keywords are refused, never aliased."""
+    '/' kept, lists element by element, other keys passed through; the module-variation decision and the per-module file
+    lists follow cli/simulate_pixels.py:106-122, 355-372."""
     from larndsim_amd import config
-    assert set(config.list_config_keys()) == {"module0", "2x2_no_modvar", "ndlar"}          # built-in snapshots
+    assert set(config.list_config_keys()) == {"module0", "2x2", "2x2_no_modvar", "ndlar"}   # built-in snapshots
     assert config.get_config("ndlar")["SNAPSHOT"] == "ndlar"
     with pytest.raises(KeyError, match="not in supported keywords"):
-        config.get_config("2x2")
+        config.get_config("2x2_mpvmpr")
+    b = config.get_config("2x2")
+    assert b["MOD2MOD_VARIATION"] is True and len(b["SNAPSHOT"]) == 4
+    assert config.module_variation_active(b, 4, None, b["PIXEL_LAYOUT"], b["RESPONSE"], None)
+    assert not config.module_variation_active(b, 1, None, b["PIXEL_LAYOUT"], b["RESPONSE"], None)      # one module
+    assert not config.module_variation_active(b, 4, None, "a.yaml", ["r.npy"], "lut.npz")             # a single set of files
+    assert not config.module_variation_active(b, 4, False, b["PIXEL_LAYOUT"], b["RESPONSE"], None)     # switched off by the flag
+    assert config.module_files(b, b["PIXEL_LAYOUT"], "PIXEL_LAYOUT_ID", 4) == [b["PIXEL_LAYOUT"][i] for i in (0, 0, 1, 0)]
+    assert config.module_files(b, ["a", "b", "c", "d"], "NO_SUCH_ID", 4) == ["a", "b", "c", "d"]
+    with pytest.raises(KeyError, match="number of response files is incorrect"):
+        config.module_files(b, ["a", "b", "c"], "NO_SUCH_ID", 4, "response files")
+    assert config.single_file(["x"]) == "x" and config.single_file("x") == "x"
+    with pytest.raises(KeyError, match="more than one"):
+        config.single_file(["x", "y"], "response file")
     if not os.path.isdir(REF):
         pytest.skip("reference tree not present on this box")
     keys = set(config.list_config_keys(REF))
@@ -291,13 +317,19 @@ def test_config_keyword_resolution():
     assert c["RESPONSE"] == os.path.join(REF, "bin", "response_44.npy")
     assert c["LIGHT_LUT"].startswith("/global/cfs/")                   # has a '/': kept as written
     assert c["MOD2MOD_VARIATION"] is False and c["LIGHT_SIMULATED"] is True
-    config.check_single_configuration("2x2_no_modvar", c)
     m = config.get_config("2x2", REF)
     assert m["PIXEL_LAYOUT"] == [os.path.join(REF, "pixel_layouts", f) for f in
                                  ("multi_tile_layout-2.4.16.yaml", "multi_tile_layout-2.5.16.yaml")]
     assert m["PIXEL_LAYOUT_ID"] == [0, 0, 1, 0] and m["MOD2MOD_VARIATION"] is True
-    with pytest.raises(NotImplementedError, match="module-to-module variation"):
-        config.check_single_configuration("2x2", m)
+    # per-module loading through the package's own YAML loader == the per-module snapshots written from the reference's
+    layouts = config.module_files(m, m["PIXEL_LAYOUT"], "PIXEL_LAYOUT_ID", 4)
+    assert consts.get_n_modules(m["DET_PROPERTIES"]) == [1, 2, 3, 4]
+    for i_mod in (1, 2, 3, 4):
+        consts.load_properties(m["DET_PROPERTIES"], layouts, m["SIM_PROPERTIES"], i_module=i_mod)
+        mine = json.loads(json.dumps(consts.snapshot_dict()))
+        snap = json.load(open(os.path.join(REPO, "larnd-sim_amd", "larndsim_amd", "snapshots", f"2x2_mod{i_mod}.json")))
+        assert mine == snap, i_mod
+    assert consts.detector.RESPONSE_SAMPLING == 0.05 and consts.sim.MAX_MC_TRUTH_IDS == 50
     with pytest.raises(KeyError):
         config.get_config("2x2_mod2mod_variation", REF)               # the reference CLI's default keyword is not in its own map
     # the resolved files load through the package's own YAML loader

@@ -1493,7 +1493,7 @@ def _load_cli():
 def test_cli_end_to_end(tmp_path):
     """simulate_pixels CLI on a .npy segment file (edep-sim frame), shipped noise charges, seeded: the per-pixel arrays equal
     a ChargeChain run by hand with the same seed, the LArPix packets are what packets.build_packets makes of them, the
-    segments come back in the edep-sim frame, and a mod2mod keyword is refused instead of aliased."""
+    segments come back in the edep-sim frame, and an unknown keyword is refused."""
     from larndsim_amd import packets
     cli = _load_cli()
     H.load_cfg("module0")
@@ -1532,9 +1532,69 @@ def test_cli_end_to_end(tmp_path):
     by_id = {int(r["segment_id"]): r for r in seg}
     for r in out["segments"]:
         assert r["x"] == by_id[int(r["segment_id"])]["x"] and r["z"] == by_id[int(r["segment_id"])]["z"]
-    # a keyword of another detector description is refused, not aliased (there is no built-in '2x2')
+    # an unknown keyword is refused
     with pytest.raises(KeyError, match="not in supported keywords"):
-        cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out2.npz"), config="2x2")
+        cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out2.npz"), config="2x2_mpvmpr")
+
+
+def test_cli_module_variation(tmp_path):
+    """--config 2x2: the reference's module-variation keyword (per-module constants: module 3 has the 3.88 mm pixel layout,
+    all four 50 ns response sampling).  The driver's module loop (cli/simulate_pixels.py:676-715): every module simulated
+    with its own constants on its own segments.  Checked: each module's per-pixel arrays equal a ChargeChain run by hand
+    under that module's snapshot; data packets sit on the module's io groups; the light datasets come per module and the
+    per-module waveforms are merged side by side; the segments of all modules come back once."""
+    from larndsim_amd import packets
+    cli = _load_cli()
+    consts.load_snapshot("2x2_mod1")
+    seg = synth.make_segments(360, seed=21, segs_per_event=120, spill=True, max_track_len=4.0)   # short tracks: every module hit
+    np.save(tmp_path / "in.npy", seg)
+    luts = []
+    for i, sd in enumerate((3, 4)):
+        np.savez(tmp_path / f"lut{i}.npz", arr=synth.make_lut((14, 26, 8), 48, 40, sd))
+        luts.append(str(tmp_path / f"lut{i}.npz"))
+    res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out.npz"), config="2x2", rand_seed=5, raw_arrays=True,
+                             light_lut_filename=luts)
+    out = np.load(tmp_path / "out.npz")
+    assert res["n_segments"] == out["segments"].shape[0] > 150 and res["n_hits"] > 50
+    assert len(np.unique(out["segments"]["segment_id"])) == out["segments"].shape[0]
+    pk = out["packets"]
+    data = pk[pk["packet_type"] == 0]
+    n_data = 0
+    tr_all = cli.prepare_tracks(seg.copy())
+    for i_mod in (1, 2, 3, 4):
+        consts.load_snapshot(f"2x2_mod{i_mod}")
+        det = consts.detector
+        if i_mod == 3:
+            assert det.N_PIXELS == (160, 320) and abs(det.PIXEL_PITCH - 0.387975) < 1e-12
+        act = tr_all[batching.select_active_volume(tr_all, det.TPC_BORDERS)]
+        borders = det.TPC_BORDERS[(i_mod - 1) * 2: i_mod * 2]
+        tr = act[batching.select_active_volume(act, borders)]
+        bid, order, table = batching.assign_batches(tr, tpc_borders=borders)
+        tr, bid = np.ascontiguousarray(tr[order]), bid[order]
+        ch = ChargeChain(synth.make_response("survey", response_sampling=det.RESPONSE_SAMPLING))
+        ch.upload(tr, bid); ch.quench_drift(); ch.run(0, len(tr), want_fractions=True)
+        ref = ch.download()
+        k = f"raw_mod{i_mod - 1}__"
+        assert np.array_equal(out[k + "unique_pix"], ref["unique_pix"]), i_mod
+        # the FEE noise draws differ (the CLI's state table has been advanced by the modules before), the pixel sets do not
+        planes = ref["unique_pix"] // (det.N_PIXELS[0] * det.N_PIXELS[1])
+        assert set(np.unique(planes)) <= {2 * (i_mod - 1), 2 * (i_mod - 1) + 1} and len(ref["unique_pix"]) > 10
+        n_mod_data = int((out[k + "adc_digit"] > packets._digitize0()).sum())
+        n_data += n_mod_data
+        dat = out[f"light_dat__light_dat_module{i_mod - 1}"]
+        assert dat.shape == (len(tr), 96) and (dat["n_photons_det"] > 0).any()
+    assert len(data) == n_data
+    io = consts.detector.MODULE_TO_IO_GROUPS
+    assert set(np.unique(data["io_group"])) <= set(g for v in io.values() for g in v) and len(np.unique(data["io_group"])) >= 4
+    # beam trigger mode: one waveform row per (event, module group) and module, merged to all 384 channels; one light_trig row
+    # per spill
+    light = consts.light
+    ns = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING))
+    wv = out["light_wvfm"]
+    assert wv.shape[1:] == (384, ns) and wv.shape[0] == res["n_light_triggers"] // 4 >= 2 and (wv != 0).any()
+    assert not any(k.startswith("light_wvfm/") or k.startswith("light_wvfm__") for k in out.files)
+    assert out["light_trig"].shape[0] == len(np.unique(seg["event_id"])) and out["light_trig"]["op_channel"].shape[1] == 384
+    assert (out["light_wvfm_mc_assn"]["op_channel_id"] >= 96).any()          # channel ids of modules past the first
 
 
 def test_cli_light_leg(tmp_path):
