@@ -1023,6 +1023,79 @@ def test_compact_hit_rows_decode_to_the_downloaded_arrays():
         cm.destroy()
 
 
+def test_light_waveform_chain_properties_full_spill():
+    """One full 2x2 spill (5000 segments, all 384 channels, 16000 ticks, the shipped 16 us window) through the resident
+    light waveform chain, checked by properties that do not need the O(T*C) oracle loops: the scintillation stage conserves
+    photons up to the window's end, the Poisson stage conserves them statistically, the SiPM stage is the gain-scaled linear
+    convolution with the impulse model (FFT reference), the beam trigger digitises every channel, samples are LSB multiples."""
+    H.load_cfg("2x2_no_modvar")
+    consts.sim.MAX_MC_TRUTH_IDS = 0
+    light = consts.light
+    seg = synth.make_segments(5000, seed=20241016 + 3, segs_per_event=5000, spill=True)
+    batching.swap_coordinates(seg)
+    seg = seg[batching.select_active_volume(seg, consts.detector.TPC_BORDERS)]
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = np.ascontiguousarray(seg[order]), bid[order]
+    assert len(table) == 1
+    lut = synth.make_lut((14, 26, 8), 48, 100, 3)
+    ch = ChargeChain()
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    ch.light_incidence(lut)
+    opc = light.TPC_TO_OP_CHANNEL[:].ravel()
+    n_ticks, t_start = ch.sum_light(0, len(seg), opc)
+    assert n_ticks == 16000 and t_start == 0
+    inc, _, _ = ch.download_light()
+    ch.seed_rng(11, opc.shape[0] * n_ticks)
+    ch.light_response(fluctuate=True)
+    sc, di, resp, _, _ = ch.download_light_response(stages=True)
+    tick = light.LIGHT_TICK_SIZE
+    # scintillation: every photon is spread over the profile; what falls past the end of the array is lost, nothing is gained
+    C = int(np.ceil((light.LIGHT_WINDOW[1] - light.LIGHT_WINDOW[0]) / tick))
+    n = np.arange(C + 1)
+    w = (light.SINGLET_FRACTION * np.exp(-n * tick / light.TAU_S) * (1 - np.exp(-tick / light.TAU_S))
+         + (1 - light.SINGLET_FRACTION) * np.exp(-n * tick / light.TAU_T) * (1 - np.exp(-tick / light.TAU_T)))
+    tot_in, tot_sc = inc.sum(axis=1, dtype=np.float64), sc.sum(axis=1, dtype=np.float64)
+    live = tot_in > 0
+    assert live.sum() > 300 and (tot_sc[live] <= tot_in[live] * (w.sum() + 1e-5)).all()
+    assert (tot_sc[live] > 0.95 * tot_in[live]).all()            # arrivals sit in the first microseconds of a 16 us array
+    ref_sc = np.array([np.convolve(inc[d].astype(np.float64), w)[:n_ticks] for d in np.flatnonzero(live)[:4]])
+    np.testing.assert_allclose(sc[np.flatnonzero(live)[:4]], ref_sc, rtol=2e-4, atol=1e-6 * ref_sc.max())
+    # Poisson: integer counts per tick, totals within 6 sigma of the expectation
+    counts = di.astype(np.float64) * tick
+    assert np.array_equal(counts, np.round(counts)) and (di[sc <= 0] == 0).all()
+    mean = tot_sc * tick
+    assert (np.abs(counts.sum(axis=1) - mean)[live] < 6 * np.sqrt(mean[live]) + 6).all()
+    # SiPM response = LIGHT_GAIN[row] * (disc convolved with the impulse model resampled to the tick), f4 accumulation
+    imp = np.asarray(light.IMPULSE_MODEL, dtype=float)
+    idx = n * tick / light.IMPULSE_TICK_SIZE
+    i0 = np.floor(idx).astype(int)
+    wi = np.where(i0 > len(imp) - 2, np.where((i0 == idx) & (i0 <= len(imp) - 1), imp[np.minimum(i0, len(imp) - 1)], 0.0),
+                  imp[np.minimum(i0, len(imp) - 2)] + (imp[np.minimum(i0 + 1, len(imp) - 1)] - imp[np.minimum(i0, len(imp) - 2)]) * (idx - i0))
+    wi = wi / (light.IMPULSE_TICK_SIZE / tick)
+    rows = np.flatnonzero(live)[:4]
+    ref_r = np.array([light.LIGHT_GAIN[d] * np.convolve(di[d].astype(np.float64), wi)[:n_ticks] for d in rows])
+    np.testing.assert_allclose(resp[rows], ref_r, rtol=5e-4, atol=2e-6 * np.abs(ref_r).max())
+    assert resp.min() < 0 <= resp.max() + 1e-3                   # negative-going pulses (gain < 0)
+    # beam trigger mode: one trigger at tick 0 on every channel; LSB-quantised waveforms that carry the pulses
+    thr = np.repeat(np.array(light.LIGHT_TRIG_THRESHOLD)[..., None], light.OP_CHANNEL_PER_TRIG, axis=-1).ravel()[opc]
+    thr = thr.reshape(-1, light.OP_CHANNEL_PER_TRIG)[..., 0].copy()
+    trig, trig_op, trig_type = light_sim.get_triggers(None, thr, opc, 0)
+    assert trig.tolist() == [0] and trig_type.tolist() == [1] and trig_op.shape == (1, 384)
+    ns = int(np.ceil((light.LIGHT_TRIG_WINDOW[1] + light.LIGHT_TRIG_WINDOW[0]) / light.LIGHT_DIGIT_SAMPLE_SPACING))
+    wv, _, _ = light_sim.sim_triggers(None, None, None, opc, None, None, trig, trig_op, ns, None)
+    lsb = 2.0 ** (16 - light.LIGHT_NBIT)
+    assert wv.shape == (1, 384, ns) and np.array_equal(wv, np.round(wv / lsb) * lsb)
+    # sample i reads padded tick 16 i; the padding in front is LIGHT_TRIG_WINDOW[0] / tick ticks of zeros
+    pre = int(np.ceil(light.LIGHT_TRIG_WINDOW[0] / tick))
+    step = int(round(light.LIGHT_DIGIT_SAMPLE_SPACING / tick))
+    k = np.arange(ns) * step - pre
+    ok = (k >= 0) & (k < n_ticks)
+    expect = np.zeros((384, ns))
+    expect[:, ok] = resp[:, k[ok]]
+    assert np.array_equal(wv[0], np.round(expect / lsb) * lsb)
+
+
 def test_stage_call_between_upload_and_run_is_refused():
     """The host-buffer stage calls upload their records into the store the resident chain uses.  A chain call that finds
     the store taken over by a stage call must refuse (LDSIM_ESTATE) instead of simulating the stage call's records."""
