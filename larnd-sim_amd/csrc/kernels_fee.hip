@@ -15,19 +15,29 @@
 #define M_MAX 64      // max MAX_TRACKS_PER_PIXEL handled by the chain kernel
 
 
+// Wave-64 scans with DPP (row shifts inside the 16-lane rows, then row_bcast:15 / :31 across rows: the GFX9 controls gfx950
+// keeps) instead of shuffles through the LDS crossbar, whose latency the trigger scan paid six times per 64-tick chunk.
+// Lanes without a source read 0 (bound_ctrl), rows masked out keep the `old` operand 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    double o = __shfl_up(v, off);
-    if (lane >= off) v += o;
-  }
+  v += dpp_or_zero<0x111, 0xF>(v);       // row_shr:1
+  v += dpp_or_zero<0x112, 0xF>(v);       // row_shr:2
+  v += dpp_or_zero<0x114, 0xF>(v);       // row_shr:4
+  v += dpp_or_zero<0x118, 0xF>(v);       // row_shr:8   -> inclusive scan inside every row of 16
+  v += dpp_or_zero<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3: + total of the row before
+  v += dpp_or_zero<0x143, 0xC>(v);       // row_bcast:31 into rows 2 and 3: + total of lanes 0..31
   return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return __shfl(v, 0);
+// value of lane l (wave-uniform index) in every lane
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+__device__ __forceinline__ double wave_sum(double v) { return lane_bcast(wave_incl_scan(v, 0), 63); }
 
 // q(ic): buffer-convolved charge of tick ic (fee.py:566-579), taps limited by last_reset and N_t
 __device__ __forceinline__ double conv_q(const double* S, int NT, int ic, int last_reset, int ntap, const double* wtap,
@@ -103,15 +113,15 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
     if (tm == 0) {
       if (z) cur += 2 * n_live;
       if (n_live < 64) break;
-      q_sum = __shfl(qs, 63);
-      true_q += __shfl(incl, 63);
+      q_sum = lane_bcast(qs, 63);
+      true_q += lane_bcast(incl, 63);
       ic += 64;
       adc_busy = adc_busy > 64 ? adc_busy - 64 : 0;
       continue;
     }
     int f = __ffsll((long long)tm) - 1;
-    q_sum = __shfl(qs, f);
-    true_q += __shfl(incl, f);
+    q_sum = lane_bcast(qs, f);
+    true_q += lane_bcast(incl, f);
     if (z) cur += 2 * (f + 1);
     int ict = ic + f;
     int integrate_end = ict + interval;
@@ -170,7 +180,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   const int A = c->max_adc_values, M = c->max_tracks_per_pixel;
   const double dt = c->time_sampling, rt = c->buffer_risetime;
 
-  __shared__ double S[NT_MAX];
+  extern __shared__ double S[];          // [n_time_ticks]: sized at launch, so LDS (not VGPRs) stops at 8 pixels per CU
   __shared__ HitRec hits[A_MAX];
   __shared__ int s_start[M_MAX];
   __shared__ int64_t s_row[M_MAX];
@@ -253,9 +263,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   }
   // ---- backtracking fractions (fee.py:572-573, 633-635): sum_jc sig_k[jc]*G[min(ntap, b-jc)] / true_q ------------
   if (F.fractions) {
-    double* fr = F.fractions + u * (int64_t)A * M;
-    for (int i = tid; i < A * M; i += FEE_THREADS) fr[i] = 0;
-    __syncthreads();
+    double* fr = F.fractions + u * (int64_t)A * M;       // zero on entry (one memset of the whole array by the launcher)
     for (int k = wv; k < n_slots; k += FEE_THREADS / 64) {
       const float* wf = F.waves + s_row[k] * (int64_t)F.T;
       const int st = s_start[k];
@@ -285,7 +293,9 @@ extern "C++" int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F) {
     ldsim_set_error("FEE constants exceed the kernel's static tiles");
     return LDSIM_EINVAL;
   }
-  hipLaunchKernelGGL(pixel_adc_kernel, dim3((unsigned)F.U), dim3(FEE_THREADS), 0, ctx->stream, F);
+  if (F.fractions)      // the kernel writes the (hit, slot) entries that exist; everything else reads 0 like the reference's array
+    HIPCHK(hipMemsetAsync(F.fractions, 0, (size_t)F.U * h.max_adc_values * h.max_tracks_per_pixel * 8, ctx->stream));
+  hipLaunchKernelGGL(pixel_adc_kernel, dim3((unsigned)F.U), dim3(FEE_THREADS), (size_t)((h.n_time_ticks + 1) & ~1) * 8, ctx->stream, F);
   HIPCHK(hipGetLastError());
   return 0;
 }
