@@ -15,6 +15,7 @@
 // Pairs whose segment is longer than ~130 widths (N > 256: sT -> 0 next to the anode) and pairs that exceed the item /
 // correction / run capacities are flagged and recomputed by the monolithic current_kernel, like in weights_kernel.
 #include "qpair.h"
+#include "wave_ops.h"
 
 #define QNB 16            // quadrature nodes per batch (tables of one batch live in LDS)
 #define QTILES 512        // (cell, 8-shift block) tiles per column group: two per thread, accumulated in registers
@@ -54,6 +55,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   __shared__ double s_X[QNB][QCOLS], s_Y[QNB][NJ_MAX], s_Z[QNB][ZC], s_Zi[QNB][ZC];
   __shared__ double s_C[NEDGE][NU_MAX];
   __shared__ double s_dx[NS_MAX], s_dy[NS_MAX], s_dz[ZC], s_Q[QNB];
+  // the same offsets in member-list order (position k of s_ixord / s_iyord / s_zord): the table tasks walk a bin's members
+  // with one LDS read per member instead of an index read followed by a dependent value read
+  __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
+  __shared__ unsigned char s_invs[ZC];
   __shared__ int s_shift[ZC], s_inval[ZC];
   __shared__ short s_icell[NS_MAX], s_jcell[NS_MAX], s_colof[NS_MAX], s_coli[NS_MAX], s_colstart[NS_MAX + 1];
   __shared__ short s_jstart[NJ_MAX + 1], s_ustart[NU_MAX + 1];
@@ -102,14 +107,13 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       int sq = __builtin_amdgcn_readlane(myslot, q);
       if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
     }
-    if (myslot >= 0) s_ixord[posn] = (unsigned char)lane;
+    if (myslot >= 0) {
+      s_ixord[posn] = (unsigned char)lane;
+      s_dxs[posn] = ddx;
+    }
     if (is_leader) s_colstart[slot] = (short)posn;
     int nvalid = __popcll(__ballot(myslot >= 0));
-    double lo = myslot >= 0 ? ddx : 1e300, hi = myslot >= 0 ? ddx : -1e300;
-    for (int off = 32; off > 0; off >>= 1) {
-      lo = fmin(lo, __shfl_down(lo, off));
-      hi = fmax(hi, __shfl_down(hi, off));
-    }
+    const double lo = wave_min_f64(myslot >= 0 ? ddx : 1e300), hi = wave_max_f64(myslot >= 0 ? ddx : -1e300);
     if (lane == 0) {
       s_colstart[ncol] = (short)nvalid;
       s_misc[0] = ncol;
@@ -134,14 +138,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       ddy = y - s_par[PP_SY];
       s_dy[lane] = ddy;
     }
-    int jmin = (j >= 0) ? j : (1 << 20), jmax = j;
-    double lo = j >= 0 ? ddy : 1e300, hi = j >= 0 ? ddy : -1e300;
-    for (int off = 32; off > 0; off >>= 1) {
-      jmin = min(jmin, __shfl_xor(jmin, off));
-      jmax = max(jmax, __shfl_xor(jmax, off));
-      lo = fmin(lo, __shfl_xor(lo, off));
-      hi = fmax(hi, __shfl_xor(hi, off));
-    }
+    const int jmin = wave_min_i32((j >= 0) ? j : (1 << 20)), jmax = wave_max_i32(j);
+    const double lo = wave_min_f64(j >= 0 ? ddy : 1e300), hi = wave_max_f64(j >= 0 ? ddy : -1e300);
     // members of one j are contiguous in s_iyord; s_jstart[j'] = number of valid samples with j < jmin + j'
     int posn = 0, below = 0;
     for (int q = 0; q < NS; q++) {
@@ -149,7 +147,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       if (jq >= 0 && j >= 0 && (jq < j || (jq == j && q < lane))) posn++;
       if (jq >= 0 && jq < jmin + lane) below++;
     }
-    if (j >= 0) s_iyord[posn] = (unsigned char)lane;
+    if (j >= 0) {
+      s_iyord[posn] = (unsigned char)lane;
+      s_dys[posn] = ddy;
+    }
     if (jmax >= jmin && lane <= jmax - jmin + 1 && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
     if (lane == 0) {
       s_misc[1] = jmin;
@@ -189,13 +190,15 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     if (wv == 0) {
       int nmax = min(ZC, iz_hi - iz_next + 1);
       int sh = 0, inval = 0;
+      double dzv = 0;
       if (lane < nmax) {
         double z, t0;
         bool amb;
         sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_next + lane, z,
                                t0, amb);
         if (amb) atomicAdd(&A.counters[0], 1ull);
-        s_dz[lane] = z - s_par[PP_SZ];
+        dzv = z - s_par[PP_SZ];
+        s_dz[lane] = dzv;
         s_shift[lane] = sh;
 #pragma unroll
         for (int e = 0; e < NEDGE; e++) {
@@ -215,11 +218,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
         }
         s_inval[lane] = inval;
       }
-      int pmin = lane < nmax ? sh : (1 << 30), pmax = lane < nmax ? sh : -(1 << 30);
-      for (int off = 1; off < 64; off <<= 1) {
-        int a1 = __shfl_up(pmin, off), a2 = __shfl_up(pmax, off);
-        if (lane >= off) { pmin = min(pmin, a1); pmax = max(pmax, a2); }
-      }
+      const int pmin = wave_scan_i32(lane < nmax ? sh : (1 << 30), 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+      const int pmax = wave_scan_i32(lane < nmax ? sh : -(1 << 30), (int)0x80000000, [](int a, int b) { return a > b ? a : b; });
       bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
       unsigned long long fm = __ballot(fits);
       int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
@@ -231,11 +231,17 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
         if (lane < n && (sq < sh || (sq == sh && q < lane))) posn++;
         if (sq < lo + lane) below++;
       }
-      if (lane < n) s_zord[posn] = (unsigned char)lane;
+      if (lane < n) {
+        s_zord[posn] = (unsigned char)lane;
+        s_dzs[posn] = dzv;
+        s_invs[posn] = (unsigned char)inval;
+      }
       if (lane < hi - lo + 1) s_ustart[lane] = (short)below;
       if (lane == 0) s_ustart[hi - lo + 1] = (short)n;
-      anyinv = (lane < n) ? inval : 0;
-      for (int off = 32; off > 0; off >>= 1) anyinv |= __shfl_xor(anyinv, off);
+      anyinv = 0;
+#pragma unroll
+      for (int e = 0; e < NEDGE; e++)
+        if (__ballot(lane < n && (inval & (1 << e)))) anyinv |= 1 << e;
       if (lane == 0) {
         s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
         s_misc[20] = anyinv;
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
               const double cen = sn * uxr;
               double sum = 0;
               for (int k = s_colstart[col0 + b]; k < s_colstart[col0 + b + 1]; k++) {
-                const double d = s_dx[s_ixord[k]] - cen;
+                const double d = s_dxs[k] - cen;
                 sum += exp_neg(-d * d * i2T);
               }
               s_X[n][b] = sum;
@@ -293,7 +299,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
               const double cen = sn * uyr;
               double sum = 0;
               for (int k = s_jstart[b]; k < s_jstart[b + 1]; k++) {
-                const double d = s_dy[s_iyord[k]] - cen;
+                const double d = s_dys[k] - cen;
                 sum += exp_neg(-d * d * i2T);
               }
               s_Y[n][b] = sum;
@@ -301,11 +307,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
               const double cen = sn * uzr;
               double sum = 0, sumi = 0;
               for (int k = s_ustart[b]; k < s_ustart[b + 1]; k++) {
-                const int sl = s_zord[k];
-                const double d = s_dz[sl] - cen;
+                const double d = s_dzs[k] - cen;
                 const double e = exp_neg(-d * d * i2L);
                 sum += e;
-                if (s_inval[sl]) sumi += e;      // refined per edge below when several edges are flagged
+                if (s_invs[k]) sumi += e;        // refined per edge below when several edges are flagged
               }
               double wn = wscale * gw_tab[n0 + n];
               if (kappa != 0.0) wn *= exp_neg(-sn * sn * kappa);
@@ -375,8 +380,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
               }
 #pragma unroll
               for (int m = 0; m < QNB / NWAVE; m++) {
-                double p = part[m];
-                for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+                const double p = wave_add_f64(part[m]);
                 if (lane == 0 && wv + NWAVE * m < nb) s_Q[wv + NWAVE * m] = p;
               }
             }
@@ -414,11 +418,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
           const int ulo = act ? __ffsll((long long)mk) - 1 : 0, uhi = act ? 63 - __clzll((long long)mk) : 0;
           unsigned long long am = __ballot(act);
           int nb8 = act ? ((uhi - (ulo & ~7)) / 8 + 1) : 0;
-          int sc = nb8;
-          for (int off = 1; off < 64; off <<= 1) {
-            int o = __shfl_up(sc, off);
-            if (lane >= off) sc += o;
-          }
+          const int sc = wave_scan_i32(nb8, 0, [](int a, int b) { return a + b; });
           if (cell < ncell) {
             s_culo[cell] = act ? (unsigned char)ulo : (unsigned char)255;
             s_cuhi[cell] = (unsigned char)uhi;
