@@ -86,27 +86,33 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       ddx = x - s_par[PP_SX];
       s_dx[lane] = ddx;
     }
-    int leader = lane;
-    for (int q = 0; q < NS; q++) {
-      int iq = __builtin_amdgcn_readlane(i, q);
-      if (q < leader && iq == i) leader = q;
+    // Cells present, as a bit mask over i (ni < 64); the loop below runs over its set bits -- the handful of distinct cells
+    // the 40 samples fall into -- with one ballot each, instead of over the 40 lanes three times.
+    const bool valid = lane < NS && i >= 0;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    unsigned long long present = 0;
+    {
+      const int mlo = wave_lane_i32(wave_scan_i32(valid && i < 32 ? (1 << i) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      const int mhi = wave_lane_i32(wave_scan_i32(valid && i >= 32 ? (1 << (i - 32)) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      present = (unsigned long long)(unsigned)mlo | ((unsigned long long)(unsigned)mhi << 32);
     }
-    bool is_leader = (lane < NS) && (i >= 0) && (leader == lane);
-    int slot = 0;   // rank of this column's i among the distinct i  -> cells come out sorted by (i, j)
-    for (int q = 0; q < NS; q++) {
-      int iq = __builtin_amdgcn_readlane(i, q);
-      bool lq = __builtin_amdgcn_readlane((int)is_leader, q);
-      if (lq && iq < i) slot++;
+    const int slot = valid ? __popcll(present & ((1ull << i) - 1ull)) : 0;    // rank of this column's i among the distinct i
+    const int ncol = __popcll(present);
+    int posn = 0;
+    bool is_leader = false;
+    for (unsigned long long m = present; m; m &= m - 1) {
+      const int bcell = __ffsll((long long)m) - 1;
+      const unsigned long long bal = __ballot(valid && i == bcell);
+      if (valid && i > bcell) posn += __popcll(bal);
+      if (valid && i == bcell) {
+        const int before = __popcll(bal & lane_lt);
+        posn += before;
+        is_leader = before == 0;
+      }
     }
-    int myslot = (i < 0 || lane >= NS) ? -1 : slot;
-    int ncol = __popcll(__ballot(is_leader));
+    const int myslot = valid ? slot : -1;
     if (lane < NS) s_colof[lane] = (short)myslot;
     if (is_leader) s_coli[slot] = (short)i;
-    int posn = 0;
-    for (int q = 0; q < NS; q++) {
-      int sq = __builtin_amdgcn_readlane(myslot, q);
-      if (sq >= 0 && myslot >= 0 && (sq < myslot || (sq == myslot && q < lane))) posn++;
-    }
     if (myslot >= 0) {
       s_ixord[posn] = (unsigned char)lane;
       s_dxs[posn] = ddx;
@@ -142,10 +148,15 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     const double lo = wave_min_f64(j >= 0 ? ddy : 1e300), hi = wave_max_f64(j >= 0 ? ddy : -1e300);
     // members of one j are contiguous in s_iyord; s_jstart[j'] = number of valid samples with j < jmin + j'
     int posn = 0, below = 0;
-    for (int q = 0; q < NS; q++) {
-      int jq = __builtin_amdgcn_readlane(j, q);
-      if (jq >= 0 && j >= 0 && (jq < j || (jq == j && q < lane))) posn++;
-      if (jq >= 0 && jq < jmin + lane) below++;
+    if (jmax >= jmin) {
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bj = jmin; bj <= jmax; bj++) {               // the few distinct j, one ballot each
+        const unsigned long long bal = __ballot(j == bj);
+        const int cnt = __popcll(bal);
+        if (j > bj) posn += cnt;
+        if (j == bj) posn += __popcll(bal & lane_lt);
+        if (bj < jmin + lane) below += cnt;
+      }
     }
     if (j >= 0) {
       s_iyord[posn] = (unsigned char)lane;

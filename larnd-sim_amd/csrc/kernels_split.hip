@@ -695,7 +695,7 @@ static int split_M(const ldsim_ctx* ctx, const CurArgs& args) {
   const LdsimConsts& h = ctx->h_consts;
   double ratio = h.time_sampling / h.response_sampling;
   int M = (int)llround(ratio);
-  if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX ||
+  if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX || args.ni > 64 ||
       args.ni * args.nj > 65535 || args.n_pairs > 0x7fffffffLL)
     return 0;
   return M;
