@@ -237,10 +237,15 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       int lo = __builtin_amdgcn_readlane(pmin, n - 1), hi = __builtin_amdgcn_readlane(pmax, n - 1);
       // slices of the chunk ordered by shift (|z - z_anode| need not be monotone in iz): s_zord, s_ustart[u]
       int posn = 0, below = 0, anyinv = 0;
-      for (int q = 0; q < n; q++) {
-        int sq = __builtin_amdgcn_readlane(sh, q);
-        if (lane < n && (sq < sh || (sq == sh && q < lane))) posn++;
-        if (sq < lo + lane) below++;
+      {
+        const unsigned long long lane_lt = (1ull << lane) - 1ull;
+        for (int bs = lo; bs <= hi; bs++) {                    // the chunk's distinct shifts (<= NU_MAX), one ballot each
+          const unsigned long long bal = __ballot(lane < n && sh == bs);
+          const int cnt = __popcll(bal);
+          if (lane < n && sh > bs) posn += cnt;
+          if (lane < n && sh == bs) posn += __popcll(bal & lane_lt);
+          if (bs < lo + lane) below += cnt;
+        }
       }
       if (lane < n) {
         s_zord[posn] = (unsigned char)lane;
