@@ -250,7 +250,7 @@ def main():
         value = n_job * a.steps / elapsed
         split = acc["w_ms"] > 0
         M = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
-        mac_name = "mac_shift_kernel" if M == 1 else f"mac_kernel<{M}>"       # csrc/kernels_macshift.hip / kernels_split.hip
+        mac_name = "mac_shift_kernel" if M == 1 else "mac_shift2_kernel"        # csrc/kernels_macshift.hip
         # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
