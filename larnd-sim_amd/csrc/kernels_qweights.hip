@@ -69,6 +69,79 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   __shared__ int s_misc[24];
   __shared__ unsigned long long s_base64;
 
+  // ---- one chunk's slices: response shift, edge flags, member lists ordered by shift.  One wave: wave 2 for the first
+  // chunk, while waves 0 / 1 build the sample maps (nothing here depends on them); wave 0 for the chunks after it.
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  auto chunk_setup = [&](int iz_first, bool first) {
+    int nmax = min(ZC, iz_hi - iz_first + 1);
+    int sh = 0, inval = 0;
+    double dzv = 0;
+    if (lane < nmax) {
+      double z, t0;
+      bool amb;
+      sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_first + lane, z,
+                             t0, amb);
+      if (amb) atomicAdd(&A.counters[0], 1ull);
+      dzv = z - s_par[PP_SZ];
+      s_dz[lane] = dzv;
+      s_shift[lane] = sh;
+#pragma unroll
+      for (int e = 0; e < NEDGE; e++) {
+        // a correction is needed only where the correlation would use this slice's weight at a tick the reference
+        // does not: the edge index must be inside the staged response range, reachable by this shift (an integer tick)
+        // and that tick inside the stored window; everything else is dropped at the end anyway
+        bool need = false;
+        const int num = edge_k[e] - sh;
+        if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+          const int it_e = num / M;
+          if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+            int64_t kk;
+            need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
+          }
+        }
+        if (need) inval |= 1 << e;
+      }
+      s_inval[lane] = inval;
+    }
+    const int pmin = wave_scan_i32(lane < nmax ? sh : (1 << 30), 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+    const int pmax = wave_scan_i32(lane < nmax ? sh : -(1 << 30), (int)0x80000000, [](int a, int b) { return a > b ? a : b; });
+    bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
+    unsigned long long fm = __ballot(fits);
+    int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
+    int lo = __builtin_amdgcn_readlane(pmin, n - 1), hi = __builtin_amdgcn_readlane(pmax, n - 1);
+    // slices of the chunk ordered by shift (|z - z_anode| need not be monotone in iz): s_zord, s_ustart[u]
+    int posn = 0, below = 0, anyinv = 0;
+    {
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bs = lo; bs <= hi; bs++) {                    // the chunk's distinct shifts (<= NU_MAX), one ballot each
+        const unsigned long long bal = __ballot(lane < n && sh == bs);
+        const int cnt = __popcll(bal);
+        if (lane < n && sh > bs) posn += cnt;
+        if (lane < n && sh == bs) posn += __popcll(bal & lane_lt);
+        if (bs < lo + lane) below += cnt;
+      }
+    }
+    if (lane < n) {
+      s_zord[posn] = (unsigned char)lane;
+      s_dzs[posn] = dzv;
+      s_invs[posn] = (unsigned char)inval;
+    }
+    if (lane < hi - lo + 1) s_ustart[lane] = (short)below;
+    if (lane == 0) s_ustart[hi - lo + 1] = (short)n;
+    anyinv = 0;
+#pragma unroll
+    for (int e = 0; e < NEDGE; e++)
+      if (__ballot(lane < n && (inval & (1 << e)))) anyinv |= 1 << e;
+    if (lane == 0) {
+      s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
+      s_misc[20] = anyinv;
+      const int r = first ? 0 : s_misc[19];            // the first chunk is set up next to the maps, before anyone wrote these
+      if (r < RUNS_MAX) hdr[8 + r] = first ? 0 : s_misc[16]; else s_misc[18] = 1;
+      s_misc[19] = r + 1;
+    }
+  };
+
   // ---- sample -> response cell maps; member lists ordered by response index (x: wave 0, y: wave 1) ----------------
   // (lane values are fetched with v_readlane -- the lane index is the loop counter, wave-uniform -- not with a shuffle through
   // the LDS crossbar, whose latency a non-unrolled loop pays on every iteration)
@@ -127,8 +200,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       s_rng[1] = hi;
       s_misc[16] = 0;   // items emitted
       s_misc[17] = 0;   // corrections emitted
-      s_misc[18] = 0;   // overflow
-      s_misc[19] = 0;   // runs
+      s_misc[18] = 0;   // overflow (s_misc[19], the run count, is set by the first chunk's set-up on wave 2)
     }
   } else if (wv == 1) {
     int j = -1;
@@ -169,6 +241,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       s_rng[2] = lo;
       s_rng[3] = hi;
     }
+  } else if (wv == 2) {
+    if (iz_lo <= iz_hi) chunk_setup(iz_lo, true);
+    else if (lane == 0) s_misc[19] = 0;
   }
   __syncthreads();
   const int ncol = s_misc[0], jmin = s_misc[1], jmax = s_misc[2];
@@ -176,8 +251,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   if (ncol == 0 || NJ <= 0 || NJ > NJ_MAX) { write_empty(); return; }
   if (A.debug_phases & 0x200) { write_empty(); return; }      // timing tools: stop after the sample maps
 
-  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
-  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
   const double* __restrict__ gx_tab = glx + (int64_t)NQ * (NQ - 1) / 2;
   const double* __restrict__ gw_tab = glw + (int64_t)NQ * (NQ - 1) / 2;
   const bool do_prune = A.prune_log > 0;
@@ -197,75 +270,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   int iz_next = iz_lo;
   while (iz_next <= iz_hi) {
     __syncthreads();
-    // ---- this chunk's slices: response shift, edge flags, member lists ordered by shift (wave 0) ------------------------------
-    if (wv == 0) {
-      int nmax = min(ZC, iz_hi - iz_next + 1);
-      int sh = 0, inval = 0;
-      double dzv = 0;
-      if (lane < nmax) {
-        double z, t0;
-        bool amb;
-        sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_next + lane, z,
-                               t0, amb);
-        if (amb) atomicAdd(&A.counters[0], 1ull);
-        dzv = z - s_par[PP_SZ];
-        s_dz[lane] = dzv;
-        s_shift[lane] = sh;
-#pragma unroll
-        for (int e = 0; e < NEDGE; e++) {
-          // a correction is needed only where the correlation would use this slice's weight at a tick the reference
-          // does not: the edge index must be inside the staged response range, reachable by this shift (an integer tick)
-          // and that tick inside the stored window; everything else is dropped at the end anyway
-          bool need = false;
-          const int num = edge_k[e] - sh;
-          if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
-            const int it_e = num / M;
-            if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
-              int64_t kk;
-              need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
-            }
-          }
-          if (need) inval |= 1 << e;
-        }
-        s_inval[lane] = inval;
-      }
-      const int pmin = wave_scan_i32(lane < nmax ? sh : (1 << 30), 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
-      const int pmax = wave_scan_i32(lane < nmax ? sh : -(1 << 30), (int)0x80000000, [](int a, int b) { return a > b ? a : b; });
-      bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
-      unsigned long long fm = __ballot(fits);
-      int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
-      int lo = __builtin_amdgcn_readlane(pmin, n - 1), hi = __builtin_amdgcn_readlane(pmax, n - 1);
-      // slices of the chunk ordered by shift (|z - z_anode| need not be monotone in iz): s_zord, s_ustart[u]
-      int posn = 0, below = 0, anyinv = 0;
-      {
-        const unsigned long long lane_lt = (1ull << lane) - 1ull;
-        for (int bs = lo; bs <= hi; bs++) {                    // the chunk's distinct shifts (<= NU_MAX), one ballot each
-          const unsigned long long bal = __ballot(lane < n && sh == bs);
-          const int cnt = __popcll(bal);
-          if (lane < n && sh > bs) posn += cnt;
-          if (lane < n && sh == bs) posn += __popcll(bal & lane_lt);
-          if (bs < lo + lane) below += cnt;
-        }
-      }
-      if (lane < n) {
-        s_zord[posn] = (unsigned char)lane;
-        s_dzs[posn] = dzv;
-        s_invs[posn] = (unsigned char)inval;
-      }
-      if (lane < hi - lo + 1) s_ustart[lane] = (short)below;
-      if (lane == 0) s_ustart[hi - lo + 1] = (short)n;
-      anyinv = 0;
-#pragma unroll
-      for (int e = 0; e < NEDGE; e++)
-        if (__ballot(lane < n && (inval & (1 << e)))) anyinv |= 1 << e;
-      if (lane == 0) {
-        s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
-        s_misc[20] = anyinv;
-        int r = s_misc[19];
-        if (r < RUNS_MAX) hdr[8 + r] = s_misc[16]; else s_misc[18] = 1;
-        s_misc[19] = r + 1;
-      }
-    }
+    if (wv == 0 && iz_next != iz_lo) chunk_setup(iz_next, false);
     for (int i = tid; i < NEDGE * NU_MAX; i += CUR_THREADS) (&s_C[0][0])[i] = 0;
     __syncthreads();
     const int n_sl = s_misc[3], u_min = s_misc[4];
