@@ -10,7 +10,8 @@
 
 // =============================================================================================================
 template <int M>
-__global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams* __restrict__ pp, int qn_max) {
+__global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams* __restrict__ pp, int qn_max, double qn0,
+                                                         double qslope) {
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -89,7 +90,9 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   }
   if (!(s_hi > s_lo) || iz_hi < iz_lo) { pp[pair] = P; return; }
   const double qlen = s_hi - s_lo;
-  const double nq_f = ceil(6.0 + 1.9 * qlen * sqrt(2.0 * a));
+  // nodes for a relative quadrature error of exp(-quad_log) of the peak weight: tools/quad_nodes.py (default 1e-10: 4.8 + 1.6 r;
+  // 1e-12 needs 6 + 1.9 r), r = clipped length in Gaussian widths along the segment
+  const double nq_f = ceil(qn0 + qslope * qlen * sqrt(2.0 * a));
   // response shifts of the slices -> the tick window in which any of them sees a staged response entry
   int sh_min = 1 << 30, sh_max = -(1 << 30);
   for (int iz = iz_lo; iz <= iz_hi; iz++) {
@@ -132,8 +135,9 @@ extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, v
   }
   PairParams* pp = (PairParams*)params;
   const unsigned g0 = (unsigned)((S.c.n_pairs + 255) / 256);
-  if (M == 1) hipLaunchKernelGGL(pair_setup_kernel<1>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax);
-  else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax);
+  if (M == 1) hipLaunchKernelGGL(pair_setup_kernel<1>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0,
+                                 ctx->quad_slope);
+  else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0, ctx->quad_slope);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -243,6 +243,13 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   }
   else if (!strcmp(name, "numba_f32")) ctx->numba_f32 = value != 0;
   else if (!strcmp(name, "mc_current")) ctx->mc_current = value != 0;
+  else if (!strcmp(name, "quad_accuracy_log10")) {
+    // relative quadrature error of the weights stage as a power of ten of the peak weight: 10 (default) or 12 (fits of
+    // tools/quad_nodes.py: N = ceil(4.8 + 1.6 r) / ceil(6 + 1.9 r) nodes for a segment r Gaussian widths long)
+    if (value == 10) { ctx->quad_n0 = 4.8; ctx->quad_slope = 1.6; }
+    else if (value == 12) { ctx->quad_n0 = 6.0; ctx->quad_slope = 1.9; }
+    else { ldsim_set_error("quad_accuracy_log10 must be 10 or 12"); return LDSIM_EINVAL; }
+  }
   else if (!strcmp(name, "quad_max_nodes")) {
     if (!(value >= 8 && value <= 256)) { ldsim_set_error("quad_max_nodes must be in [8, 256]"); return LDSIM_EINVAL; }
     ctx->gl_nmax = (int)value;

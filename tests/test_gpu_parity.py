@@ -1353,7 +1353,8 @@ def _two_event_set(cfg, seed, n=1200):
 
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 1), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
-                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0), ("mac_mode", 1)):
+                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0), ("mac_mode", 1),
+                    ("quad_accuracy_log10", 10)):
         lib.set_option(name, v)
 
 
@@ -1442,9 +1443,11 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
     ch.quench_drift()
     res = {}
     try:
-        for name, cap, prune in (("default", 256, 30.0), ("again", 256, 30.0), ("cap12", 12, 30.0), ("keepall", 256, 0.0)):
+        for name, cap, prune in (("default", 256, 30.0), ("again", 256, 30.0), ("cap12", 12, 30.0), ("keepall", 256, 0.0),
+                                 ("acc12", 256, 30.0)):
             lib.set_option("quad_max_nodes", cap)
             lib.set_option("prune_log", prune)
+            lib.set_option("quad_accuracy_log10", 12 if name == "acc12" else 10)
             st = ch.run(0, len(seg), want_fractions=True)
             res[name] = ch.download()
             if name == "default":
@@ -1458,6 +1461,9 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
     assert (a["adc_list"] != 0).sum() > 100
     for k in a:
         assert np.array_equal(a[k], res["again"][k]), f"{k}: not bitwise reproducible"
+    # the shipped node rule (1e-10 of the peak weight) against the tighter one (1e-12): charges agree far inside the 1e-5 bar
+    np.testing.assert_allclose(res["acc12"]["adc_list"], a["adc_list"], rtol=2e-9, atol=0)
+    assert np.array_equal(res["acc12"]["adc_digit"], a["adc_digit"]) and np.array_equal(res["acc12"]["adc_ticks_list"], a["adc_ticks_list"])
     for name in ("cap12", "keepall"):
         b = res[name]
         assert np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"])
