@@ -111,6 +111,9 @@ int ldsim_device_count(void);
 /* consts.load_properties + importlib.reload (cli/simulate_pixels.py:431,458-464) */
 int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx** out);
 int ldsim_ctx_destroy(ldsim_ctx* ctx);
+/* page-locked host memory for the download / upload buffers of a caller that wants PCIe-rate copies (hipHostMalloc) */
+int ldsim_host_alloc(void** p, size_t bytes);
+int ldsim_host_free(void* p);
 int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts);
 /* cp.load(response_file) (cli/simulate_pixels.py:436): f64 table [ni][nj][nk], host pointer */
 int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_t ni, int32_t nj, int32_t nk);

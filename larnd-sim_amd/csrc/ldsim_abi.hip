@@ -60,6 +60,7 @@ void ldsim_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ldsim_last_error(void) { return g_err; }
 extern "C" int ldsim_abi_version(void) { return LDSIM_ABI_VERSION; }
+
 extern "C" int ldsim_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -105,6 +106,17 @@ struct Tmp {
       return LDSIM_EINVAL;         \
     }                              \
   } while (0)
+
+extern "C" int ldsim_host_alloc(void** p, size_t bytes) {
+  NEED(p, "null argument");
+  *p = nullptr;
+  HIPCHK(hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+extern "C" int ldsim_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
+  return 0;
+}
 
 // Gauss-Legendre nodes and weights of every rule N = 1..nmax (Newton on P_N from the Chebyshev guess, long double):
 // rule N occupies entries [N(N-1)/2, N(N-1)/2 + N), nodes ascending.  Used by qweights_kernel (kernels_qweights.hip).

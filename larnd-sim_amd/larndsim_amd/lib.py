@@ -26,6 +26,7 @@ _ctx_device = None
 
 EXPORTS = [
     "ldsim_last_error", "ldsim_abi_version", "ldsim_device_count", "ldsim_ctx_create", "ldsim_ctx_destroy",
+    "ldsim_host_alloc", "ldsim_host_free",
     "ldsim_set_consts", "ldsim_set_response", "ldsim_set_light_channels", "ldsim_set_light_lut", "ldsim_set_option",
     "ldsim_set_pixel_thresholds", "ldsim_set_pixel_gains", "ldsim_clear_pixel_tables",
     "ldsim_synchronize", "ldsim_quench", "ldsim_drift", "ldsim_max_pixels", "ldsim_get_pixels",
@@ -84,6 +85,19 @@ def context_light_shape():
 def check(rc):
     if rc != 0:
         raise LdsimError(f"ldsim error {rc}: {load().ldsim_last_error().decode()}")
+
+
+def pinned_array(shape, dtype):
+    """numpy array over page-locked host memory (ldsim_host_alloc / hipHostMalloc); freed with the array."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    check(load().ldsim_host_alloc(C.byref(p), C.c_size_t(max(n, 8))))
+    buf = (C.c_char * max(n, 8)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, load().ldsim_host_free, C.c_void_p(p.value))
+    return arr
 
 
 def ptr(a):

@@ -426,6 +426,10 @@ def test_chain_properties_full_event():
     ch.quench_drift()
     st = ch.run(0, len(seg))
     both = ch.download()
+    # the page-locked download buffers (ldsim_host_alloc) hold the same arrays; they are the chain's, reused by the next call
+    pin = ch.download(pinned=True)
+    for k in both:
+        assert np.array_equal(pin[k], both[k]), k
     q = ch.download_segments(seg.copy())
     # (1) sortedness: rows ordered by (batch, pixel id), pixel ids unique inside a batch
     key = both["batch"].astype(np.int64) * (1 << 32) + both["unique_pix"]
