@@ -7,6 +7,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "ldsim_dev.h"
+#include "wave_ops.h"
 
 // key = batch(24) | pixel(32) | ringcode(4, 15 = invalid) ; invalid pairs get ~0 and sort last
 __global__ void make_keys_kernel(const int32_t* __restrict__ neigh, const int32_t* __restrict__ nrad,
@@ -65,17 +66,40 @@ __global__ void batch_first_kernel(const int32_t* __restrict__ batch, int64_t se
 __global__ void tmax_batch_kernel(SegStore s, const LdsimConsts* __restrict__ c, int64_t begin, int64_t n, int32_t batch0,
                                   double* __restrict__ starts, int32_t* __restrict__ tmax_b,
                                   unsigned long long* __restrict__ tran_b) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  int64_t i = begin + r;
-  double t_end = py_round((s.f[LDSIM_T_END][i] + 1) / c->time_sampling) * c->time_sampling;
-  double t_start = py_round((s.f[LDSIM_T_START][i] - c->time_padding) / c->time_sampling) * c->time_sampling;
-  starts[r] = t_start;
-  int32_t b = s.batch[i];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int32_t b = -1, len_i = 0;
+  double td = 0;
+  if (r < n) {
+    const int64_t i = begin + r;
+    double t_end = py_round((s.f[LDSIM_T_END][i] + 1) / c->time_sampling) * c->time_sampling;
+    double t_start = py_round((s.f[LDSIM_T_START][i] - c->time_padding) / c->time_sampling) * c->time_sampling;
+    starts[r] = t_start;
+    b = s.batch[i];
+    if (b >= 0) {
+      double len = ceil((t_end - t_start) / c->time_sampling);
+      if (len > 0 && len < 2.0e9) len_i = (int32_t)len;
+      td = s.f[LDSIM_TRAN_DIFF][i];
+      if (!(td > 0)) td = 0;
+    }
+  }
+  // segments are sorted by batch, so nearly every wave holds one batch: one atomic per wave instead of one per segment on
+  // the few per-batch cells (50 k contended atomics cost 0.7 ms per launch)
+  const unsigned long long act = __ballot(b >= 0);
+  if (act == 0) return;
+  const int first = __ffsll((long long)act) - 1;
+  const int bref = __builtin_amdgcn_readlane(b, first);
+  if (__ballot(b >= 0 && b != bref) == 0) {
+    const int m = wave_max_i32(len_i);
+    const double tm = wave_max_f64(td);
+    if (lane == first) {
+      if (m > 0) atomicMax(&tmax_b[bref - batch0], m);
+      if (tran_b && tm > 0) atomicMax(&tran_b[bref - batch0], (unsigned long long)__double_as_longlong(tm));
+    }
+    return;
+  }
   if (b < 0) return;
-  double len = ceil((t_end - t_start) / c->time_sampling);
-  if (len > 0 && len < 2.0e9) atomicMax(&tmax_b[b - batch0], (int32_t)len);
-  double td = s.f[LDSIM_TRAN_DIFF][i];
+  if (len_i > 0) atomicMax(&tmax_b[b - batch0], len_i);
   if (tran_b && td > 0) atomicMax(&tran_b[b - batch0], (unsigned long long)__double_as_longlong(td));
 }
 
