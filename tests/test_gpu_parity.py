@@ -1169,6 +1169,25 @@ def test_light_properties_baseline_sizes():
     assert checked == n_sim
 
 
+def test_rng_table_growth_follows_maybe_create_rng_states():
+    """rng.maybe_create_rng_states (cli/simulate_pixels.py:92-104): a table that is long enough is untouched; a shorter one
+    keeps its states (advanced or not) and gets a fresh create_xoroshiro128p_states(n - len, seed) chain appended; the
+    chain's own growth (more pixel rows than states) continues the last chain instead."""
+    H.load_cfg("module0")
+    st = lrng.create_xoroshiro128p_states(100, 3)
+    first = st.copy_to_host().copy()
+    assert np.array_equal(first.view(np.uint64), O.rng_create_states(100, 3).view(np.uint64))
+    assert lrng.maybe_create_rng_states(80, 5, st) is st and len(st) == 100
+    assert np.array_equal(st.copy_to_host().view(np.uint64), first.view(np.uint64))
+    lrng.maybe_create_rng_states(150, 9, st)
+    grown = st.copy_to_host()
+    assert len(st) == 150 and grown.shape[0] == 150
+    assert np.array_equal(grown[:100].view(np.uint64), first.view(np.uint64))
+    assert np.array_equal(grown[100:].view(np.uint64), O.rng_create_states(50, 9).view(np.uint64))
+    fresh = lrng.maybe_create_rng_states(7, 11, None)
+    assert np.array_equal(fresh.copy_to_host().view(np.uint64), O.rng_create_states(7, 11).view(np.uint64))
+
+
 def test_fee_noise_stream_vs_oracle():
     """FEE noise (fee.py:557,583-584,616-617,621,649) with the xoroshiro128p + Box-Muller generator Numba documents
     (csrc/rng.h; oracle/ldsim_oracle.c holds the same restatement -- the stream is third-party and unpinned).  On the
