@@ -88,20 +88,20 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift_kernel(SplitArgs S) 
         const unsigned long long wo = ((unsigned long long)itx.woff_hi << 32) | (unsigned long long)itx.woff_lo;
         touch = (lane < nblk * 8) ? S.wbuf[wo + lane] : 0.0;
       };
-      // one 8-shift block on the window lo ++ hi, weights w[0..8) read through the scalar cache (wave-uniform address);
-      // with `more`, dst (a dead chunk's registers) becomes the chunk after hi: shifted in from the next lane, lane 63's
-      // from the tail.  Three register sets take the roles lo / hi / dst in rotation, so no chunk is ever copied.
-      auto block = [&](double (&lo)[8], double (&hi)[8], double (&dst)[8], wconst_ptr w, const double* tnext, bool more) {
+      // one 8-shift block on the window lo ++ hi, weights w[0..8) read through the scalar cache (wave-uniform address)
+      auto fmas = [&](double (&lo)[8], double (&hi)[8], wconst_ptr w) {
 #pragma unroll
         for (int du = 0; du < 8; du++) {
           const double av = w[du];
 #pragma unroll
           for (int j = 0; j < TPL; j++) acc[j] = fma(av, (j + du < 8) ? lo[j + du] : hi[j + du - 8], acc[j]);
         }
-        if (more) {
+      };
+      // dst (a dead chunk's registers) becomes the chunk after hi: shifted in from the next lane, lane 63's from the tail.
+      // Three register sets take the roles lo / hi / dst in rotation, so no chunk is ever copied.
+      auto shift = [&](double (&dst)[8], double (&hi)[8], const double* tnext) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) dst[q] = wave_shl1(tnext[q], hi[q]);
-        }
+        for (int q = 0; q < 8; q++) dst[q] = wave_shl1(tnext[q], hi[q]);
       };
       Item d_cur{}, d_next{};
       // two register sets: the item being correlated and the one being fetched swap roles every item (no copies)
@@ -120,19 +120,32 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift_kernel(SplitArgs S) 
         double y[8], z[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) y[q] = wave_shl1(tl[q], a[q]);
-        int blk = 0;
-        if (A.debug_phases & 0x1000) blk = nblk;              // timing tools: everything but the correlation blocks
-        // chunk c of lane 63 = tl[8(c-1) ..]: block blk shifts in chunk blk + 2
-        for (; blk + 2 < nblk; blk += 3) {
-          block(a, y, z, w + 8 * blk, tl + 8 * (blk + 1), true);
-          block(y, z, a, w + 8 * (blk + 1), tl + 8 * (blk + 2), true);
-          block(z, a, y, w + 8 * (blk + 2), tl + 8 * (blk + 3), blk + 3 < nblk);
-        }
-        if (nblk - blk == 1) {
-          block(a, y, z, w + 8 * blk, tl, false);
-        } else if (nblk - blk == 2) {
-          block(a, y, z, w + 8 * blk, tl + 8 * (blk + 1), true);
-          block(y, z, a, w + 8 * (blk + 1), tl, false);
+        // The <= 8 blocks of an item as straight-line code with forward exits instead of a loop: a loop's back edge made the
+        // compiler copy every shifted chunk back into the registers the loop entered with (8 v_mov_b64 per block).
+        // chunk c of lane 63 = tl[8(c-1) ..]; before block b the sets hold chunks b and b+1.
+        if (!(A.debug_phases & 0x1000)) {                      // 0x1000 (timing tools): everything but the correlation blocks
+          fmas(a, y, w);
+          if (nblk > 1) {
+            shift(z, y, tl + 8);  fmas(y, z, w + 8);
+            if (nblk > 2) {
+              shift(a, z, tl + 16);  fmas(z, a, w + 16);
+              if (nblk > 3) {
+                shift(y, a, tl + 24);  fmas(a, y, w + 24);
+                if (nblk > 4) {
+                  shift(z, y, tl + 32);  fmas(y, z, w + 32);
+                  if (nblk > 5) {
+                    shift(a, z, tl + 40);  fmas(z, a, w + 40);
+                    if (nblk > 6) {
+                      shift(y, a, tl + 48);  fmas(a, y, w + 48);
+                      if (nblk > 7) {
+                        shift(z, y, tl + 56);  fmas(y, z, w + 56);
+                      }
+                    }
+                  }
+                }
+              }
+            }
+          }
         }
         n_blocks += nblk;
       };
