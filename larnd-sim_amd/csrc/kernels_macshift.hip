@@ -22,7 +22,7 @@ __device__ __forceinline__ double wave_shl1(double old, double src) {
 
 typedef const double __attribute__((address_space(4)))* wconst_ptr;   // constant address space: uniform reads go through s_load
 
-__global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 5) mac_shift_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be: item walk and weights stay scalar
