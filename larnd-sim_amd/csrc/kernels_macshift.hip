@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 5) mac_shift_kernel(SplitArgs S) 
 // read through the scalar cache straight from HBM (the list is up to 32 KB per pair at M = 2, too much LDS).
 typedef const Item __attribute__((address_space(4)))* iconst_ptr;
 
-__global__ void __launch_bounds__(CUR_THREADS, 3) mac_shift2_kernel(SplitArgs S) {
+__global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift2_kernel(SplitArgs S) {
   const CurArgs& A = S.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,24 +286,27 @@ __global__ void __launch_bounds__(CUR_THREADS, 3) mac_shift2_kernel(SplitArgs S)
         double c[8], d[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) c[q] = wave_shl1(tl[q], a[q]);          // chunk 2 = the next lane's chunk 0
-        int blk = 0;
-        // block blk shifts in chunk blk + 3 = tl[8(blk+1) ..] for lane 63
-        for (; blk + 3 < nblk; blk += 4) {
-          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
-          block(b, c, d, a, w + 8 * (blk + 1), tl + 8 * (blk + 2), true);
-          block(c, d, a, b, w + 8 * (blk + 2), tl + 8 * (blk + 3), true);
-          block(d, a, b, c, w + 8 * (blk + 3), tl + 8 * (blk + 4), blk + 4 < nblk);
-        }
-        const int rem = nblk - blk;
-        if (rem == 1) {
-          block(a, b, c, d, w + 8 * blk, tl, false);
-        } else if (rem == 2) {
-          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
-          block(b, c, d, a, w + 8 * (blk + 1), tl, false);
-        } else if (rem == 3) {
-          block(a, b, c, d, w + 8 * blk, tl + 8 * (blk + 1), true);
-          block(b, c, d, a, w + 8 * (blk + 1), tl + 8 * (blk + 2), true);
-          block(c, d, a, b, w + 8 * (blk + 2), tl, false);
+        // straight-line blocks with forward exits (see mac_shift_kernel); before block k the sets hold chunks k, k+1, k+2 and
+        // block k shifts in chunk k + 3 = tl[8(k+1) ..] for lane 63
+        block(a, b, c, d, w, tl + 8, nblk > 1);
+        if (nblk > 1) {
+          block(b, c, d, a, w + 8, tl + 16, nblk > 2);
+          if (nblk > 2) {
+            block(c, d, a, b, w + 16, tl + 24, nblk > 3);
+            if (nblk > 3) {
+              block(d, a, b, c, w + 24, tl + 32, nblk > 4);
+              if (nblk > 4) {
+                block(a, b, c, d, w + 32, tl + 40, nblk > 5);
+                if (nblk > 5) {
+                  block(b, c, d, a, w + 40, tl + 48, nblk > 6);
+                  if (nblk > 6) {
+                    block(c, d, a, b, w + 48, tl + 56, nblk > 7);
+                    if (nblk > 7) block(d, a, b, c, w + 56, tl, false);
+                  }
+                }
+              }
+            }
+          }
         }
         n_blocks += nblk;
       };
