@@ -20,6 +20,7 @@
 #define QNB 16            // quadrature nodes per batch (tables of one batch live in LDS)
 #define QTILES 512        // (cell, 8-shift block) tiles per column group: two per thread, accumulated in registers
 #define QCOLS 32          // response columns per group
+#define QN_LDS 64         // nodes of a rule kept in LDS (longer rules -- segments of > 37 Gaussian widths -- read the table)
 #define Q_CELLS 512       // response cells per group
 
 template <int M>
@@ -49,6 +50,16 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   auto write_empty = [&]() {
     if (tid < HDR_INTS) hdr[tid] = 0;
   };
+  // the pair's Gauss-Legendre nodes and weights (rule NQ of the table) into LDS: the table tasks read them per task, and
+  // from global memory every one of those reads was a full L2 round trip inside a latency-bound phase
+  __shared__ double s_gl[2][QN_LDS];
+  {
+    const int64_t off = (int64_t)NQ * (NQ - 1) / 2;
+    if (tid < NQ && tid < QN_LDS) {
+      s_gl[0][tid] = glx[off + tid];
+      s_gl[1][tid] = glw[off + tid];
+    }
+  }
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
 
@@ -251,8 +262,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   if (ncol == 0 || NJ <= 0 || NJ > NJ_MAX) { write_empty(); return; }
   if (A.debug_phases & 0x200) { write_empty(); return; }      // timing tools: stop after the sample maps
 
-  const double* __restrict__ gx_tab = glx + (int64_t)NQ * (NQ - 1) / 2;
-  const double* __restrict__ gw_tab = glw + (int64_t)NQ * (NQ - 1) / 2;
+  // this pair's rule: staged in LDS before the maps, or (more than QN_LDS nodes) read from the table
+  const double* gx_tab = NQ <= QN_LDS ? (const double*)s_gl[0] : glx + (int64_t)NQ * (NQ - 1) / 2;
+  const double* gw_tab = NQ <= QN_LDS ? (const double*)s_gl[1] : glw + (int64_t)NQ * (NQ - 1) / 2;
   const bool do_prune = A.prune_log > 0;
   // numba_f32: _b divides by sigma*sigma typed f32 while delta and a use the f64 square (detsim.py:116-118,141-148), so per
   // axis the exponent is -[(d - r u s)^2 + u^2 s^2 (1 - r^2)] / (2 sigma^2), r = sigma^2 / (sigma*sigma)_f32: still one
