@@ -6,6 +6,10 @@ coalesced read (same guide, HBM), so it is doubled.  Writes profiles/r02_traffic
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... (same command)
   python tools/pmc_traffic.py module0 gpurun_out/pmc_fetch gpurun_out/pmc_write
+(without --output-format csv rocprofv3 leaves a *_results.db instead; both are read)
+
+  python tools/pmc_traffic.py --kernel-stats gpurun_out/r02_stats/ks_results.db profiles/r02_kernel_stats_module0.csv
+turns the sqlite output of `rocprofv3 --kernel-trace --stats` into the kernel_stats.csv table (same columns, ns).
 """
 import csv
 import glob
@@ -27,10 +31,38 @@ def per_kernel(directory, counter):
                 name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0]
                 tot[name] = tot.get(name, 0.0) + float(row["Counter_Value"])
                 cnt[name] = cnt.get(name, 0) + 1
+    # rocprofv3 without --output-format csv writes one sqlite file (rocpd): the same rows sit in its counters_collection view
+    for f in glob.glob(os.path.join(directory, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        with sqlite3.connect(f) as db:
+            for kname, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+                name = re.sub(r"^void ", "", kname).split("(")[0]
+                tot[name] = tot.get(name, 0.0) + float(value)
+                cnt[name] = cnt.get(name, 0) + 1
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
+def kernel_stats(db_path, out_csv):
+    import sqlite3
+    import statistics
+    per = {}
+    with sqlite3.connect(db_path) as db:
+        for name, dur in db.execute("select name, duration from kernels"):
+            per.setdefault(name, []).append(float(dur))
+    total = sum(sum(v) for v in per.values())
+    with open(out_csv, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), int(sum(v)), round(sum(v) / len(v), 6), round(100.0 * sum(v) / total, 2), int(min(v)), int(max(v)),
+                        round(statistics.stdev(v), 6) if len(v) > 1 else 0.0])
+    for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:6]:
+        print(f"{name.split('(')[0][:50]:50s} {len(v):4d} launches  {sum(v) / len(v) / 1e6:9.3f} ms avg")
+
+
 def main():
+    if sys.argv[1] == "--kernel-stats":
+        return kernel_stats(sys.argv[2], sys.argv[3])
     config, d_fetch, d_write = sys.argv[1:4]
     fetch, write = per_kernel(d_fetch, "FETCH_SIZE"), per_kernel(d_write, "WRITE_SIZE")
     path = os.path.join(REPO, "profiles", "r02_traffic.json")
