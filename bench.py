@@ -309,17 +309,20 @@ def main():
         if light_on and acc["inc_n"]:
             n_op = int(consts.light.N_OP_CHANNEL)
             inc_ms = acc["inc_ms"] / acc["inc_n"]
-            b_alg = len(seg) * (152.0 + 12.0 * n_op)            # S*152 read + S*n_op*12 written
-            written = len(seg) * n_op * (8.0 if consts.light.LIGHT_TRIG_MODE == 0 else 4.0) + len(seg) * 12.0
+            # bytes the stage has to move in this library's layout: 44 B of SoA columns read per segment, n_photons_det
+            # (+ t0_det in trigger mode 0) f4 per (segment, channel) and the voxel written.  SURVEY 8d counts the reference's
+            # record (152 B) and {segment_id, n_photons_det, t0_det} per channel; that figure is kept beside it.
+            per_ch = 8.0 if consts.light.LIGHT_TRIG_MODE == 0 else 4.0
+            b_alg = len(seg) * (44.0 + 12.0 + per_ch * n_op)
+            b_survey = len(seg) * (152.0 + 12.0 * n_op)
             out["roofline_light_incidence"] = {
-                "bound": "hbm", "kernel": "light_incidence_kernel", "achieved": b_alg / (inc_ms * 1e-3) / 1e9,
+                "bound": "hbm", "kernel": "light_incidence4_kernel", "achieved": b_alg / (inc_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "launch_ms_avg": inc_ms, "algorithmic_bytes_per_launch": b_alg,
-                "bytes_written_per_launch": written, "written_GBs": written / (inc_ms * 1e-3) / 1e9,
+                "survey_8d_bytes_per_launch": b_survey,
                 "traffic": None, "traffic_source": "no PMC pass",
-                "note": "algorithmic bytes per SURVEY 8d (reference record + {segment_id, n_photons_det, t0_det} per channel); "
-                        "the kernel itself reads 44 B of SoA columns per segment and writes n_photons_det (+ t0_det in "
-                        "trigger mode 0) and the voxel",
+                "note": "streaming write of the dense [segment][channel] f4 array(s); torch.zero_() of the same size runs at "
+                        "5.0-6.9 TB/s on this GPU (tools/fill_bw.py)",
                 "photon_sum_ms_avg": acc["sum_ms"] / max(acc["sum_n"], 1), "photon_sums": acc["sum_n"] // max(a.steps, 1)}
         out.update(extras)
         if world > 1:

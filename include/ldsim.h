@@ -136,7 +136,8 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
  * "quad_accuracy_log10" (qweights_kernel: node count for a quadrature error of 1e-10 (default) or 1e-12 of the peak weight),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows
- * staged in LDS; bit-identical results),
+ * staged in LDS; bit-identical results), "light_incidence_scalar" (1 = calculate_light_incidence with one channel per lane
+ * instead of four (the form used when n_out or the LUT's detector count is not a multiple of 4); identical bits; default 0),
  * "numba_f32" (1 = the sub-expressions Numba types float32 for f4 record fields are evaluated in float, detsim.py:74-79,
  * 116-118,141,387; 0 = all-f64, what the reference computes for f8 records and what the goldens pin; default 0),
  * "mc_current" (1 = the fused chain takes its induced currents from tracks_current_mc like the reference driver does;

@@ -91,6 +91,106 @@ __global__ void __launch_bounds__(256) light_incidence_kernel(SegStore s, const 
   }
 }
 
+// The same stage with four channels per lane (n_out and the LUT's detector count multiples of 4): the output is a dense
+// [segment][channel] f4 array of which only the segment's own TPC's channels are non-zero, so the kernel is a streaming
+// write and should run at HBM write speed.  One float4 store per lane and (segment, channel quad); FIXED (n_out ==
+// n_op_channel: every segment reads the same slice of ch2tpc) keeps a lane's ch2tpc quads in registers across the tile's 32
+// segments; efficiency and visibility are only read for quads that hold a channel of the segment's TPC.  A channel of
+// another TPC gets (float)(eff * (vis * 0) * n_photons) in the reference = (float)(0.0 * n_photons) for a finite eff >= 0
+// and vis >= 0 (the launcher checks the efficiencies and otherwise takes the one-channel kernel): identical bits.
+#define LI_QPT 4       // channel quads per lane and pass: 256 lanes x 4 quads x 4 = 4096 channels per pass
+template <bool FIXED>
+__global__ void __launch_bounds__(256) light_incidence4_kernel(SegStore s, const LdsimConsts* __restrict__ c, int64_t seg0,
+                                                               int64_t n, const float* __restrict__ vis,
+                                                               const float* __restrict__ t0lut, int nx, int ny, int nz,
+                                                               int ndet, const double* __restrict__ eff,
+                                                               const int32_t* __restrict__ ch2tpc, int n_out,
+                                                               float* __restrict__ nph, float* __restrict__ t0det,
+                                                               int32_t* __restrict__ voxel, int fill) {
+  __shared__ int64_t s_vb[LI_SEGS];
+  __shared__ int s_tpc[LI_SEGS];
+  __shared__ double s_np[LI_SEGS], s_t0[LI_SEGS];
+  const int64_t r0 = (int64_t)blockIdx.x * LI_SEGS;
+  const int nt = (int)min((int64_t)LI_SEGS, n - r0);
+  if (nt <= 0) return;
+  if (threadIdx.x < nt) {
+    const int64_t r = r0 + threadIdx.x, it = seg0 + r;
+    int itpc = s.pixel_plane[it];
+    if (itpc == c->default_plane_index || itpc < 0 || itpc >= c->n_tpc) {
+      itpc = -1;
+      if (fill) { voxel[r * 3 + 0] = 0; voxel[r * 3 + 1] = 0; voxel[r * 3 + 2] = 0; }
+    } else {
+      int i, j, k;
+      get_voxel(c, s.f[LDSIM_X][it], s.f[LDSIM_Y][it], s.f[LDSIM_Z][it], itpc, nx, ny, nz, i, j, k);
+      voxel[r * 3 + 0] = i;
+      voxel[r * 3 + 1] = j;
+      voxel[r * 3 + 2] = k;
+      s_vb[threadIdx.x] = (((int64_t)i * ny + j) * nz + k) * ndet;
+      s_np[threadIdx.x] = s.f[LDSIM_N_PHOTONS][it];
+      s_t0[threadIdx.x] = s.f[LDSIM_T0][it];
+    }
+    s_tpc[threadIdx.x] = itpc;
+  }
+  __syncthreads();
+  const bool trig0 = c->light_trig_mode == 0;
+  const double ns = 1.0, mus = 1e-6 * 1e9;
+  const int nquad = n_out >> 2;
+  for (int q0 = 0; q0 < nquad; q0 += 256 * LI_QPT) {
+    int4 ct0 = make_int4(-1, -1, -1, -1), ct1 = ct0, ct2 = ct0, ct3 = ct0;
+    const int qa = q0 + (int)threadIdx.x, qb = qa + 256, qc = qa + 512, qd = qa + 768;
+    if (FIXED) {
+      if (qa < nquad) ct0 = *(const int4*)(ch2tpc + 4 * qa);
+      if (qb < nquad) ct1 = *(const int4*)(ch2tpc + 4 * qb);
+      if (qc < nquad) ct2 = *(const int4*)(ch2tpc + 4 * qc);
+      if (qd < nquad) ct3 = *(const int4*)(ch2tpc + 4 * qd);
+    }
+    for (int sl = 0; sl < nt; sl++) {
+      const int itpc = s_tpc[sl];
+      if (itpc < 0 && !fill) continue;
+      float* rowp = nph + (r0 + sl) * (int64_t)n_out;
+      float* rowt = t0det + (r0 + sl) * (int64_t)n_out;
+      const int64_t vb0 = itpc >= 0 ? s_vb[sl] : 0;
+      const double npho = itpc >= 0 ? s_np[sl] : 0.0, t0s = itpc >= 0 ? s_t0[sl] : 0.0;
+      const int coff = FIXED ? 0 : n_out * (max(itpc, 0) / 2);
+      const float zv = itpc >= 0 ? (float)(0.0 * npho) : 0.f;
+      auto quad = [&](int q, int4 cq) {
+        if (q >= nquad) return;
+        float4 o4 = make_float4(zv, zv, zv, zv);
+        if (itpc >= 0) {
+          const int op = 4 * q + coff;
+          if (!FIXED) cq = *(const int4*)(ch2tpc + op);
+          const bool m0 = cq.x == itpc, m1 = cq.y == itpc, m2 = cq.z == itpc, m3 = cq.w == itpc;
+          const int64_t vb = vb0 + (4 * q) % ndet;      // ndet % 4 == 0: the quad's LUT entries are consecutive, 16-byte aligned
+          if (m0 | m1 | m2 | m3) {
+            const float4 v4 = *(const float4*)(vis + vb);
+            const double2 e0 = *(const double2*)(eff + op), e1 = *(const double2*)(eff + op + 2);
+            o4.x = (float)(e0.x * ((double)v4.x * (m0 ? 1 : 0)) * npho);
+            o4.y = (float)(e0.y * ((double)v4.y * (m1 ? 1 : 0)) * npho);
+            o4.z = (float)(e1.x * ((double)v4.z * (m2 ? 1 : 0)) * npho);
+            o4.w = (float)(e1.y * ((double)v4.w * (m3 ? 1 : 0)) * npho);
+          }
+          if (trig0) {
+            const float4 l4 = *(const float4*)(t0lut + vb);
+            float4 t4;
+            t4.x = (float)(((double)l4.x * ns + t0s * mus) / mus);
+            t4.y = (float)(((double)l4.y * ns + t0s * mus) / mus);
+            t4.z = (float)(((double)l4.z * ns + t0s * mus) / mus);
+            t4.w = (float)(((double)l4.w * ns + t0s * mus) / mus);
+            *(float4*)(rowt + 4 * q) = t4;
+          }
+        } else if (trig0) {
+          *(float4*)(rowt + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *(float4*)(rowp + 4 * q) = o4;
+      };
+      quad(qa, ct0);
+      quad(qb, ct1);
+      quad(qc, ct2);
+      quad(qd, ct3);
+    }
+  }
+}
+
 // min / max of t0_det over the entries with n_photons_det > 0 (light_sim.get_nticks, light_sim.py:34-39), as ordered ints
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __global__ void __launch_bounds__(256) light_t0_range_kernel(const float* __restrict__ nph, const float* __restrict__ t0det,
@@ -296,6 +396,19 @@ static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 int light_launch_incidence(ldsim_ctx* ctx, int64_t seg0, int64_t n, int n_out, float* nph, float* t0det, int32_t* voxel,
                            int fill) {
   if (n == 0 || n_out == 0) return 0;
+  if (n_out % 4 == 0 && ctx->lut_ndet % 4 == 0 && ctx->light_eff_plain && !ctx->light_incidence_scalar) {
+    const dim3 grid((unsigned)((n + LI_SEGS - 1) / LI_SEGS));
+    if (n_out < ctx->h_consts.n_op_channel)
+      hipLaunchKernelGGL(light_incidence4_kernel<false>, grid, dim3(256), 0, ctx->stream, ctx->seg, ctx->d_consts, seg0, n,
+                         ctx->d_lut_vis, ctx->d_lut_t0, ctx->lut_nx, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->d_eff,
+                         ctx->d_ch2tpc, n_out, nph, t0det, voxel, fill);
+    else
+      hipLaunchKernelGGL(light_incidence4_kernel<true>, grid, dim3(256), 0, ctx->stream, ctx->seg, ctx->d_consts, seg0, n,
+                         ctx->d_lut_vis, ctx->d_lut_t0, ctx->lut_nx, ctx->lut_ny, ctx->lut_nz, ctx->lut_ndet, ctx->d_eff,
+                         ctx->d_ch2tpc, n_out, nph, t0det, voxel, fill);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(light_incidence_kernel, dim3((unsigned)((n + LI_SEGS - 1) / LI_SEGS)), dim3(256), 0, ctx->stream,
                      ctx->seg, ctx->d_consts, seg0, n, ctx->d_lut_vis, ctx->d_lut_t0, ctx->lut_nx, ctx->lut_ny,
                      ctx->lut_nz, ctx->lut_ndet, ctx->d_eff, ctx->d_ch2tpc, n_out, nph, t0det, voxel, fill);

@@ -249,6 +249,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     ctx->weights_mode = (int)value;
     ctx->wbuf_learned = 0;
   }
+  else if (!strcmp(name, "light_incidence_scalar")) ctx->light_incidence_scalar = value != 0;
   else if (!strcmp(name, "mac_mode")) {
     if (!(value == 0 || value == 1)) { ldsim_set_error("mac_mode must be 0 or 1"); return LDSIM_EINVAL; }
     ctx->mac_mode = (int)value;
@@ -354,6 +355,9 @@ extern "C" int ldsim_set_light_channels(ldsim_ctx* ctx, const double* eff, const
   HIPCHK(hipMalloc((void**)&ctx->d_eff, n * sizeof(double)));
   HIPCHK(hipMalloc((void**)&ctx->d_ch2tpc, n * sizeof(int32_t)));
   HIPCHK(hipMemcpy(ctx->d_eff, eff, n * sizeof(double), hipMemcpyHostToDevice));
+  ctx->light_eff_plain = 1;             // finite, non-negative efficiencies: what light_incidence4_kernel's zero fill assumes
+  for (int32_t i = 0; i < n; i++)
+    if (!(eff[i] >= 0.0 && eff[i] <= 1.7e308)) ctx->light_eff_plain = 0;
   HIPCHK(hipMemcpy(ctx->d_ch2tpc, ch2tpc, n * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
 }

@@ -103,6 +103,8 @@ struct ldsim_ctx {
   DevBuf resp_pad;                           // zero-padded copy of the response rows for mac_shift_kernel
   int32_t resp_pad_lo = 0, resp_pad_hi = -2; // staged range it was built for (-2: not built)
   double quad_n0 = 4.8, quad_slope = 1.6;    // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-10 of the peak weight
+  int light_eff_plain = 0;                   // every OP_CHANNEL_EFFICIENCY finite and >= 0
+  int light_incidence_scalar = 0;            // 1 = the one-channel-per-lane light_incidence_kernel (A/B checks)
   int mac_mode = 1;                          // M = 1 correlation: 1 = mac_shift_kernel (DPP window), 0 = mac_kernel<1> (LDS rows)
   float *d_lut_vis = nullptr, *d_lut_t0 = nullptr, *d_lut_t0avg = nullptr, *d_lut_td = nullptr;
   int32_t lut_nx = 0, lut_ny = 0, lut_nz = 0, lut_ndet = 0, lut_nprof = 0;

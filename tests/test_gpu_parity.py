@@ -138,11 +138,13 @@ def test_pixels_time_intervals_golden(cfg):
     assert tmax[0] == int(g["max_length"])
 
 
-@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("cfg,tag", [(c, "") for c in CFGS] + [("module0", "corners_"), ("ndlar", "corners_")])
 @pytest.mark.parametrize("prune", [30.0, 0.0])
-def test_tracks_current_sampled_golden(cfg, prune):
+def test_tracks_current_sampled_golden(cfg, tag, prune):
+    """The HIP tracks_current against the reference's own output at sampled ticks; `corners_` = degenerate geometries
+    (face-hugging, micrometre-short, along / perpendicular to the drift axis, heavily ionising)."""
     H.load_cfg(cfg)
-    g = H.gold(f"sampled_{cfg}.npz")
+    g = H.gold(f"sampled_{tag}{cfg}.npz")
     r = H.quench_drift(O, g["segments_in"])
     neigh = np.ascontiguousarray(g["neigh"])
     T = int(g["max_length"])
@@ -804,6 +806,46 @@ def test_light_properties_baseline_event():
     # a channel of another TPC sees nothing from this TPC's segments, and nothing arrives before the first deposit
     seen = inc['n_photons_det'][:, opc].sum(axis=0) > 0
     assert np.array_equal(one.sum(axis=1) > 0, seen)
+
+
+@pytest.mark.parametrize("cfg", ["module0", "ndlar"])
+def test_light_incidence_four_channel_kernel_is_bitwise_the_scalar_one(cfg):
+    """light_incidence4_kernel (four channels per lane, float4 stores, channel tables in registers) against the
+    one-channel-per-lane kernel and the oracle: n_photons_det, t0_det (threshold-trigger configs) and voxels identical,
+    on the resident path and through the stage call; rows of segments outside the TPCs read zero."""
+    seg, bid = _prepared_set(cfg, 3000, 7)
+    n_op = synth.set_synthetic_light(48)
+    lut = synth.make_lut((14, 26, 8), 48, 100, synth.SEED_BASE + 7)
+    r = H.quench_drift(_HipQD, seg)
+    r["pixel_plane"][::97] = consts.detector.DEFAULT_PLANE_INDEX          # some segments outside every TPC
+    n = len(r)
+    lib.context()
+    got = {}
+    try:
+        for scalar in (1, 0):
+            lib.set_option("light_incidence_scalar", scalar)
+            inc = np.zeros((n, n_op), dtype=[('segment_id', 'u4'), ('n_photons_det', 'f4'), ('t0_det', 'f4')])
+            vox = np.full((n, 3), -1, dtype='i4')
+            lightLUT.calculate_light_incidence[1, 256](r, lut, inc, vox)
+            ch = ChargeChain()
+            ch.upload(r, np.zeros(n, dtype=np.int32))
+            ch.light_incidence(lut)
+            rinc, rvox = ch.download_light_incidence()
+            got[scalar] = (inc, vox, rinc, rvox)
+    finally:
+        lib.set_option("light_incidence_scalar", 0)
+    for a, b in zip(got[1], got[0]):
+        assert a.tobytes() == b.tobytes()
+    inc, vox, rinc, rvox = got[0]
+    out = r["pixel_plane"] == consts.detector.DEFAULT_PLANE_INDEX
+    assert (inc['n_photons_det'][out] == 0).all() and (rinc['n_photons_det'][out] == 0).all()
+    assert np.array_equal(inc['n_photons_det'][~out], rinc['n_photons_det'][~out])
+    onph, ot0, ovox = O.light_incidence(r, lut)
+    assert np.array_equal(vox[~out], ovox[~out])
+    assert np.array_equal(inc['n_photons_det'][~out], onph[~out])
+    if consts.light.LIGHT_TRIG_MODE == 0:
+        assert np.array_equal(inc['t0_det'][~out], ot0[~out])
+    assert (inc['n_photons_det'][~out] > 0).sum() > 1000
 
 
 @pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
