@@ -122,7 +122,9 @@ int ldsim_set_light_channels(ldsim_ctx* ctx, const double* efficiency, const int
 /* np.load(light_lut)['arr'] as SoA planes: vis,t0,t0_avg [nx*ny*nz*ndet] f32; time_dist [..*nprof] f32 */
 int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const float* t0_avg,
                         const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet, int32_t nprof);
-/* tuning / validation knobs: "prune_log" (weights below exp(-v) of the local peak are skipped, 0 = keep all),
+/* tuning / validation knobs: "prune_log" (weights below exp(-v) of the local peak are skipped, 0 = keep all;
+ * default 23 = 1e-10 of the peak like the quadrature rule: ADC charges move by < 1e-8 relative against keeping everything,
+ * tools/prune_sweep.py; 30 was the default before and costs 16-19 % more correlation work),
  * "tail_log" (split path: charge samples bounded by exp(-v) of the segment's peak density are evaluated in f32,
  * relative error ~3e-7 of a term that small; 0 = every sample in f64),
  * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell),

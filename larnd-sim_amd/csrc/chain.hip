@@ -318,6 +318,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   F.fractions = want_fractions ? (double*)ctx->scratch[SB_FRAC].p : nullptr;
   F.counters = counters;
   F.hit_count = d_hitcnt;
+  F.debug = ctx->debug_phases;
   // FEE noise (fee.py:557,583-584,616-617,621,649): row u of this launch draws from state u of the numba-style table
   const bool noisy = h.reset_noise_charge != 0 || h.uncorrelated_noise_charge != 0 || h.discriminator_noise != 0;
   if (noisy) {

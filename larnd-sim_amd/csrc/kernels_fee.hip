@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   // ---- summed waveform: each thread owns ticks tid, tid+256, ...  (detsim.py:516-520) -----------------------------
   for (int t = tid; t < NT; t += FEE_THREADS) {
     double acc = 0;
-    for (int k = 0; k < n_slots; k++) {
+    for (int k = 0; k < n_slots && !(F.debug & 0x10000); k++) {
       int it = t - s_start[k];
       if (it >= 0 && it < F.T) acc += (double)F.waves[s_row[k] * (int64_t)F.T + it];
     }
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   if (wv == 0) {
     const double thr = F.thr_table ? F.thr_table[F.upix[u]] : F.threshold;
     int nd = 0;
-    int nh = adc_scan(c, S, NT, 1 * c->time_interval[1], thr, F.time_padding, lane, hits, wtap, ntap,
+    int nh = (F.debug & 0x20000) ? 0 : adc_scan(c, S, NT, 1 * c->time_interval[1], thr, F.time_padding, lane, hits, wtap, ntap,
                       F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd);
     if (lane == 0) {
       s_nh = nh;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
     if (nh) atomicAdd(&F.counters[3], (unsigned long long)nh);
   }
   // ---- backtracking fractions (fee.py:572-573, 633-635): sum_jc sig_k[jc]*G[min(ntap, b-jc)] / true_q ------------
-  if (F.fractions) {
+  if (F.fractions && !(F.debug & 0x40000)) {
     double* fr = F.fractions + u * (int64_t)A * M;       // zero on entry (one memset of the whole array by the launcher)
     for (int k = wv; k < n_slots; k += FEE_THREADS / 64) {
       const float* wf = F.waves + s_row[k] * (int64_t)F.T;

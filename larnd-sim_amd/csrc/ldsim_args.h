@@ -60,6 +60,7 @@ struct FeeArgs {
   const float* noise_z;       // [U][noise_nd]
   int32_t noise_nd;
   int32_t* n_draws;           // [U] normals the scan consumed
+  int32_t debug;              // timing tools (debug_phases bits 0x10000 / 0x20000 / 0x40000: no waveform sum / scan / fractions)
 };
 
 int current_launch(ldsim_ctx* ctx, const CurArgs& args);

@@ -109,7 +109,7 @@ struct ldsim_ctx {
   float *d_lut_vis = nullptr, *d_lut_t0 = nullptr, *d_lut_t0avg = nullptr, *d_lut_td = nullptr;
   int32_t lut_nx = 0, lut_ny = 0, lut_nz = 0, lut_ndet = 0, lut_nprof = 0;
   // options
-  double prune_log = 30.0;
+  double prune_log = 23.0;                   // exp(-23) = 1e-10 of the pair's peak weight, the accuracy the node rule is fitted for
   double tail_log = 14.0;
   int trim_response = 1;
   int debug_phases = 15;

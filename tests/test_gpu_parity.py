@@ -139,7 +139,7 @@ def test_pixels_time_intervals_golden(cfg):
 
 
 @pytest.mark.parametrize("cfg,tag", [(c, "") for c in CFGS] + [("module0", "corners_"), ("ndlar", "corners_")])
-@pytest.mark.parametrize("prune", [30.0, 0.0])
+@pytest.mark.parametrize("prune", [23.0, 0.0])
 def test_tracks_current_sampled_golden(cfg, tag, prune):
     """The HIP tracks_current against the reference's own output at sampled ticks; `corners_` = degenerate geometries
     (face-hugging, micrometre-short, along / perpendicular to the drift axis, heavily ionising)."""
@@ -155,7 +155,7 @@ def test_tracks_current_sampled_golden(cfg, tag, prune):
         sig = np.zeros(neigh.shape + (T,), dtype=np.float32)
         detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
     finally:
-        lib.set_option("prune_log", 30.0)
+        lib.set_option("prune_log", 23.0)
     # tolerance is relative to the peak of the FULL waveform, not of the sampled ticks
     peak = np.abs(sig).max(axis=-1, keepdims=True)
     got, ref = sig[:, :, g["ticks"]].astype(np.float64), g["signals"].astype(np.float64)
@@ -1418,7 +1418,7 @@ def _two_event_set(cfg, seed, n=1200):
 
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 1), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
-                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 30.0), ("mac_mode", 1),
+                    ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 23.0), ("mac_mode", 1),
                     ("quad_accuracy_log10", 10)):
         lib.set_option(name, v)
 
@@ -1465,7 +1465,8 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
         b = res[name]
         assert np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"])
         assert np.array_equal(a["adc_list"] != 0, b["adc_list"] != 0)
-        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=1e-9)
+        # the two paths drop different sets of weights below exp(-prune_log) = 1e-10 of the peak: charges within 2e-8
+        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=2e-8)
         assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
         assert np.array_equal(a["adc_digit"], b["adc_digit"])
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
@@ -1508,8 +1509,8 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
     ch.quench_drift()
     res = {}
     try:
-        for name, cap, prune in (("default", 256, 30.0), ("again", 256, 30.0), ("cap12", 12, 30.0), ("keepall", 256, 0.0),
-                                 ("acc12", 256, 30.0)):
+        for name, cap, prune in (("default", 256, 23.0), ("again", 256, 23.0), ("cap12", 12, 23.0), ("keepall", 256, 0.0),
+                                 ("acc12", 256, 23.0), ("prune30", 256, 30.0)):
             lib.set_option("quad_max_nodes", cap)
             lib.set_option("prune_log", prune)
             lib.set_option("quad_accuracy_log10", 12 if name == "acc12" else 10)
@@ -1529,11 +1530,14 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
     # the shipped node rule (1e-10 of the peak weight) against the tighter one (1e-12): charges agree far inside the 1e-5 bar
     np.testing.assert_allclose(res["acc12"]["adc_list"], a["adc_list"], rtol=2e-9, atol=0)
     assert np.array_equal(res["acc12"]["adc_digit"], a["adc_digit"]) and np.array_equal(res["acc12"]["adc_ticks_list"], a["adc_ticks_list"])
-    for name in ("cap12", "keepall"):
+    # the shipped pruning (weights below exp(-23) = 1e-10 of the pair's peak dropped) against keeping every weight and against
+    # the earlier exp(-30): charges within 2e-8, three orders inside the bar and below the f32 resolution of the reference's
+    # own currents; discrete outputs identical
+    for name in ("cap12", "keepall", "prune30"):
         b = res[name]
         assert np.array_equal(a["unique_pix"], b["unique_pix"]) and np.array_equal(a["track_pixel_map"], b["track_pixel_map"])
         assert np.array_equal(a["adc_list"] != 0, b["adc_list"] != 0)
-        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=1e-9)
+        np.testing.assert_allclose(b["adc_list"], a["adc_list"], rtol=2e-8)
         assert np.array_equal(a["adc_ticks_list"], b["adc_ticks_list"])
         assert np.array_equal(a["adc_digit"], b["adc_digit"])
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
