@@ -846,6 +846,23 @@ def test_light_incidence_four_channel_kernel_is_bitwise_the_scalar_one(cfg):
     if consts.light.LIGHT_TRIG_MODE == 0:
         assert np.array_equal(inc['t0_det'][~out], ot0[~out])
     assert (inc['n_photons_det'][~out] > 0).sum() > 1000
+    # a per-module slice of the channels (n_out < N_OP_CHANNEL: the tables' slice then follows the segment's TPC,
+    # lightLUT.py:93-97) takes the kernel's other instantiation
+    n_mod = 2 * n_op // consts.detector.TPC_BORDERS.shape[0]
+    if n_mod < n_op:
+        sl = {}
+        try:
+            for scalar in (1, 0):
+                lib.set_option("light_incidence_scalar", scalar)
+                inc2 = np.zeros((n, n_mod), dtype=inc.dtype)
+                vox2 = np.full((n, 3), -1, dtype='i4')
+                lightLUT.calculate_light_incidence[1, 256](r, lut, inc2, vox2)
+                sl[scalar] = inc2
+        finally:
+            lib.set_option("light_incidence_scalar", 0)
+        assert sl[1].tobytes() == sl[0].tobytes()
+        onph2, _, _ = O.light_incidence(r, lut, n_out=n_mod)
+        assert np.array_equal(sl[0]['n_photons_det'][~out], onph2[~out]) and (onph2 > 0).sum() > 1000
 
 
 @pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
