@@ -246,6 +246,47 @@ def hand_segments(det, n, seed, plane_choices=None, long_frac=0.2, steep_frac=0.
     return seg
 
 
+def corner_segments(det, n, seed):
+    """Geometry corners for tracks_current (the shapes tools/fuzz_chain.py's last three flavours draw): segments hugging a TPC
+    face in x / y (neighbour pixels fall off the plane -> pID -1 slots), very short ones (0.5-50 um), nearly along the drift
+    axis (|cz| > 0.99999) and nearly perpendicular to it (|dz| ~ 1e-4 of the length), plus a heavily ionising long one."""
+    seg = hand_segments(det, n, seed)
+    rng = np.random.default_rng(seed + 1000)
+    B = np.sort(np.asarray(det.TPC_BORDERS), axis=-1)
+    for i in range(n):
+        flavour = i % 5
+        p = int(rng.integers(0, B.shape[0]))
+        lo, hi = B[p, :, 0] + 0.8, B[p, :, 1] - 0.8
+        c = rng.uniform(lo, hi)
+        L, cz, ph = rng.uniform(0.05, 0.6), rng.uniform(-0.9, 0.9), rng.uniform(0, 2 * np.pi)
+        if flavour == 0:                         # hugging a face: centre 0.02-0.2 cm inside the border in x or y
+            ax = int(rng.integers(0, 2))
+            side = int(rng.integers(0, 2))
+            c[ax] = B[p, ax, side] + (1 - 2 * side) * rng.uniform(0.02, 0.2)
+            L = rng.uniform(0.02, 0.3)
+        elif flavour == 1:                       # very short
+            L = 10 ** rng.uniform(-4.3, -2.3)
+        elif flavour == 2:                       # along the drift axis
+            cz = rng.choice([-1, 1]) * (1 - 10 ** rng.uniform(-7, -5))
+            L = rng.uniform(0.1, 1.2)
+        elif flavour == 3:                       # perpendicular to it
+            cz = rng.choice([-1, 1]) * 10 ** rng.uniform(-5, -3.5)
+            L = rng.uniform(0.1, 1.0)
+        else:                                    # heavily ionising, long
+            L = rng.uniform(1.2, 2.4)
+            seg["dEdx"][i] = rng.uniform(8, 30)
+        sxy = np.sqrt(max(0.0, 1 - cz * cz))
+        d = np.array([sxy * np.cos(ph), sxy * np.sin(ph), cz])
+        a, b = c - 0.5 * L * d, c + 0.5 * L * d
+        seg["x_start"][i], seg["y_start"][i], seg["z_start"][i] = a
+        seg["x_end"][i], seg["y_end"][i], seg["z_end"][i] = b
+        seg["dx"][i] = L
+    for ax in "xyz":
+        seg[ax] = 0.5 * (seg[ax + "_start"].astype(np.float64) + seg[ax + "_end"])
+    seg["dE"] = seg["dEdx"].astype(np.float64) * seg["dx"]
+    return seg
+
+
 def run_quench_drift(ref, r, mode):
     n = r.shape[0]
     ref.quenching.quench[max(1, -(-n // 256)), 256](r, mode)
@@ -479,10 +520,14 @@ class _PadVec:
 
 def gen_sampled(jobs):
     """tracks_current at sampled ticks for many diverse (segment, pixel) pairs."""
-    for cfg, seed, nseg, kind in (("module0", 41, 10, "golden"), ("2x2_no_modvar", 42, 6, "survey"),
-                                  ("ndlar", 43, 6, "golden")):
+    sets = (("module0", 41, 10, "golden", ""), ("2x2_no_modvar", 42, 6, "survey", ""), ("ndlar", 43, 6, "golden", ""),
+            ("module0", 51, 10, "golden", "corners_"), ("ndlar", 53, 5, "golden", "corners_"))
+    only = os.environ.get("GEN_SAMPLED_ONLY")            # e.g. "corners_" to make only the corner sets
+    for cfg, seed, nseg, kind, tag in sets:
+        if only is not None and tag != only:
+            continue
         ref = Ref(cfg)
-        seg = hand_segments(ref.detector, nseg, seed, long_frac=0.3, steep_frac=0.35)
+        seg = corner_segments(ref.detector, nseg, seed) if tag else hand_segments(ref.detector, nseg, seed, long_frac=0.3, steep_frac=0.35)
         if cfg == "2x2_no_modvar":                      # spill-style t0
             seg["t0"] = np.random.default_rng(seed).uniform(0, 10, nseg)
             seg["t0_start"] = seg["t0"]; seg["t0_end"] = seg["t0"]
@@ -501,9 +546,9 @@ def gen_sampled(jobs):
         signals = np.zeros((r.shape[0], pix["neigh"].shape[1], len(ticks)), dtype=np.float32)
         for itrk, s in res:
             signals[itrk] = s[:, ticks]
-        np.savez_compressed(os.path.join(GOLD, f"sampled_{cfg}.npz"), segments_in=seg, ticks=np.array(ticks),
+        np.savez_compressed(os.path.join(GOLD, f"sampled_{tag}{cfg}.npz"), segments_in=seg, ticks=np.array(ticks),
                             signals=signals, response_kind=kind, **pix)
-        print("sampled", cfg, "pairs", int((pix["neigh"] >= 0).sum()), "ticks", len(ticks),
+        print("sampled", tag + cfg, "pairs", int((pix["neigh"] >= 0).sum()), "ticks", len(ticks),
               "nonzero", int((signals != 0).sum()))
 
 

@@ -51,11 +51,16 @@ def test_pixels_time_intervals(cfg):
     assert (g["active"] == -1).any()        # the -1 gap quirk is exercised
 
 
-@pytest.mark.parametrize("cfg", CFGS)
-def test_tracks_current_sampled(cfg):
-    """Induced current at sampled ticks for diverse (segment, pixel) pairs incl. the pID == -1 quirk slots."""
+SAMPLED_SETS = [(c, "") for c in CFGS] + [("module0", "corners_"), ("ndlar", "corners_")]
+
+
+@pytest.mark.parametrize("cfg,tag", SAMPLED_SETS)
+def test_tracks_current_sampled(cfg, tag):
+    """Induced current at sampled ticks for diverse (segment, pixel) pairs incl. the pID == -1 quirk slots.  The `corners_`
+    sets hold the degenerate geometries: segments hugging a TPC face, 0.5-50 um long, along / perpendicular to the drift axis,
+    heavily ionising long ones (oracle/gen_golden.py:corner_segments)."""
     H.load_cfg(cfg)
-    g = H.gold(f"sampled_{cfg}.npz")
+    g = H.gold(f"sampled_{tag}{cfg}.npz")
     r = H.quench_drift(O, g["segments_in"])
     neigh = g["neigh"]
     T = int(g["max_length"])
