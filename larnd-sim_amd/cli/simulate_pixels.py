@@ -149,7 +149,7 @@ class _Output:
     def close(self):
         if self.h5py is None:
             out = {k: (np.concatenate(v) if len(v) > 1 else v[0]) for k, v in self.parts.items() if len(v)}
-            np.savez_compressed(self.filename, **out)
+            np.savez(self.filename, **out)       # uncompressed like the HDF5 datasets it stands in for (zlib cost a quarter of a run)
 
 
 def _as_list(v):

@@ -57,10 +57,12 @@ def _data_parity(chip_id, channel_id, timestamp, first_packet, dataword):
     return 1 - (bin(word).count("1") % 2)
 
 
-def build_packets(event_id_list, adc_list, adc_ticks_list, unique_pix, current_fractions, track_ids, traj_ids,
-                  event_start_times, light_trigger_times=None, light_trigger_event_id=None, light_trigger_modules=None,
-                  bad_channels=None, i_mod=-1):
-    """``fee.export_to_hdf5`` up to the file write: returns (packets, mc_packets_assn) structured arrays.
+def build_packets_loop(event_id_list, adc_list, adc_ticks_list, unique_pix, current_fractions, track_ids, traj_ids,
+                       event_start_times, light_trigger_times=None, light_trigger_event_id=None, light_trigger_modules=None,
+                       bad_channels=None, i_mod=-1):
+    """``fee.export_to_hdf5`` up to the file write, hit by hit like the reference's own loop: returns (packets,
+    mc_packets_assn) structured arrays.  Kept as the statement of the logic that the goldens pin and as the checker of
+    ``build_packets`` (the array form the driver calls; this one costs ~27 us per hit).
 
     Same arguments as the reference: ``event_id_list`` [U][A] event of every ADC slot, ``adc_list`` [U][A] digitised ADC,
     ``adc_ticks_list`` [U][A], ``unique_pix`` [U], ``current_fractions`` [U][A][M], ``track_ids`` / ``traj_ids`` [U][M]
@@ -218,6 +220,278 @@ def _empty_assn(n):
 def get_trig_io():
     """io_group of the PACMAN the light / beam trigger is forwarded to (fee.py:30-38)"""
     return 2 if consts.light.LIGHT_TRIG_MODE == 0 else 1
+
+
+_READOUT_LUT_CACHE = {}
+
+
+def _readout_luts():
+    """Array forms of the readout maps (pixel in tile -> chip / channel, (tile, chip) -> io, tile orientation, tile map),
+    rebuilt when consts.detector carries other objects."""
+    d = consts.detector
+    key = (id(d.PIXEL_CONNECTION_DICT), id(d.TILE_CHIP_TO_IO), id(d.TILE_ORIENTATIONS), id(d.TILE_MAP), len(d.PIXEL_CONNECTION_DICT))
+    hit = _READOUT_LUT_CACHE.get("luts")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    ntx, nty = int(d.N_PIXELS_PER_TILE[0]), int(d.N_PIXELS_PER_TILE[1])
+    chip_lut = np.full((ntx, nty), -1, dtype=np.int64)
+    chan_lut = np.full((ntx, nty), -1, dtype=np.int64)
+    for (px, py), (chip, channel) in d.PIXEL_CONNECTION_DICT.items():
+        if 0 <= px < ntx and 0 <= py < nty:
+            chip_lut[px, py], chan_lut[px, py] = chip, channel
+    tile_map = np.asarray(d.TILE_MAP, dtype=np.int64)                   # [anode][tile_x][tile_y]
+    n_tile = int(max(max(d.TILE_ORIENTATIONS), max(d.TILE_CHIP_TO_IO) if d.TILE_CHIP_TO_IO else 0, tile_map.max())) + 1
+    n_chip = int(max([max(v) for v in d.TILE_CHIP_TO_IO.values() if v] + [int(chip_lut.max())])) + 1
+    io_lut = np.full((n_tile, n_chip), -1, dtype=np.int64)
+    for tile, chips in d.TILE_CHIP_TO_IO.items():
+        for chip, io in chips.items():
+            io_lut[tile, chip] = io
+    flip_x = np.zeros(n_tile, dtype=bool)
+    flip_y = np.zeros(n_tile, dtype=bool)
+    has_orient = np.zeros(n_tile, dtype=bool)
+    for tile, axes in d.TILE_ORIENTATIONS.items():
+        flip_x[tile], flip_y[tile], has_orient[tile] = axes[2] < 0, axes[1] < 0, True
+    luts = dict(chip=chip_lut, chan=chan_lut, io=io_lut, flip_x=flip_x, flip_y=flip_y, has_orient=has_orient, tile_map=tile_map)
+    _READOUT_LUT_CACHE["luts"] = (key, luts)
+    return luts
+
+
+def _parity_array(chip_id, channel_id, timestamp, first_packet, dataword):
+    """_data_parity over arrays."""
+    word = ((chip_id.astype(np.uint64) & np.uint64(0xFF)) << np.uint64(2)) | ((channel_id.astype(np.uint64) & np.uint64(0x3F)) << np.uint64(10)) \
+        | ((timestamp.astype(np.uint64) & np.uint64(0x7FFFFFFF)) << np.uint64(16)) | (np.uint64(first_packet & 1) << np.uint64(47)) \
+        | ((dataword.astype(np.uint64) & np.uint64(0xFF)) << np.uint64(48))
+    bits = np.unpackbits(word.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)
+    return (1 - (bits % 2)).astype(np.uint8)
+
+
+def build_packets(event_id_list, adc_list, adc_ticks_list, unique_pix, current_fractions, track_ids, traj_ids,
+                  event_start_times, light_trigger_times=None, light_trigger_event_id=None, light_trigger_modules=None,
+                  bad_channels=None, i_mod=-1):
+    """``fee.export_to_hdf5`` up to the file write (larndsim/fee.py:84-356): returns (packets, mc_packets_assn).
+
+    Same arguments and the same bytes as ``build_packets_loop`` (tested on the goldens and on random inputs), computed with
+    array operations: the per-hit state of the reference's loop is (a) the clock rollover, a running count of
+    CLOCK_RESET_PERIODs subtracted from every later row (:164-183) -- found by re-evaluating all hits once per rollover --,
+    (b) "event changed" and "timestamp changed" flags (:187,267), comparisons with the previous hit, and (c) positions in
+    the output stream, a cumulative sum of the packets each hit emits.  Only the per-event packets (timestamp / sync /
+    light triggers) and rows whose trajectory sums have 8 or more terms (numpy's pairwise order) are handled in Python."""
+    d, light, sim, units = consts.detector, consts.light, consts.sim, consts.units
+    if not d.PIXEL_CONNECTION_DICT:
+        raise RuntimeError("the pixel layout (chip / channel map) is not loaded: packets need consts.load_properties(...) on "
+                           "the detector / pixel-layout YAML files or a snapshot that carries the readout map")
+    L = _readout_luts()
+    io_groups = np.unique(np.array(list(d.MODULE_TO_IO_GROUPS.values())))
+    io_groups = io_groups if i_mod < 0 else io_groups[(i_mod - 1) * 2: i_mod * 2]
+    M_pix = sim.MAX_TRACKS_PER_PIXEL
+    event_id_list = np.asarray(event_id_list)
+    adc_list = np.asarray(adc_list)
+    adc_ticks_list = np.asarray(adc_ticks_list)
+    unique_pix = np.asarray(unique_pix)
+    track_ids, traj_ids, current_fractions = np.asarray(track_ids), np.asarray(traj_ids), np.asarray(current_fractions)
+    n_trk, n_trj, n_frac = track_ids.shape[1], traj_ids.shape[1], current_fractions.shape[2]
+    if not (n_trk == n_trj == n_frac == M_pix):           # the reference's np.array(mc_*) needs equal widths as well
+        return build_packets_loop(event_id_list, adc_list, adc_ticks_list, unique_pix, current_fractions, track_ids, traj_ids,
+                                  event_start_times, light_trigger_times, light_trigger_event_id, light_trigger_modules,
+                                  bad_channels, i_mod)
+    empty = (np.zeros(0, dtype=packets_dtype), np.zeros(0, dtype=assn_dtype()))
+    if len(adc_list) == 0:
+        return empty
+    unique_events, unique_events_inv = np.unique(event_id_list[..., 0], return_inverse=True)
+    event_start_times = np.asarray(event_start_times)
+    base = (event_start_times[unique_events_inv] / d.CLOCK_CYCLE).astype(int)            # event_start_time_list
+    light_trigger_times = np.empty((0,)) if light_trigger_times is None else np.asarray(light_trigger_times)
+    light_trigger_event_id = np.empty((0,), dtype=int) if light_trigger_event_id is None else np.asarray(light_trigger_event_id)
+    light_trigger_modules = np.empty((0,)) if light_trigger_modules is None else np.asarray(light_trigger_modules)
+    ped = _digitize0()
+    CRP = int(d.CLOCK_RESET_PERIOD)
+    A = adc_list.shape[1]
+
+    # ---- rows that enter the hit loop, and their slots up to the first ADC <= pedestal --------------------------------------
+    nx, ny = int(d.N_PIXELS[0]), int(d.N_PIXELS[1])
+    pid = unique_pix.astype(np.int64)
+    pix_x, pix_y, plane_id = pid % nx, (pid // nx) % ny, pid // (nx * ny)
+    module_id = plane_id // 2 + 1
+    known_module = np.isin(module_id, np.array(list(d.MODULE_TO_IO_GROUPS.keys()), dtype=np.int64))
+    above = adc_list > ped
+    n_valid = np.where(above.all(axis=1), A, np.argmin(above, axis=1))
+    rows_in = np.flatnonzero(above[:, 0] & known_module)
+    counts = n_valid[rows_in]
+    n_hit = int(counts.sum())
+    if n_hit == 0:
+        return empty
+    hit_row = np.repeat(rows_in, counts)
+    hit_slot = np.arange(n_hit) - np.repeat(np.cumsum(counts) - counts, counts)
+
+    # ---- clock rollover: `off` reset periods have been subtracted from this and every later row when a hit is reached ---------
+    t_cc = adc_ticks_list[hit_row, hit_slot] / d.CLOCK_CYCLE
+    base_h = base[hit_row].astype(np.int64)
+    off = np.zeros(n_hit, dtype=np.int64)
+    while True:
+        event_t0 = base_h - off * CRP
+        time_tick = np.floor(t_cc + event_t0).astype(np.int64)
+        viol = (event_t0 > CRP - 1) | (time_tick > CRP - 1)
+        if not viol.any():
+            break
+        off[int(np.argmax(viol)):] += 1
+    # row 0 of event_start_time_list as the timestamp packets see it: rollovers hit it only while row 0 is processed
+    in_row0 = hit_row == 0
+    off_row0_final = int(off[in_row0][-1]) if in_row0.any() else 0
+    row0_value = int(base[0]) - np.where(in_row0, off, off_row0_final) * CRP
+    event_t0 = event_t0 % CRP
+    time_tick = time_tick % CRP
+    event = event_id_list[hit_row, hit_slot]
+
+    # ---- readout address of every row; hits of rows without one are dropped after the event bookkeeping -----------------------
+    ntx, nty = L["chip"].shape
+    tile_x, tile_y = pix_x[rows_in] // ntx, pix_y[rows_in] // nty
+    anode = plane_id[rows_in] % 2
+    tm = L["tile_map"]
+    in_map = (anode < tm.shape[0]) & (tile_x < tm.shape[1]) & (tile_y < tm.shape[2])
+    if not in_map.all():
+        raise IndexError("pixel outside the tile map")                   # the loop form raises on the same input
+    tile_id = tm[anode, tile_x, tile_y]
+    px, py = pix_x[rows_in] % ntx, pix_y[rows_in] % nty
+    px = np.where(L["flip_x"][tile_id], ntx - px - 1, px)
+    py = np.where(L["flip_y"][tile_id], nty - py - 1, py)
+    chip, channel = L["chip"][px, py], L["chan"][px, py]
+    ok = (chip >= 0) & L["has_orient"][tile_id]       # (a tile without an orientation raises KeyError inside the loop form's try)
+    io = np.where(ok & (chip < L["io"].shape[1]), L["io"][np.minimum(tile_id, L["io"].shape[0] - 1),
+                                                        np.clip(chip, 0, L["io"].shape[1] - 1)], -1)
+    ok &= io >= 0
+    io_group_idx, io_channel = io // 1000, io % 1000
+    mod_groups = {int(m): list(g) for m, g in d.MODULE_TO_IO_GROUPS.items()}
+    io_group = np.zeros(len(rows_in), dtype=np.int64)
+    for m, g in mod_groups.items():
+        sel = ok & (module_id[rows_in] == m)
+        if sel.any():
+            io_group[sel] = np.asarray(g, dtype=np.int64)[io_group_idx[sel] - 1]
+    if bad_channels:
+        bad = set()
+        for chip_key, chans in bad_channels.items():
+            for ch in chans:
+                bad.add("%s:%i" % (chip_key, int(ch)))
+        if bad:
+            for i in np.flatnonzero(ok):
+                if "%i-%i-%i:%i" % (io_group[i], io_channel[i], chip[i], channel[i]) in bad:
+                    ok[i] = False
+    row_pos = np.repeat(np.arange(len(rows_in)), counts)                 # index into the per-row arrays above
+    passes = ok[row_pos]
+
+    # ---- what every hit emits ------------------------------------------------------------------------------------------------
+    ev_change = np.zeros(n_hit, dtype=bool)
+    if light.LIGHT_TRIG_MODE != 1:
+        ev_change[0] = event[0] != -1
+        ev_change[1:] = event[1:] != event[:-1]
+    ev_rows = {}            # hit index -> list of (ptype, io_group, timestamp, trigger_type)
+    for h in np.flatnonzero(ev_change):
+        lst = []
+        for g in io_groups:
+            lst.append((TIMESTAMP, g, int(event_start_times[unique_events_inv[hit_row[h]]] * units.mus / units.s), 0))
+            lst.append((SYNC, g, int(time_tick[h]), ord('S')))
+        trig_mask = light_trigger_event_id == event[h]
+        if trig_mask.any():
+            for t_trig, module_trig in zip(light_trigger_times[trig_mask], light_trigger_modules[trig_mask]):
+                t_trig = int(np.floor(t_trig / d.CLOCK_CYCLE + event_t0[h])) % CRP
+                if light.LIGHT_TRIG_MODE == 0:
+                    for g in d.MODULE_TO_IO_GROUPS[int(module_trig)]:
+                        lst.append((TRIGGER, g, t_trig, 2))
+        ev_rows[int(h)] = lst
+    n_ev = np.zeros(n_hit, dtype=np.int64)
+    for h, lst in ev_rows.items():
+        n_ev[h] = len(lst)
+    tick_change = np.zeros(n_hit, dtype=bool)
+    ph = np.flatnonzero(passes)
+    if len(ph):
+        tt = time_tick[ph]
+        tick_change[ph[0]] = tt[0] != -1
+        tick_change[ph[1:]] = tt[1:] != tt[:-1]
+    n_out = n_ev + tick_change + passes
+    start = np.cumsum(n_out) - n_out
+    n_rows = int(n_out.sum())
+    if n_rows == 0:
+        return empty
+
+    packets = np.zeros(n_rows, dtype=packets_dtype)
+    packets['valid_parity'] = 1
+    is_data = np.zeros(n_rows, dtype=bool)
+    for h, lst in ev_rows.items():
+        for k, (ptype, g, ts, trig) in enumerate(lst):
+            r = packets[start[h] + k: start[h] + k + 1]
+            r['io_group'], r['packet_type'], r['timestamp'], r['trigger_type'] = g, ptype, ts, trig
+    th = np.flatnonzero(tick_change)
+    pos = start[th] + n_ev[th]
+    packets['io_group'][pos] = io_group[row_pos[th]]
+    packets['packet_type'][pos] = TIMESTAMP
+    packets['timestamp'][pos] = np.floor(row0_value[th] * d.CLOCK_CYCLE * units.mus / units.s).astype(np.int64)
+    pos = start[ph] + n_ev[ph] + tick_change[ph]
+    is_data[pos] = True
+    rp = row_pos[ph]
+    dataword = adc_list[hit_row[ph], hit_slot[ph]].astype(np.int64)
+    packets['io_group'][pos] = io_group[rp]
+    packets['io_channel'][pos] = io_channel[rp]
+    packets['chip_id'][pos] = chip[rp]
+    packets['packet_type'][pos] = DATA
+    packets['parity'][pos] = _parity_array(chip[rp], channel[rp], time_tick[ph], 1, dataword)
+    packets['channel_id'][pos] = channel[rp]
+    packets['timestamp'][pos] = time_tick[ph]
+    packets['dataword'][pos] = dataword
+    packets['first_packet'][pos] = 1
+    packets['receipt_timestamp'][pos] = time_tick[ph]
+
+    # ---- mc_packets_assn (fee.py:284-344) -----------------------------------------------------------------------------------
+    # Rows of the inserted packets hold the fill values whatever the sort does with them; the work is on the data rows only.
+    n_keep = sim.ASSOCIATION_COUNT_TO_STORE
+    ds = np.zeros(n_rows, dtype=assn_dtype())
+    ds['event_ids'] = -1
+    ds['segment_ids'] = -1
+    ds['file_traj_ids'] = -1
+    n_data = len(ph)
+    if n_data == 0:
+        return packets, ds
+    F = current_fractions[hit_row[ph], hit_slot[ph]].astype(np.float64, copy=False)
+    frac_order = np.flip(np.argsort(F, axis=1), axis=1)          # on the same rows the reference sorts: ties fall the same way
+    head = frac_order[:, :n_keep]
+    w = head.shape[1]
+    hr = hit_row[ph][:, None]
+    seg_head = track_ids[hr, head]
+    ass_fractions = np.take_along_axis(F, frac_order, axis=1)
+    ass_trajectory_ids = traj_ids[hr, frac_order]
+    out_seg = np.full((n_data, n_keep), -1, dtype=np.int64)
+    out_frac = np.zeros((n_data, n_keep))
+    out_seg[:, :w] = seg_head
+    out_frac[:, :w] = ass_fractions[:, :w]
+    # trajectories: per row the ids in ascending order with the sum of their fractions.  The reference sums every id's terms
+    # with np.sum in fraction order and stores f4; np.sum's association of a handful of f8 terms depends on numpy's SIMD
+    # build, so f8 agreement to the last bit is not defined -- sums here run left to right (reduceat) and are rounded to f4
+    # like the reference's (a differing f8 last bit moves the f4 value once in ~1e9 sums).
+    out_tid = np.full((n_data, n_keep), -1, dtype=np.int64)
+    out_tfr = np.zeros((n_data, n_keep), dtype=np.float32)
+    mask = ass_trajectory_ids > -1
+    r, _ = np.nonzero(mask)                                      # row-major: inside a row the fraction order is kept
+    if len(r):
+        ids = ass_trajectory_ids[mask].astype(np.int64)
+        fr = ass_fractions[mask]
+        idx = np.lexsort((ids, r))                               # stable: by row, then id, then fraction order
+        r2, ids2, fr2 = r[idx], ids[idx], fr[idx]
+        newg = np.ones(len(r2), dtype=bool)
+        newg[1:] = (r2[1:] != r2[:-1]) | (ids2[1:] != ids2[:-1])
+        starts = np.flatnonzero(newg)
+        sums = np.add.reduceat(fr2, starts)
+        g_row = r2[starts]
+        first_of_row = np.ones(len(starts), dtype=bool)
+        first_of_row[1:] = g_row[1:] != g_row[:-1]
+        g_idx = np.arange(len(starts))
+        local = g_idx - np.maximum.accumulate(np.where(first_of_row, g_idx, 0))
+        sel = local < n_keep
+        out_tid[g_row[sel], local[sel]] = ids2[starts][sel].astype(np.int32)      # the reference's id array is int32
+        out_tfr[g_row[sel], local[sel]] = sums[sel]
+    ds['segment_ids'][pos] = out_seg
+    ds['fraction'][pos] = out_frac
+    ds['file_traj_ids'][pos] = out_tid
+    ds['fraction_traj'][pos] = out_tfr
+    ds['event_ids'][pos, 0] = event[ph]
+    return packets, ds
 
 
 def build_sync_packets(sync_times, i_mod=-1):

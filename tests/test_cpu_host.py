@@ -228,6 +228,84 @@ def test_cli_input_checks_like_the_reference(tmp_path):
     assert np.array_equal(new["t0"], [1, 2, 3]) and (new["t"] == 0).all() and (new["x"] == 7).all() and (new["z"] == 5).all()
 
 
+def _random_packet_inputs(rng, n_pix, n_ev, spill):
+    """Per-pixel ADC arrays as the chain hands them to the packet writer, shaped to reach every branch of the hit loop: slots
+    that stop at the pedestal, several hits per pixel, pixels off the readout map, events past the 1 s clock reset, equal
+    tick stamps in a row, trajectories with up to 12 segments on one pixel (numpy's pairwise summation starts at 9 terms)."""
+    from larndsim_amd import packets
+    d, sim = consts.detector, consts.sim
+    A, M = sim.MAX_ADC_VALUES, sim.MAX_TRACKS_PER_PIXEL
+    ped = packets._digitize0()
+    n_tot = int(d.N_PIXELS[0]) * int(d.N_PIXELS[1]) * d.TPC_BORDERS.shape[0]
+    upix = np.sort(rng.choice(n_tot, n_pix, replace=False)).astype(np.int64)
+    ev_of_pix = np.sort(rng.integers(0, n_ev, n_pix))
+    adc = np.full((n_pix, A), ped, dtype=np.float64)
+    ticks = np.zeros((n_pix, A))
+    nh = rng.choice([0, 1, 1, 1, 2, 3, A], n_pix)
+    for u in range(n_pix):
+        adc[u, :nh[u]] = rng.integers(int(ped) + 1, 255, nh[u])
+        ticks[u, :nh[u]] = np.sort(rng.choice([12.3, 40.0, 40.0, 77.7, 150.2, 199.9], nh[u])) if rng.random() < 0.3 \
+            else np.sort(rng.uniform(0, 200, nh[u]))
+        if nh[u] > 1 and rng.random() < 0.1:
+            adc[u, 1] = ped            # the loop stops here although a later slot is above the pedestal
+    event_id_list = np.repeat(ev_of_pix[:, None], A, axis=1)
+    frac = np.zeros((n_pix, A, M))
+    seg_ids = np.full((n_pix, M), -1, dtype=np.int64)
+    traj_ids = np.full((n_pix, M), -1, dtype=np.int64)
+    for u in range(n_pix):
+        k = int(rng.integers(1, min(M, 14) + 1))
+        seg_ids[u, :k] = rng.choice(10_000, k, replace=False)
+        traj_ids[u, :k] = rng.choice([3, 3, 3, 3, 8, 11, 40], k) if rng.random() < 0.5 else 5
+        frac[u, :, :k] = rng.dirichlet(np.ones(k), A) * rng.choice([1.0, 1.0, 0.5], (A, 1))
+    t0 = np.sort(rng.uniform(0, 50, n_ev)) + (np.arange(n_ev) * 1.2e6 / 3 if spill else 0)
+    return dict(event_id_list=event_id_list, adc_list=adc, adc_ticks_list=ticks, unique_pix=upix, current_fractions=frac,
+                track_ids=seg_ids, traj_ids=traj_ids, event_start_times=t0)
+
+
+@pytest.mark.parametrize("cfg,spill", [("module0", False), ("module0", True), ("2x2_no_modvar", True)])
+def test_packets_array_form_equals_the_hit_loop(cfg, spill):
+    """packets.build_packets (array operations; what the driver calls) against packets.build_packets_loop (the reference's
+    loop restated hit by hit, pinned by the goldens): the same bytes, on the golden inputs and on random ones that walk every
+    branch -- clock rollovers (events up to 4 s apart), pixels without a chip, a disabled channel, light triggers, module
+    selection, trajectory sums of 9 and more terms."""
+    from larndsim_amd import packets
+    H.load_cfg(cfg, noise_zero=False)
+    g = H.gold(f"packets_{cfg}.npz")
+    n_ev = len(g["event_times"])
+    bad = {str(g["bad_key"]): [int(g["bad_channel"])]} if str(g["bad_key"]) else None
+    args = (g["event_id_list"], g["adc"], g["ticks"], g["unique_pix"], g["fractions"], g["segment_ids"], g["traj_ids"], g["event_times"])
+    kw = dict(light_trigger_times=g["trig_times"], light_trigger_event_id=np.arange(n_ev), light_trigger_modules=np.ones(n_ev),
+              bad_channels=bad)
+    a, b = packets.build_packets(*args, **kw), packets.build_packets_loop(*args, **kw)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and len(a[0]) > 40
+    rng = np.random.default_rng(77)
+    n_big = 0
+    for trial in range(6):
+        inp = _random_packet_inputs(rng, 400, 12, spill)
+        kw = {}
+        if trial % 2 == 0:
+            kw = dict(light_trigger_times=rng.uniform(0, 5, 12), light_trigger_event_id=rng.integers(0, 12, 12),
+                      light_trigger_modules=np.ones(12))
+        if trial % 3 == 1:
+            kw["i_mod"] = 1
+        a = packets.build_packets(**inp, **kw)
+        if trial == 2 and len(a[0]):           # disable a channel that carries data
+            first = a[0][a[0]["packet_type"] == 0][0]
+            kw["bad_channels"] = {"%i-%i-%i" % (first["io_group"], first["io_channel"], first["chip_id"]): [int(first["channel_id"])]}
+            a = packets.build_packets(**inp, **kw)
+        b = packets.build_packets_loop(**inp, **kw)
+        assert len(a[0]) == len(b[0]) > 300, trial
+        for name in a[0].dtype.names:
+            assert np.array_equal(a[0][name], b[0][name]), (trial, name)
+        for name in a[1].dtype.names:
+            assert a[1][name].tobytes() == b[1][name].tobytes(), (trial, name)
+        t = inp["traj_ids"]
+        n_big += int(((t == 3).sum(axis=1) >= 9).sum() + ((t == 5).sum(axis=1) >= 9).sum())
+        if spill:
+            assert (inp["event_start_times"] / consts.detector.CLOCK_CYCLE > consts.detector.CLOCK_RESET_PERIOD).any()
+    assert n_big > 0          # the pairwise-summation branch was reached
+
+
 @pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
 def test_packets_writer_golden(cfg):
     """packets.build_packets (larpix-control-free writer of the `packets` / `mc_packets_assn` datasets) against

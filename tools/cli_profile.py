@@ -1,0 +1,37 @@
+"""Where the bundled simulate_pixels CLI spends its time on a synthetic spill: python tools/cli_profile.py [cfg] [n_segments]
+Prints wall time, segments/s and the cProfile top of cumulative time (host side: batching, packet building, writers)."""
+import cProfile
+import importlib.util
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "larnd-sim_amd"), REPO, os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import numpy as np                                      # noqa: E402
+from larndsim_amd import synth                          # noqa: E402
+import helpers as H                                     # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "module0"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+spec = importlib.util.spec_from_file_location("ldsim_cli", os.path.join(REPO, "larnd-sim_amd", "cli", "simulate_pixels.py"))
+cli = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(cli)
+H.load_cfg(cfg)
+seg = synth.make_segments(n, seed=synth.SEED_BASE + 2, segs_per_event=5000)
+with tempfile.TemporaryDirectory() as d:
+    np.save(os.path.join(d, "in.npy"), seg)
+    np.save(os.path.join(d, "resp.npy"), synth.make_response("survey"))
+    kw = dict(config=cfg, response_file=os.path.join(d, "resp.npy"), rand_seed=5)
+    cli.run_simulation(os.path.join(d, "in.npy"), os.path.join(d, "warm.npz"), **kw)       # library, constants, caches
+    pr = cProfile.Profile()
+    t0 = time.time()
+    pr.enable()
+    res = cli.run_simulation(os.path.join(d, "in.npy"), os.path.join(d, "out.npz"), **kw)
+    pr.disable()
+    dt = time.time() - t0
+print(f"{cfg}: {n} segments in {dt:.2f} s = {n / dt:.3g} segments/s; packets {res.get('n_packets')}")
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
