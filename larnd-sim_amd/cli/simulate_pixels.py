@@ -471,8 +471,13 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         chain.run(int(b), int(e), want_fractions=True)
         r = chain.download()
         # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
-        for bb in np.unique(r["batch"]):
-            m = r["batch"] == bb
+        # the chain returns the unique pixels ordered by batch: a batch is a contiguous run (a view, not a 12 KB-per-pixel copy
+        # of the backtracking array); an unordered result falls back to masks
+        rb = r["batch"]
+        ordered = len(rb) < 2 or bool((rb[1:] >= rb[:-1]).all())
+        for bb in np.unique(rb):
+            m = slice(int(np.searchsorted(rb, bb, side="left")), int(np.searchsorted(rb, bb, side="right"))) if ordered \
+                else rb == bb
             lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
             seg_ids = tracks["segment_id"][lo:].astype(np.int64)
             trj_ids = tracks[traj_field][lo:].astype(np.int64)
