@@ -1,4 +1,5 @@
-"""Where the bundled simulate_pixels CLI spends its time on a synthetic spill: python tools/cli_profile.py [cfg] [n_segments]
+"""Where the bundled simulate_pixels CLI spends its time on a synthetic spill: python tools/cli_profile.py [cfg] [n_segments] [light]
+(`light`: also the light leg on a synthetic LUT -- incidence, photon sums, waveform chain, light datasets)
 Prints wall time, segments/s and the cProfile top of cumulative time (host side: batching, packet building, writers)."""
 import cProfile
 import importlib.util
@@ -17,6 +18,7 @@ import helpers as H                                     # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "module0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+with_light = len(sys.argv) > 3 and sys.argv[3] == "light"
 spec = importlib.util.spec_from_file_location("ldsim_cli", os.path.join(REPO, "larnd-sim_amd", "cli", "simulate_pixels.py"))
 cli = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(cli)
@@ -26,6 +28,9 @@ with tempfile.TemporaryDirectory() as d:
     np.save(os.path.join(d, "in.npy"), seg)
     np.save(os.path.join(d, "resp.npy"), synth.make_response("survey"))
     kw = dict(config=cfg, response_file=os.path.join(d, "resp.npy"), rand_seed=5)
+    if with_light:
+        np.savez(os.path.join(d, "lut.npz"), arr=synth.make_lut((14, 26, 8), 48, 100, 3))
+        kw["light_lut_filename"] = os.path.join(d, "lut.npz")
     cli.run_simulation(os.path.join(d, "in.npy"), os.path.join(d, "warm.npz"), **kw)       # library, constants, caches
     pr = cProfile.Profile()
     t0 = time.time()
@@ -33,5 +38,5 @@ with tempfile.TemporaryDirectory() as d:
     res = cli.run_simulation(os.path.join(d, "in.npy"), os.path.join(d, "out.npz"), **kw)
     pr.disable()
     dt = time.time() - t0
-print(f"{cfg}: {n} segments in {dt:.2f} s = {n / dt:.3g} segments/s; packets {res.get('n_packets')}")
+print(f"{cfg}{' + light' if with_light else ''}: {n} segments in {dt:.2f} s = {n / dt:.3g} segments/s; packets {res.get('n_packets')}")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
