@@ -229,7 +229,9 @@ def _readout_luts():
     """Array forms of the readout maps (pixel in tile -> chip / channel, (tile, chip) -> io, tile orientation, tile map),
     rebuilt when consts.detector carries other objects."""
     d = consts.detector
-    key = (id(d.PIXEL_CONNECTION_DICT), id(d.TILE_CHIP_TO_IO), id(d.TILE_ORIENTATIONS), id(d.TILE_MAP), len(d.PIXEL_CONNECTION_DICT))
+    # keyed by content, not identity: another configuration's dicts can be handed the ids of the ones it replaced
+    key = (hash(frozenset(d.PIXEL_CONNECTION_DICT.items())), repr(d.TILE_CHIP_TO_IO), repr(d.TILE_ORIENTATIONS), repr(d.TILE_MAP),
+           tuple(int(v) for v in d.N_PIXELS_PER_TILE))
     hit = _READOUT_LUT_CACHE.get("luts")
     if hit is not None and hit[0] == key:
         return hit[1]
