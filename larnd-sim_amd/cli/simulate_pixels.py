@@ -152,6 +152,36 @@ class _Output:
             np.savez(self.filename, **out)       # uncompressed like the HDF5 datasets it stands in for (zlib cost a quarter of a run)
 
 
+def _prepend_t_event(arr):
+    """The dataset with an f4 ``t_event`` field in front (aligned dtype, cli/simulate_pixels.py:618-625, 632-639)."""
+    if "t_event" in arr.dtype.names:
+        return arr
+    descr = [("t_event", "f4")] + arr.dtype.descr
+    new = np.empty(arr.shape, dtype=np.dtype(descr, align=True))
+    for field in descr[1:]:
+        if len(field[0]) == 0:
+            continue
+        new[field[0]] = arr[field[0]]
+    return new
+
+
+def attach_event_times(truth, event_times, sim):
+    """Event times into the truth datasets that are passed through (cli/simulate_pixels.py:614-642): ``vertices['t_event']``
+    for non-spill simulations -- one time per distinct event id, repeated over that event's rows in file order --, then
+    copied row by row into ``mc_hdr``.  ``truth`` is changed in place."""
+    if "vertices" in truth and not sim.IS_SPILL_SIM:
+        vertices = _prepend_t_event(truth["vertices"])
+        uniq_ev, counts = np.unique(vertices[sim.EVENT_SEPARATOR], return_counts=True)
+        vertices["t_event"] = np.repeat(np.take(np.asarray(event_times), uniq_ev, mode="wrap"), counts)   # (cupy.take wraps)
+        truth["vertices"] = vertices
+    if "mc_hdr" in truth and "vertices" in truth and "t_event" in truth["vertices"].dtype.names:
+        vertices, mc_hdr = truth["vertices"], _prepend_t_event(truth["mc_hdr"])
+        if len(vertices) != len(mc_hdr):
+            raise ValueError("vertices and mc_hdr datasets have different number of vertices! The number should be the same.")
+        mc_hdr["t_event"] = vertices["t_event"]
+        truth["mc_hdr"] = mc_hdr
+
+
 def _as_list(v):
     """a flag given as 'a,b,c' (argparse) or a list (fire-style call) -> list; a plain value stays"""
     if isinstance(v, str) and "," in v:
@@ -253,6 +283,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     num_evids = int(tracks[sim.EVENT_SEPARATOR].max() % sim.MAX_EVENTS_PER_FILE) + 1
     host_rng = np.random.default_rng(rand_seed)
     event_times = (np.arange(num_evids) * sim.SPILL_PERIOD if sim.IS_SPILL_SIM else gen_event_times(num_evids, host_rng))
+    attach_event_times(truth, event_times, sim)                                             # :614-642
     all_tracks = tracks[batching.select_active_volume(tracks, det.TPC_BORDERS)]            # :664-668
     all_events = np.unique(all_tracks[sim.EVENT_SEPARATOR])
     traj_field = "file_traj_id" if "file_traj_id" in all_tracks.dtype.names else "traj_id"

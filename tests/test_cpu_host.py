@@ -228,6 +228,43 @@ def test_cli_input_checks_like_the_reference(tmp_path):
     assert np.array_equal(new["t0"], [1, 2, 3]) and (new["t"] == 0).all() and (new["x"] == 7).all() and (new["z"] == 5).all()
 
 
+def _load_cli():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sp_cli", os.path.join(REPO, "larnd-sim_amd", "cli", "simulate_pixels.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    return cli
+
+
+def test_cli_event_times_into_truth_datasets():
+    """cli/simulate_pixels.py:614-642: t_event is put in front of `vertices` (non-spill simulations: one time per distinct
+    event id, repeated over the event's rows) and copied into `mc_hdr`; spill simulations leave `vertices` alone; a length
+    mismatch is the reference's ValueError."""
+    cli = _load_cli()
+    H.load_cfg("module0")
+    assert not consts.sim.IS_SPILL_SIM
+    vt = np.zeros(5, dtype=[("event_id", "u4"), ("vertex_id", "u8"), ("x_vert", "f4")])
+    vt["event_id"] = [0, 0, 2, 3, 3]
+    vt["x_vert"] = np.arange(5)
+    hdr = np.zeros(5, dtype=[("event_id", "u4"), ("reaction", "i4")])
+    hdr["event_id"], hdr["reaction"] = vt["event_id"], np.arange(5) + 10
+    times = np.array([1.5, 20.0, 300.0, 4000.0])
+    truth = {"vertices": vt.copy(), "mc_hdr": hdr.copy(), "trajectories": np.zeros(2, dtype=[("event_id", "u4")])}
+    cli.attach_event_times(truth, times, consts.sim)
+    assert truth["vertices"].dtype.names[0] == "t_event" and truth["vertices"].dtype["t_event"] == np.float32
+    assert np.array_equal(truth["vertices"]["t_event"], np.float32([1.5, 1.5, 300.0, 4000.0, 4000.0]))
+    assert np.array_equal(truth["vertices"]["x_vert"], vt["x_vert"]) and np.array_equal(truth["vertices"]["vertex_id"], vt["vertex_id"])
+    assert np.array_equal(truth["mc_hdr"]["t_event"], truth["vertices"]["t_event"]) and np.array_equal(truth["mc_hdr"]["reaction"], hdr["reaction"])
+    assert truth["trajectories"].dtype.names == ("event_id",)
+    with pytest.raises(ValueError, match="different number of vertices"):
+        cli.attach_event_times({"vertices": vt.copy(), "mc_hdr": hdr[:3].copy()}, times, consts.sim)
+    H.load_cfg("2x2_no_modvar")
+    assert consts.sim.IS_SPILL_SIM
+    truth = {"vertices": vt.copy(), "mc_hdr": hdr.copy()}
+    cli.attach_event_times(truth, times, consts.sim)
+    assert "t_event" not in truth["vertices"].dtype.names and "t_event" not in truth["mc_hdr"].dtype.names
+
+
 def _random_packet_inputs(rng, n_pix, n_ev, spill):
     """Per-pixel ADC arrays as the chain hands them to the packet writer, shaped to reach every branch of the hit loop: slots
     that stop at the pedestal, several hits per pixel, pixels off the readout map, events past the 1 s clock reset, equal
