@@ -146,7 +146,11 @@ class _Output:
         else:
             self.parts[name.replace("/", "__")] = [data]
 
-    def close(self):
+    def close(self, pixel_layout=None):
+        if self.h5py is not None:                                   # cli/simulate_pixels.py:1299-1301
+            with self.h5py.File(self.filename, "a") as f:
+                if "configs" in f.keys() and pixel_layout is not None:
+                    f["configs"].attrs["pixel_layout"] = pixel_layout
         if self.h5py is None:
             out = {k: (np.concatenate(v) if len(v) > 1 else v[0]) for k, v in self.parts.items() if len(v)}
             np.savez(self.filename, **out)       # uncompressed like the HDF5 datasets it stands in for (zlib cost a quarter of a run)
@@ -354,7 +358,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
             out.put(f"light_dat/light_dat_module{i_mod - 1}" if m2m else "light_dat/light_dat_allmodules", dat)
         for k, v in truth.items():
             out.put(k, v)
-        out.close()
+        out.close(pixel_layout if isinstance(pixel_layout, str) else None if pixel_layout is None else list(pixel_layout))
     finally:
         lib.set_option("mc_current", 0)
     print(f"simulated {totals['n_segments']} segments in {totals['n_batches']} batches -> {totals['n_hits']} hits, "

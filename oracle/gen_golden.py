@@ -249,7 +249,7 @@ def hand_segments(det, n, seed, plane_choices=None, long_frac=0.2, steep_frac=0.
 def corner_segments(det, n, seed):
     """Geometry corners for tracks_current (the shapes tools/fuzz_chain.py's last three flavours draw): segments hugging a TPC
     face in x / y (neighbour pixels fall off the plane -> pID -1 slots), very short ones (0.5-50 um), nearly along the drift
-    axis (|cz| > 0.99999) and nearly perpendicular to it (|dz| ~ 1e-4 of the length), plus a heavily ionising long one."""
+    axis (0.1-0.8 degrees off it) and nearly perpendicular to it (|dz| ~ 1e-4 of the length), plus a heavily ionising long one."""
     seg = hand_segments(det, n, seed)
     rng = np.random.default_rng(seed + 1000)
     B = np.sort(np.asarray(det.TPC_BORDERS), axis=-1)
@@ -267,13 +267,15 @@ def corner_segments(det, n, seed):
         elif flavour == 1:                       # very short
             L = 10 ** rng.uniform(-4.3, -2.3)
         elif flavour == 2:                       # along the drift axis
-            cz = rng.choice([-1, 1]) * (1 - 10 ** rng.uniform(-7, -5))
-            L = rng.uniform(0.1, 1.2)
+            # 0.1-0.8 degrees off the axis: closer to it the reference's z_interval hands its slice loop ranges that take the
+            # pure-Python launcher hours per segment (the HIP-vs-oracle fuzz covers 1e-7 off the axis in seconds)
+            cz = rng.choice([-1, 1]) * (1 - 10 ** rng.uniform(-5.7, -4))
+            L = rng.uniform(0.05, 0.4)
         elif flavour == 3:                       # perpendicular to it
             cz = rng.choice([-1, 1]) * 10 ** rng.uniform(-5, -3.5)
             L = rng.uniform(0.1, 1.0)
         else:                                    # heavily ionising, long
-            L = rng.uniform(1.2, 2.4)
+            L = rng.uniform(1.0, 1.6)
             seg["dEdx"][i] = rng.uniform(8, 30)
         sxy = np.sqrt(max(0.0, 1 - cz * cz))
         d = np.array([sxy * np.cos(ph), sxy * np.sin(ph), cz])
@@ -541,6 +543,8 @@ def gen_sampled(jobs):
         peak = int(round((K - 70) * ref.detector.RESPONSE_SAMPLING / ref.detector.TIME_SAMPLING
                          - (ref.detector.TIME_WINDOW - ref.detector.TIME_PADDING) / ref.detector.TIME_SAMPLING))
         ticks = sorted(set(list(range(3, T, 211)) + list(range(max(0, peak - 60), min(T, peak + 50), 4)) + [0, T - 1]))
+        if tag:      # a segment along the drift axis costs the pure-Python launcher ~2 minutes per tick: a dozen ticks
+            ticks = sorted(set(list(range(3, T, 811)) + list(range(max(0, peak - 48), min(T, peak + 40), 12)) + [0, T - 1]))
         with Pool(jobs) as pool:
             res = pool.map(_current_job, [(cfg, r, pix["neigh"], T, i, ticks, kind) for i in range(r.shape[0])])
         signals = np.zeros((r.shape[0], pix["neigh"].shape[1], len(ticks)), dtype=np.float32)

@@ -162,7 +162,7 @@ def test_tracks_current_sampled_golden(cfg, tag, prune):
     err = np.abs(got - ref)
     tol = 1e-5 * np.abs(ref) + 1e-7 * peak
     assert (err <= tol).all(), f"max excess {np.max(err - tol)} at {np.unravel_index(np.argmax(err - tol), err.shape)}"
-    assert (ref != 0).sum() > 500
+    assert (ref != 0).sum() > (100 if tag else 500)        # the corner sets hold a dozen ticks per pair
 
 
 def test_tracks_current_vs_oracle_full_ticks():

@@ -68,7 +68,7 @@ def test_tracks_current_sampled(cfg, tag):
     sig = O.tracks_current(r, neigh, T, resp)
     got = sig[:, :, g["ticks"]]
     ref = g["signals"]
-    assert (ref != 0).sum() > 500
+    assert (ref != 0).sum() > (100 if tag else 500)        # the corner sets hold a dozen ticks per pair
     # same operation order as the reference -> f32 outputs agree to the last bit or two
     np.testing.assert_allclose(got, ref, rtol=3e-7, atol=0)
     nz = ref != 0
