@@ -153,7 +153,7 @@ def main():
     op_all = consts.light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32) if light_on else None
 
     def new_acc():
-        return {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0,
+        return {"cur_ms": 0.0, "w_ms": 0.0, "m_ms": 0.0, "f_ms": 0.0, "samples": 0, "adc_ms": 0.0, "bytes": 0.0, "dfma": 0, "dfma_useful": 0,
                 "S": 0, "U": 0, "pairs": 0, "launches": 0, "hits": 0, "ambig": 0, "ovf": 0, "inc_ms": 0.0, "inc_n": 0,
                 "sum_ms": 0.0, "sum_n": 0, "photons": 0.0}
     acc = new_acc()
@@ -179,7 +179,7 @@ def main():
                 acc["w_ms"] += ms["weights_ms"]; acc["m_ms"] += ms["mac_ms"]; acc["f_ms"] += ms["fallback_ms"]
                 acc["samples"] += st.n_samples
                 acc["bytes"] += 184.0 * st.n_segments + 484.0 * st.n_unique     # SURVEY 8d B_alg
-                acc["dfma"] += st.n_dfma; acc["S"] += st.n_segments; acc["U"] += st.n_unique
+                acc["dfma"] += st.n_dfma; acc["dfma_useful"] += st.n_dfma_useful; acc["S"] += st.n_segments; acc["U"] += st.n_unique
                 acc["pairs"] += st.n_pairs; acc["launches"] += 1; acc["ambig"] += st.n_ambiguous
                 acc["ovf"] += st.n_overflow
                 acc["hits"] += ch.compact_hits()[1]
@@ -244,6 +244,7 @@ def main():
                                         "dfma_per_segment": acc["dfma"] / max(acc["S"], 1),
                                         "valu_f64_frac": (2.0 * acc["dfma"] / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS)
                                         if acc["m_ms"] > 0 else None,
+                                        "useful_share_of_issued": (acc["dfma_useful"] / acc["dfma"]) if acc["dfma"] else None,
                                         "note": "synthetic 'dense' response (no exact zeros, so trim_response skips nothing)"}
             lib.set_response(response, ch.ctx)
         acc = main_acc
@@ -304,7 +305,12 @@ def main():
                          "valu_f64": {"kernel": mac_name if split else f"current_kernel<{M}>",
                                       "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tflops / FP64_VALU_PEAK_TFLOPS,
-                                      "dfma_per_segment": acc["dfma"] / max(acc["S"], 1)}},
+                                      "dfma_per_segment": acc["dfma"] / max(acc["S"], 1),
+                                      # the FMAs that are neither zero padding of an 8-shift weight block nor ticks outside the
+                                      # pair's window (LdsimChainStats.n_dfma_useful)
+                                      "useful_share_of_issued": (acc["dfma_useful"] / acc["dfma"]) if acc["dfma"] else None,
+                                      "frac_useful": (tflops / FP64_VALU_PEAK_TFLOPS * acc["dfma_useful"] / acc["dfma"])
+                                      if acc["dfma"] else None}},
         }
         if light_on and acc["inc_n"]:
             n_op = int(consts.light.N_OP_CHANNEL)

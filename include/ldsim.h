@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 4
+#define LDSIM_ABI_VERSION 5
 
 /* error codes */
 #define LDSIM_OK 0
@@ -325,6 +325,9 @@ typedef struct {
   int64_t n_fallback;      /* pairs recomputed by the monolithic kernel (split-path capacity overflow) */
   int64_t n_samples;       /* charge samples that passed the bound and were evaluated (2 erf + exp each) */
   int64_t n_wbuf;          /* f64 entries of the weight arena used by the split path in this call */
+  int64_t n_dfma_useful;   /* of n_dfma, the FMAs of the quadrature path that are neither padding of an 8-shift weight block
+                              nor ticks outside the pair's window: sum over pairs of (weights kept) x (window ticks); 0 when
+                              another weights stage ran */
 } LdsimChainStats;
 
 /* Fused a5-a16 (max_pixels .. digitize) on resident segments [seg_begin, seg_end):

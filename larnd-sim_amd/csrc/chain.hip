@@ -52,7 +52,7 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
 int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc) {
   CK(ldsim_ensure(ctx, SB_MISC, 4096));
   unsigned long long* counters = (unsigned long long*)((char*)ctx->scratch[SB_MISC].p + 256);
-  HIPCHK(hipMemsetAsync(counters, 0, 64, ctx->stream));
+  HIPCHK(hipMemsetAsync(counters, 0, 128, ctx->stream));
   CurArgs a{};
   fill_cur_common(ctx, a);
   a.pair_val = nullptr; a.pair_key = nullptr;
@@ -88,7 +88,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   hipStream_t st = ctx->stream;
   HIPCHK(hipEventRecord(ctx->ev[0], st));
 
-  // ---- misc block: [0] err, [8] nmax i32, [16] tran bits u64, [256..] counters u64[8] ----------------------------
+  // ---- misc block: [0] err, [8] nmax i32, [16] tran bits u64, [256..] counters u64[16] ----------------------------
   CK(ldsim_ensure(ctx, SB_MISC, 4096));
   char* misc = (char*)ctx->scratch[SB_MISC].p;
   unsigned long long* counters = (unsigned long long*)(misc + 256);
@@ -258,7 +258,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
       CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
       if (attempt > 0) {
         HIPCHK(hipMemsetAsync(&counters[0], 0, 16, st));   // ambiguous shifts, samples
-        HIPCHK(hipMemsetAsync(&counters[5], 0, 24, st));   // dfma, overflowed pairs, pool cursor
+        HIPCHK(hipMemsetAsync(&counters[5], 0, 32, st));   // dfma, overflowed pairs, pool cursor, useful FMAs
       }
       int rc = split_launch_weights(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
                                     (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
@@ -337,8 +337,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
 
   // ---- compact hit rows (payload of the multi-GPU all-gather) -----------------------------------------------------------------------------
   CK(sort_exclusive_scan_i32(ctx, d_hitcnt, d_hitoff, U));
-  unsigned long long h_cnt[8] = {0};
-  HIPCHK(hipMemcpyAsync(h_cnt, counters, 64, hipMemcpyDeviceToHost, st));
+  unsigned long long h_cnt[9] = {0};
+  HIPCHK(hipMemcpyAsync(h_cnt, counters, 72, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
@@ -348,6 +348,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   ctx->stats.n_fallback = (int64_t)h_cnt[6];
   ctx->stats.n_samples = (int64_t)h_cnt[1];
   ctx->stats.n_wbuf = (int64_t)h_cnt[7];
+  ctx->stats.n_dfma_useful = (int64_t)h_cnt[8];
   CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
   CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
                        (int32_t*)ctx->scratch[SB_HITS].p));

@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       s_misc[16] = 0;   // items emitted
       s_misc[17] = 0;   // corrections emitted
       s_misc[18] = 0;   // overflow (s_misc[19], the run count, is set by the first chunk's set-up on wave 2)
+      s_misc[21] = 0;   // weights emitted that are not block padding
     }
   } else if (wv == 1) {
     int j = -1;
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       }
       __syncthreads();
       if (wv == 0) {
-        int nact = 0, nblk_tot = 0;
+        int nact = 0, nblk_tot = 0, nrun_tot = 0;
         for (int base = 0; base < ncell; base += 64) {
           const int cell = base + lane;
           unsigned long long mk = 0;
@@ -450,8 +451,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
           const bool act = mk != 0;
           const int ulo = act ? __ffsll((long long)mk) - 1 : 0, uhi = act ? 63 - __clzll((long long)mk) : 0;
           unsigned long long am = __ballot(act);
-          int nb8 = act ? ((uhi - (ulo & ~7)) / 8 + 1) : 0;
-          const int sc = wave_scan_i32(nb8, 0, [](int a, int b) { return a + b; });
+          int nb8 = act ? ((uhi - ulo) / 8 + 1) : 0;      // blocks of 8 shifts counted from the first kept shift, not from a multiple of 8
+          // one scan for two sums: blocks (low half) and weights inside [ulo, uhi] (high half; statistics: the FMAs that are
+          // not padding of an 8-shift block)
+          const int scp = wave_scan_i32(nb8 + ((act ? uhi - ulo + 1 : 0) << 16), 0, [](int a, int b) { return a + b; });
+          const int sc = scp & 0xFFFF;
           if (cell < ncell) {
             s_culo[cell] = act ? (unsigned char)ulo : (unsigned char)255;
             s_cuhi[cell] = (unsigned char)uhi;
@@ -459,9 +463,12 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
             s_boff[cell] = (unsigned short)(nblk_tot + sc - nb8);
           }
           nact += __popcll(am);
-          nblk_tot += __builtin_amdgcn_readlane(sc, 63);
+          const int tot = __builtin_amdgcn_readlane(scp, 63);
+          nblk_tot += tot & 0xFFFF;
+          nrun_tot += tot >> 16;
         }
         if (lane == 0) {
+          s_misc[21] += nrun_tot;
           s_misc[6] = nact;
           s_misc[7] = nblk_tot;
           int have = s_misc[16];
@@ -486,17 +493,29 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
           const int cell = tcell[r];
           if (cell < 0 || s_culo[cell] == 255) continue;
           const int ulo = s_culo[cell], uhi = s_cuhi[cell];
-          const int ulo8 = ulo & ~7, u0 = tblk[r] * 8;
-          if (u0 < ulo8 || u0 > uhi) continue;
+          const int u0 = tblk[r] * 8;
+          if (u0 + 7 < ulo || u0 > uhi) continue;
+          // the cell's run starts at its first kept shift (an 8-aligned start padded 30 % of the blocks' FMAs away); the zeros
+          // behind the last kept shift fill the last block
           const unsigned long long wo = base + (unsigned long long)s_boff[cell] * 8ull;
-          double* dst = S.wbuf + wo + (u0 - ulo8);
+          double* dst = S.wbuf + wo;
 #pragma unroll
-          for (int q = 0; q < 8; q++) dst[q] = (u0 + q >= ulo && u0 + q <= uhi) ? acc[r][q] : 0.0;
-          if (u0 == ulo8) {
+          for (int q = 0; q < 8; q++) {
+            const int u = u0 + q;
+            if (u >= ulo && u <= uhi) dst[u - ulo] = acc[r][q];
+          }
+          const int nblk = (uhi - ulo) / 8 + 1;
+          if (uhi < u0 + 8) {
+            const int run = uhi - ulo + 1;
+#pragma unroll
+            for (int k = 0; k < 7; k++)
+              if (run + k < nblk * 8) dst[run + k] = 0.0;
+          }
+          if (u0 <= ulo) {
             const int col = cell / NJ, jj = cell - col * NJ;
             Item itx;
-            itx.cell_nblk = (s_coli[col0 + col] * A.nj + (jmin + jj)) | (((uhi - ulo8) / 8 + 1) << 16);
-            itx.sbase = u_min + ulo8;
+            itx.cell_nblk = (s_coli[col0 + col] * A.nj + (jmin + jj)) | (nblk << 16);
+            itx.sbase = u_min + ulo;
             itx.woff_lo = (uint32_t)(wo & 0xFFFFFFFFull);
             itx.woff_hi = (uint32_t)(wo >> 32);
             items[have + s_li[cell]] = itx;
@@ -545,6 +564,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     int r = min(s_misc[19], RUNS_MAX);
     hdr[8 + r] = s_misc[16];
     if (s_misc[18]) atomicAdd(&A.counters[6], 1ull);
+    else {
+      const int ticks = min(T, it_w1) - max(it0, it_w0);
+      if (ticks > 0 && s_misc[21] > 0) atomicAdd(&A.counters[8], (unsigned long long)s_misc[21] * (unsigned long long)ticks);
+    }
   }
 }
 

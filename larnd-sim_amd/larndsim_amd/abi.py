@@ -52,10 +52,11 @@ class LdsimChainStats(C.Structure):
     _fields_ = [("n_segments", C.c_int64), ("n_pairs", C.c_int64), ("n_unique", C.c_int64),
                 ("n_batches", C.c_int64), ("n_overflow", C.c_int64),
                 ("max_active", C.c_int32), ("max_neigh", C.c_int32), ("max_length", C.c_int32),
-                ("n_ambiguous", C.c_int32), ("n_dfma", C.c_int64), ("n_fallback", C.c_int64), ("n_samples", C.c_int64), ("n_wbuf", C.c_int64)]
+                ("n_ambiguous", C.c_int32), ("n_dfma", C.c_int64), ("n_fallback", C.c_int64), ("n_samples", C.c_int64), ("n_wbuf", C.c_int64),
+                ("n_dfma_useful", C.c_int64)]
 
 
-ABI_VERSION = 4      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
+ABI_VERSION = 5      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/ldsim.h but not exported"
     assert set(lib.EXPORTS) == declared
-    assert l.ldsim_abi_version() == abi.ABI_VERSION == 4
+    assert l.ldsim_abi_version() == abi.ABI_VERSION == 5
 
 
 def test_graft_entry_build_succeeds():
@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
     assert c.tpc_borders.offset == 13 * 8 + 8
     assert c.n_pixels.offset == c.tpc_borders.offset + 128 * 6 * 8
     assert C.sizeof(abi.LdsimTrackLayout) == 4 + 2 * 4 * layout.NFIELDS
-    assert C.sizeof(abi.LdsimChainStats) == 5 * 8 + 4 * 4 + 4 * 8
+    assert C.sizeof(abi.LdsimChainStats) == 5 * 8 + 4 * 4 + 5 * 8
 
 
 def test_segments_dtype_is_the_edep_sim_schema():
