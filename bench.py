@@ -185,8 +185,12 @@ def main():
                 acc["hits"] += ch.compact_hits()[1]
             if cm is not None:
                 cm.accumulate_hits(reset=(i == 0))
-            if download:
+            if download == "overlapped":         # this chunk's rows cross PCIe while the next chunk computes
+                ch.download_async()
+            elif download:
                 ch.download(pinned=True)
+        if download == "overlapped":
+            ch.wait_download()
         if cm is not None:
             return cm.allgather_hits()[0]
         return 0
@@ -227,6 +231,16 @@ def main():
                                             "adc_ticks / adc_digit / track_pixel_map / current_fractions"
                                             + (" / light_sample_inc" if light_on else "")
                                             + " per chunk (records from pageable memory, results into page-locked buffers)"}
+        # (a') the same with every chunk's D2H on the copy stream beside the next chunk's kernels (ldsim_chain_download_async)
+        step(False, download="overlapped")   # sizes the second set of output / host buffers
+        ch.synchronize()
+        t1 = time.perf_counter()
+        ch.upload(seg, bid)
+        step(False, download="overlapped")
+        ch.synchronize()
+        t_ovl = time.perf_counter() - t1
+        extras["pcie_inclusive"]["overlapped_value"] = len(seg) / t_ovl
+        extras["pcie_inclusive"]["overlapped_ms_per_step"] = 1e3 * t_ovl
         # (b) the same workload on a response table without exact zeros (real response files are dense)
         if a.response != "dense":
             lib.set_response(synth.make_response("dense"), ch.ctx)

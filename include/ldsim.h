@@ -342,6 +342,14 @@ int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int32
 int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
                          double* adc_list, double* adc_ticks, double* adc_digit,
                          int64_t* track_pixel_map, double* current_fractions);
+/* The same rows on a second HIP stream, returning at once: the next ldsim_charge_chain computes, into the other of two sets
+ * of output buffers, while these rows cross PCIe (the copy engines run beside the kernels).  The host buffers must be
+ * page-locked (ldsim_host_alloc) for the copy to be asynchronous, and hold the rows after ldsim_chain_download_wait.  One
+ * download is in flight at a time (a second call waits for the first); a launch that would overwrite rows still being
+ * copied waits for that copy.  Replaces nothing in the reference (its driver copies with cupy .get() after every batch). */
+int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch, double* adc_list,
+                               double* adc_ticks, double* adc_digit, int64_t* track_pixel_map, double* fractions);
+int ldsim_chain_download_wait(ldsim_ctx* ctx);
 /* Device pointers of the last chain call's compact hit list (for a collective without a host round trip):
  * hits are (batch i32, pixel i32, adc u8-as-i32, tick f64) rows for every written ADC slot. */
 int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes);

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "ldsim_args.h"
+#include <utility>
 
 int seg_launch_max_pixels(ldsim_ctx*, int64_t, int64_t, int32_t*, unsigned long long*);
 int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int32_t*, int32_t*, int, double*, const int32_t*,
@@ -71,6 +72,17 @@ int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* 
 int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions) {
   const LdsimConsts& h = ctx->h_consts;
   const int64_t n = seg_end - seg_begin;
+  // results of the launch before this one may still be on their way to the host (ldsim_chain_download_async): this launch
+  // writes the other set of output buffers; a copy that reads the set about to be written (two launches old) is waited for
+  ctx->out_gen++;
+  if (ctx->async_out) {
+    if (ctx->copy_pending && ctx->pending_gen <= ctx->out_gen - 2) {
+      HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+      ctx->copy_pending = 0;
+    }
+    static const int out_slots[7] = {SB_UPIX, SB_UBATCH, SB_ADC, SB_TICKS, SB_DIGIT, SB_TPM, SB_FRAC};
+    for (int k = 0; k < 7; k++) std::swap(ctx->scratch[out_slots[k]], ctx->out_alt[k]);
+  }
   ctx->stats = LdsimChainStats{};
   ctx->stats.n_segments = n;
   ctx->chain_U = 0;

@@ -207,7 +207,13 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
                   ctx->d_glx, ctx->d_glw};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
   for (auto& b : ctx->scratch)
+    if (b.p) (void)hipFree(b.p);
+  for (auto& b : ctx->out_alt)
     if (b.p) (void)hipFree(b.p);
   for (int i = 0; i < 8; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -1171,6 +1177,51 @@ extern "C" int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* u
     HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// The same copies on a second stream, returning at once: the next ldsim_charge_chain computes (into the other set of output
+// buffers) while these rows cross PCIe.  Host buffers should be page-locked (ldsim_host_alloc) or the copy is not
+// asynchronous; they hold the rows after ldsim_chain_download_wait.  One download is in flight at a time.
+extern "C" int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
+                                          double* adc_list, double* adc_ticks, double* adc_digit, int64_t* tpm,
+                                          double* fractions) {
+  NEED(ctx, "null ctx");
+  const int64_t U = ctx->chain_U;
+  if (capacity < U) {
+    ldsim_set_error("capacity %lld < required %lld rows", (long long)capacity, (long long)U);
+    return LDSIM_ENOSPC;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (ctx->copy_pending) {
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    ctx->copy_pending = 0;
+  }
+  ctx->async_out = 1;
+  if (U == 0) return 0;
+  if (fractions) NEED(ctx->want_fractions, "fractions were not requested in the last ldsim_charge_chain call");
+  const int A = ctx->h_consts.max_adc_values, M = ctx->h_consts.max_tracks_per_pixel;
+  hipStream_t cs = ctx->copy_stream;      // (ldsim_charge_chain returns with its stream drained: the rows are complete)
+  if (unique_pix) HIPCHK(hipMemcpyAsync(unique_pix, ctx->scratch[SB_UPIX].p, U * 4, hipMemcpyDeviceToHost, cs));
+  if (batch) HIPCHK(hipMemcpyAsync(batch, ctx->scratch[SB_UBATCH].p, U * 4, hipMemcpyDeviceToHost, cs));
+  if (adc_list) HIPCHK(hipMemcpyAsync(adc_list, ctx->scratch[SB_ADC].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, cs));
+  if (adc_ticks) HIPCHK(hipMemcpyAsync(adc_ticks, ctx->scratch[SB_TICKS].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, cs));
+  if (adc_digit) HIPCHK(hipMemcpyAsync(adc_digit, ctx->scratch[SB_DIGIT].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, cs));
+  if (tpm) HIPCHK(hipMemcpyAsync(tpm, ctx->scratch[SB_TPM].p, (size_t)U * M * 8, hipMemcpyDeviceToHost, cs));
+  if (fractions) HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, cs));
+  ctx->copy_pending = 1;
+  ctx->pending_gen = ctx->out_gen;
+  return 0;
+}
+
+extern "C" int ldsim_chain_download_wait(ldsim_ctx* ctx) {
+  NEED(ctx, "null ctx");
+  if (ctx->copy_pending) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    ctx->copy_pending = 0;
+  }
   return 0;
 }
 

@@ -103,6 +103,13 @@ struct ldsim_ctx {
   DevBuf resp_pad;                           // zero-padded copy of the response rows for mac_shift_kernel
   int32_t resp_pad_lo = 0, resp_pad_hi = -2; // staged range it was built for (-2: not built)
   double quad_n0 = 4.8, quad_slope = 1.6;    // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-10 of the peak weight
+  // overlapped download of the chain's results (ldsim_chain_download_async): a second stream copies launch k's per-pixel
+  // arrays to the host while launch k + 1 computes into the other set of output buffers
+  hipStream_t copy_stream = nullptr;
+  DevBuf out_alt[7];                         // the other set of SB_UPIX, SB_UBATCH, SB_ADC, SB_TICKS, SB_DIGIT, SB_TPM, SB_FRAC
+  int async_out = 0;                         // alternate the output buffers from launch to launch (set by the first async download)
+  int copy_pending = 0;
+  int64_t out_gen = 0, pending_gen = 0;      // chain launches so far; the launch whose results the pending copy reads
   int light_eff_plain = 0;                   // every OP_CHANNEL_EFFICIENCY finite and >= 0
   int light_incidence_scalar = 0;            // 1 = the one-channel-per-lane light_incidence_kernel (A/B checks)
   int mac_mode = 1;                          // M = 1 correlation: 1 = mac_shift_kernel (DPP window), 0 = mac_kernel<1> (LDS rows)

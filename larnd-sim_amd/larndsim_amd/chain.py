@@ -151,6 +151,34 @@ class ChargeChain:
                                                   lib.ptr(out['track_pixel_map']), lib.ptr(fr)))
         return out
 
+    def download_async(self, fractions=None):
+        """Start copying the results of the last run() to page-locked host arrays on the library's copy stream and return them
+        at once (``ldsim_chain_download_async``): the next ``run()`` overlaps with the transfer.  The arrays hold the rows
+        after ``wait_download()``; two sets of host buffers alternate, so the arrays of one call stay valid until the call
+        after the next one."""
+        U = int(self.stats.n_unique)
+        A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
+        want_fr = fractions if fractions is not None else self._want_fractions
+        slot = self.__dict__["_async_slot"] = 1 - self.__dict__.get("_async_slot", 1)
+        tag = f"@{slot}"
+        out = dict(unique_pix=self._pinned("unique_pix" + tag, (U,), np.int32), batch=self._pinned("batch" + tag, (U,), np.int32),
+                   adc_list=self._pinned("adc_list" + tag, (U, A), np.float64),
+                   adc_ticks_list=self._pinned("adc_ticks_list" + tag, (U, A), np.float64),
+                   adc_digit=self._pinned("adc_digit" + tag, (U, A), np.float64),
+                   track_pixel_map=self._pinned("track_pixel_map" + tag, (U, M), np.int64))
+        fr = self._pinned("current_fractions" + tag, (U, A, M), np.float64) if want_fr else None
+        if fr is not None:
+            out['current_fractions'] = fr
+        lib.check(lib.load().ldsim_chain_download_async(self.ctx, C.c_int64(U), lib.ptr(out['unique_pix']),
+                                                        lib.ptr(out['batch']), lib.ptr(out['adc_list']),
+                                                        lib.ptr(out['adc_ticks_list']), lib.ptr(out['adc_digit']),
+                                                        lib.ptr(out['track_pixel_map']), lib.ptr(fr)))
+        return out
+
+    def wait_download(self):
+        """Block until the transfer started by ``download_async`` has landed."""
+        lib.check(lib.load().ldsim_chain_download_wait(self.ctx))
+
     # ---- device-resident light leg (cli/simulate_pixels.py:749-797, 1120-1153) ------------------------------------------------
     def light_incidence(self, lut=None, n_out=None):
         """``lightLUT.calculate_light_incidence`` over all resident segments (after ``quench_drift``); the arrays stay in

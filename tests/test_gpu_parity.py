@@ -1491,6 +1491,47 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
 
 
+def test_overlapped_download_returns_the_rows_of_its_own_launch():
+    """ldsim_chain_download_async: launch k's rows are copied on the second stream while launch k + 1 computes into the
+    other set of output buffers; every chunk's arrays equal the synchronous download of the same chunk, also when a wait is
+    skipped (the launch two later waits for the copy itself) and when synchronous and overlapped downloads are mixed."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(4000, seed=23, segs_per_event=800)          # five events -> five batches
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    ch = ChargeChain(H.response_for("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    cuts = [0] + [int(i) for i in np.flatnonzero(np.diff(bid)) + 1] + [len(seg)]     # one launch per batch
+    assert len(cuts) >= 5
+    ref = []
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        ch.run(b, e, want_fractions=True)
+        ref.append({k: v.copy() for k, v in ch.download().items()})
+    got, prev = [], None
+    for i, (b, e) in enumerate(zip(cuts[:-1], cuts[1:])):
+        ch.run(b, e, want_fractions=True)          # overlaps with the copy started one iteration ago
+        if prev is not None and i != 2:
+            ch.wait_download()                       # (i == 2: no explicit wait; the download_async below waits for the copy)
+        new = ch.download_async()
+        if prev is not None:
+            got.append({k: v.copy() for k, v in prev.items()})
+        prev = new
+    ch.wait_download()
+    got.append({k: v.copy() for k, v in prev.items()})
+    assert len(got) == len(ref) >= 3
+    for a, r in zip(got, ref):
+        assert set(a) == set(r)
+        for k in r:
+            assert np.array_equal(a[k], r[k]), k
+    # a synchronous download after overlapped ones still returns the last launch
+    ch.run(cuts[0], cuts[1], want_fractions=True)
+    last = ch.download()
+    for k in ref[0]:
+        assert np.array_equal(last[k], ref[0][k]), k
+
+
 @pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("module0", "dense"), ("ndlar", "golden"), ("ndlar", "dense")])
 def test_mac_shift_kernel_is_bitwise_the_lds_kernel(cfg, kind):
     """mac_shift_kernel / mac_shift2_kernel (default: window slid through the wave with DPP shifts, weights through the
