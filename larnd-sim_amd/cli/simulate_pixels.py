@@ -197,7 +197,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
                    light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None,
                    pixel_thresholds_file=None, pixel_gains_file=None, rand_seed=None, config_root=None,
-                   tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, **ignored):
+                   tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, overlap_downloads=None, **ignored):
     if not os.path.exists(input_filename):
         raise Exception(f"Input file {input_filename} does not exist.")
     if os.path.exists(output_filename):
@@ -330,7 +330,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
                 chain.set_pixel_gains(*fee.load_pixel_table(gain_file))
             res = _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, event_times, rand_seed, traj_field,
                                    per_module(light_lut_filename, i_mod) if light_simulated else None, light_det_noise_filename,
-                                   cfg, len(mod_ids), bad_list, chunk_segments, raw_arrays)
+                                   cfg, len(mod_ids), bad_list, chunk_segments, raw_arrays, overlap_downloads)
             for k in totals:
                 totals[k] += res[k]
             kept_tracks.append(res["tracks"])
@@ -368,7 +368,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
 
 
 def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, event_times, rand_seed, traj_field, light_lut,
-                     light_det_noise_filename, cfg, n_mod_ids, bad_list, chunk_segments, raw_arrays):
+                     light_det_noise_filename, cfg, n_mod_ids, bad_list, chunk_segments, raw_arrays, overlap_downloads=None):
     """One pass of the driver's module loop body (cli/simulate_pixels.py:717-1232) on the device-resident chain: quench + drift,
     light leg, charge chain, packets.  ``tracks``: the module's active segments (all active segments without module
     variation); ``all_events``: event ids of every active segment (a module without segments in an event still reads out)."""
@@ -499,12 +499,9 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             announced += 1
 
     parts = []
-    b = 0
-    for e in edges[1:]:
-        if not (e - b >= chunk_segments or e == nsim):
-            continue
-        chain.run(int(b), int(e), want_fractions=True)
-        r = chain.download()
+
+    def export_chunk(r):
+        """packets and association rows of one chain launch (`r`: the launch's per-pixel arrays)"""
         # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
         # the chain returns the unique pixels ordered by batch: a batch is a contiguous run (a view, not a 12 KB-per-pixel copy
         # of the backtracking array); an unordered result falls back to masks
@@ -534,9 +531,33 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             res["n_packets"] += len(pk)
         res["n_hits"] += int((r["adc_list"] != 0).sum())
         if raw_arrays:
+            r = {k: np.array(v) for k, v in r.items()}       # (views of page-locked buffers that later launches reuse)
             r["event_id"] = np.array([t[0] for t in table])[r["batch"]]
             parts.append(r)
+
+    # launch k's rows cross PCIe on the library's copy stream (download_async) while its packets' predecessor, launch k - 1,
+    # is turned into packets here; the arrays of a launch are complete once the next download_async (or the final wait) returns
+    # (page-locking the two sets of host arrays costs ~0.5 s: worth it from about eight launches on; shorter runs copy each
+    # launch's rows synchronously into ordinary arrays)
+    overlapped = (nsim >= 8 * chunk_segments) if overlap_downloads is None else bool(overlap_downloads)
+    b = 0
+    in_flight = None
+    for e in edges[1:]:
+        if not (e - b >= chunk_segments or e == nsim):
+            continue
+        chain.run(int(b), int(e), want_fractions=True)
+        if not overlapped:
+            export_chunk(chain.download())
+            b = e
+            continue
+        arriving = chain.download_async()
+        if in_flight is not None:
+            export_chunk(in_flight)
+        in_flight = arriving
         b = e
+    if in_flight is not None:
+        chain.wait_download()
+        export_chunk(in_flight)
     if len(all_events):
         announce_until(all_events[-1])
     if raw_arrays and parts:

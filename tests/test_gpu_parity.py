@@ -1805,6 +1805,33 @@ def test_cli_module_variation(tmp_path):
     assert (out["light_wvfm_mc_assn"]["op_channel_id"] >= 96).any()          # channel ids of modules past the first
 
 
+def test_cli_overlapped_downloads_write_the_same_file(tmp_path):
+    """The driver's pipelined form (a launch's rows on the copy stream while the previous launch's packets are built; chosen
+    from eight launches on) against the synchronous one on the same launches: every dataset of the output is identical."""
+    cli = _load_cli()
+    H.load_cfg("module0")
+    seg = synth.make_segments(480, seed=12, segs_per_event=40)          # 12 events
+    np.save(tmp_path / "in.npy", seg)
+    np.save(tmp_path / "resp.npy", synth.make_response("survey"))
+    outs = []
+    for name, ov in (("sync", False), ("ovl", True), ("auto", None)):
+        res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / f"{name}.npz"), config="module0", rand_seed=4,
+                                 response_file=str(tmp_path / "resp.npy"), chunk_segments=40, raw_arrays=True,
+                                 overlap_downloads=ov)
+        assert res["n_batches"] >= 8 and res["n_packets"] > 100
+        outs.append(dict(np.load(tmp_path / f"{name}.npz")))
+    for other in outs[1:]:
+        assert set(other) == set(outs[0])
+        for k in outs[0]:
+            a, b = outs[0][k], other[k]
+            assert a.shape == b.shape and a.dtype == b.dtype, k
+            if a.dtype.names:                      # field by field: padding bytes of an aligned record are not data
+                for f in a.dtype.names:
+                    assert np.array_equal(a[f], b[f], equal_nan=True), (k, f)
+            else:
+                assert np.array_equal(a, b, equal_nan=True), k
+
+
 def test_cli_light_leg(tmp_path):
     """--light_lut_filename: the CLI runs the device-resident light leg and writes light_dat like the reference's driver."""
     cli = _load_cli()
