@@ -499,6 +499,8 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             announced += 1
 
     parts = []
+    seg_ids_all = tracks["segment_id"].astype(np.int64)            # (once: a copy of the tail per batch is quadratic in a spill)
+    trj_ids_all = tracks[traj_field].astype(np.int64)
 
     def export_chunk(r):
         """packets and association rows of one chain launch (`r`: the launch's per-pixel arrays)"""
@@ -511,8 +513,7 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             m = slice(int(np.searchsorted(rb, bb, side="left")), int(np.searchsorted(rb, bb, side="right"))) if ordered \
                 else rb == bb
             lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
-            seg_ids = tracks["segment_id"][lo:].astype(np.int64)
-            trj_ids = tracks[traj_field][lo:].astype(np.int64)
+            seg_ids, trj_ids = seg_ids_all[lo:], trj_ids_all[lo:]
             tpm = r["track_pixel_map"][m]
             track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
             traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
