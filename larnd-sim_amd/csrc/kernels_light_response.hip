@@ -8,7 +8,8 @@
 //
 // One thread per (row, tick), a workgroup = 256 consecutive ticks of one row.  The j range of the workgroup is walked in
 // chunks of JCHUNK: the chunk of x and the weights it can meet are staged in LDS; inside a chunk all lanes read the same
-// x[j] (broadcast) and consecutive weights (conflict-free).  Truth slots (optional) follow the reference literally.
+// x[j] (broadcast) and consecutive weights (conflict-free).  Truth slots (optional) follow the reference literally; a
+// per-tick bound on the slots' photons (light_truth_max_kernel) lets a pair (i, j) skip its slot walk when none can pass.
 #include "ldsim_dev.h"
 
 #define LR_THREADS 256
@@ -18,9 +19,14 @@ template <bool RESPONSE>
 __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     const float* __restrict__ inc, const int64_t* __restrict__ tid, const double* __restrict__ tph, int D, int T, int Mt,
     const double* __restrict__ weights /* [C+1] */, int C, const double* __restrict__ gain /* [D] or NULL */,
-    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid, double* __restrict__ out_tph) {
+    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid, double* __restrict__ out_tph,
+    const double* __restrict__ truth_max /* [D][T]: light_truth_max_kernel, or NULL when Mt == 0 */) {
   __shared__ float s_x[JCHUNK];
   __shared__ double s_w[JCHUNK + LR_THREADS];
+  // largest photon count (RESPONSE: magnitude) among the filled truth slots of input tick j, -1 when it has none: a pair
+  // (i, j) whose weight times this stays below the threshold cannot pass the per-slot test (rounding is monotone), so its
+  // walk over the <= Mt slots -- Mt global reads per pair -- is skipped as a whole
+  __shared__ double s_tmax[JCHUNK];
   const int d = blockIdx.y;
   const int i0 = blockIdx.x * LR_THREADS;
   const int i = i0 + threadIdx.x;
@@ -37,7 +43,10 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     // weights this chunk can meet: n = i - j in [i0 - (jc + nj - 1), i_last - jc]
     const int n_lo = max(i0 - (jc + nj - 1), 0), n_hi = min(i_last - jc, C);
     __syncthreads();
-    for (int k = threadIdx.x; k < nj; k += LR_THREADS) s_x[k] = x[jc + k];
+    for (int k = threadIdx.x; k < nj; k += LR_THREADS) {
+      s_x[k] = x[jc + k];
+      if (Mt > 0) s_tmax[k] = truth_max[(int64_t)d * T + jc + k];
+    }
     for (int k = threadIdx.x; k <= n_hi - n_lo; k += LR_THREADS) s_w[k] = weights[n_lo + k];
     __syncthreads();
     if (!live) continue;
@@ -48,7 +57,8 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
       const double w = s_w[(i - j) - n_lo];
       if (RESPONSE) acc = (float)((double)acc + g * w * (double)xv);            // :320  LIGHT_GAIN[idet] * tick_weight * x
       else acc = (float)((double)acc + w * (double)xv);                         // :169
-      if (Mt > 0) {
+      if (Mt > 0 && s_tmax[j - jc] >= 0.0 &&
+          !(RESPONSE ? (fabs(w) * s_tmax[j - jc] < truth_threshold) : (w >= 0.0 && w * s_tmax[j - jc] < truth_threshold))) {
         const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
         for (int a = 0; a < Mt; a++) {
           if (tid[src + a] == -1) break;
@@ -79,18 +89,46 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   if (live) out[(int64_t)d * T + i] = acc;
 }
 
+// truth_max[d][j] = max over the filled slots a of tph[d][j][a] (RESPONSE: |tph|), -1 when slot 0 is empty
+__global__ void light_truth_max_kernel(const int64_t* __restrict__ tid, const double* __restrict__ tph, int64_t n, int Mt,
+                                       int response, double* __restrict__ truth_max) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double m = -1.0;
+  bool any = false;
+  for (int a = 0; a < Mt; a++) {
+    if (tid[e * Mt + a] == -1) break;
+    const double ph = response ? fabs(tph[e * Mt + a]) : tph[e * Mt + a];
+    m = any ? fmax(m, ph) : ph;
+    any = true;
+  }
+  // (scintillation mode compares signed products: a tick whose largest entry is negative still has filled slots; 0 keeps
+  // it in play -- the per-slot test decides)
+  truth_max[e] = any ? (response ? m : fmax(m, 0.0)) : -1.0;
+}
+
 extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid,
                                        const double* tph, int D, int T, int Mt, const double* weights, int C,
                                        const double* gain, float* out, int64_t* out_tid, double* out_tph) {
   if (D <= 0 || T <= 0) return 0;
   dim3 grid((unsigned)((T + LR_THREADS - 1) / LR_THREADS), (unsigned)D), block(LR_THREADS);
   const double thr = ctx->h_consts.mc_truth_threshold;
+  double* tmax = nullptr;
+  if (Mt > 0) {
+    const int64_t n = (int64_t)D * T;
+    int rc = ldsim_ensure_buf(ctx, &ctx->light_tmax, (size_t)n * 8);
+    if (rc) return rc;
+    tmax = (double*)ctx->light_tmax.p;
+    hipLaunchKernelGGL(light_truth_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tid, tph, n, Mt,
+                       response ? 1 : 0, tmax);
+    HIPCHK(hipGetLastError());
+  }
   if (response)
     hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain, thr,
-                       out, out_tid, out_tph);
+                       out, out_tid, out_tph, tmax);
   else
     hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain,
-                       thr, out, out_tid, out_tph);
+                       thr, out, out_tid, out_tph, tmax);
   HIPCHK(hipGetLastError());
   return 0;
 }
