@@ -37,6 +37,23 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   float acc = live ? out[(int64_t)d * T + i] : 0.f;
   const double g = RESPONSE ? gain[d] : 1.0;
   const int my_j0 = max(i - C, 0);
+  // RESPONSE: the reference's slot search compares ids of the INPUT row at the OUTPUT tick (light_sim.py:331-335), which
+  // does not change while this thread works: with f = index of that row's first -1 (Mt if none) and distinct ids in front
+  // of it, "first b with tid[dst+b] == tid[dst+a] or -1" is a itself for a < f and f otherwise -- no search.  Rows with a
+  // repeated id keep the literal search.
+  int row_f = Mt;
+  bool row_unique = false;
+  if (RESPONSE && Mt > 0 && live) {
+    const int64_t dst = ((int64_t)d * T + i) * Mt;
+    for (int b = 0; b < Mt; b++)
+      if (tid[dst + b] == -1) { row_f = b; break; }
+    row_unique = true;
+    for (int b = 1; b < row_f && row_unique; b++) {
+      const int64_t idb = tid[dst + b];
+      for (int e = 0; e < b; e++)
+        if (tid[dst + e] == idb) { row_unique = false; break; }
+    }
+  }
 
   for (int jc = j_begin; jc <= i_last; jc += JCHUNK) {
     const int nj = min(JCHUNK, i_last - jc + 1);
@@ -64,6 +81,14 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
           if (tid[src + a] == -1) break;
           const double ph = tph[src + a];
           if (RESPONSE ? (fabs(w * ph) < truth_threshold) : (w * ph < truth_threshold)) continue;
+          if (RESPONSE && row_unique) {
+            const int b = a < row_f ? a : row_f;
+            if (b < Mt) {
+              out_tid[dst + b] = tid[dst + a];
+              out_tph[dst + b] += w * ph;
+            }
+            continue;
+          }
           for (int b = 0; b < Mt; b++) {
             if (RESPONSE) {
               // :331-335 literally: the slot test reads the INPUT ids at [idet, itick], not the output's
