@@ -41,6 +41,32 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   // does not change while this thread works: with f = index of that row's first -1 (Mt if none) and distinct ids in front
   // of it, "first b with tid[dst+b] == tid[dst+a] or -1" is a itself for a < f and f otherwise -- no search.  Rows with a
   // repeated id keep the literal search.
+  // Scintillation stage: the output row fills from the front (a term takes the first slot that holds its id or is empty).
+  // The thread keeps the number of filled slots and a 256-bit signature of the ids stored: an id whose bit is clear is not
+  // in the row, so it goes straight to slot `filled` (or nowhere when the row is full) without the search; only ids whose
+  // bit is set search.  A row that arrives with a hole in front of a filled slot keeps the literal search.
+  int filled = 0;
+  bool prefix_ok = false;
+  unsigned long long sig0 = 0, sig1 = 0, sig2 = 0, sig3 = 0;
+  auto sig_bit = [](int64_t id, unsigned long long& word_sel) {
+    unsigned long long h = (unsigned long long)id * 0x9E3779B97F4A7C15ull;
+    word_sel = (h >> 62);
+    return 1ull << ((h >> 56) & 63ull);
+  };
+  if (!RESPONSE && Mt > 0 && live) {
+    const int64_t dst = ((int64_t)d * T + i) * Mt;
+    prefix_ok = true;
+    bool seen_empty = false;
+    for (int b = 0; b < Mt; b++) {
+      const int64_t id = out_tid[dst + b];
+      if (id == -1) { seen_empty = true; continue; }
+      if (seen_empty) { prefix_ok = false; break; }
+      filled = b + 1;
+      unsigned long long ws;
+      const unsigned long long bit = sig_bit(id, ws);
+      if (ws == 0) sig0 |= bit; else if (ws == 1) sig1 |= bit; else if (ws == 2) sig2 |= bit; else sig3 |= bit;
+    }
+  }
   int row_f = Mt;
   bool row_unique = false;
   if (RESPONSE && Mt > 0 && live) {
@@ -86,6 +112,34 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
             if (b < Mt) {
               out_tid[dst + b] = tid[dst + a];
               out_tph[dst + b] += w * ph;
+            }
+            continue;
+          }
+          if (!RESPONSE && prefix_ok) {
+            const int64_t id = tid[src + a];
+            unsigned long long ws;
+            const unsigned long long bit = sig_bit(id, ws);
+            const unsigned long long word = ws == 0 ? sig0 : (ws == 1 ? sig1 : (ws == 2 ? sig2 : sig3));
+            if (id != -1 && !(word & bit)) {             // certainly not stored yet
+              if (filled < Mt) {
+                out_tid[dst + filled] = id;
+                out_tph[dst + filled] += w * ph;
+                filled++;
+                if (ws == 0) sig0 |= bit; else if (ws == 1) sig1 |= bit; else if (ws == 2) sig2 |= bit; else sig3 |= bit;
+              }
+              continue;
+            }
+            for (int b = 0; b < Mt; b++) {              // maybe stored: the literal search (an insert extends the prefix)
+              const int64_t cur = out_tid[dst + b];
+              if (cur == id || cur == -1) {
+                out_tid[dst + b] = id;
+                out_tph[dst + b] += w * ph;
+                if (cur == -1 && id != -1) {
+                  filled = b + 1;
+                  if (ws == 0) sig0 |= bit; else if (ws == 1) sig1 |= bit; else if (ws == 2) sig2 |= bit; else sig3 |= bit;
+                }
+                break;
+              }
             }
             continue;
           }
