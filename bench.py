@@ -326,6 +326,25 @@ def main():
                                       "frac_useful": (tflops / FP64_VALU_PEAK_TFLOPS * acc["dfma_useful"] / acc["dfma"])
                                       if acc["dfma"] else None}},
         }
+        # The dominant kernel is an f64 correlation that never comes near the HBM roof ("bound by FP64 VALU ...
+        # report both"): when it dominates, the top-level roofline is the compute one -- ALGORITHMIC flops (2 x the FMAs that
+        # are neither block nor tile padding, LdsimChainStats.n_dfma_useful) over the kernel's time against the dense f64 peak
+        # (78.6 TFLOP/s, the same for v_fma_f64 and v_mfma_f64 on this part) -- with the issued-FMA figure and the HBM view beside it.
+        if split and dom_name == mac_name and acc["dfma"] > 0 and mac_s > 0:
+            hbm_view = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}
+            hbm_view["note"] = "SURVEY 8d algorithmic bytes (184 B per segment + 484 B per unique pixel) over the kernel's time: tiny by construction"
+            useful = acc["dfma_useful"] if acc["dfma_useful"] > 0 else acc["dfma"]
+            tf_alg = 2.0 * useful / mac_s / 1e12
+            out["roofline"].update({
+                "bound": "mfma", "achieved": tf_alg, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf_alg / FP64_VALU_PEAK_TFLOPS,
+                "algorithmic_flops_per_launch": 2.0 * useful / nl,
+                "issued": {"achieved": tflops, "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                           "note": "every lane of every v_fma_f64 the kernel issues, padding of 8-shift blocks and of the 512-tick "
+                                   "tile included; the VALU pipe is busy all the time at this figure (profiles/r02_sq_counters_final_20k.txt)"},
+                "hbm": hbm_view,
+                "note": "f64-VALU-bound kernel (no MFMA in it: the f64 matrix and vector pipes have the same peak here and are not "
+                        "additive); `traffic` = HBM bytes of this kernel per launch from the PMC passes"})
         if light_on and acc["inc_n"]:
             n_op = int(consts.light.N_OP_CHANNEL)
             inc_ms = acc["inc_ms"] / acc["inc_n"]
