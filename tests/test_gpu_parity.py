@@ -1579,6 +1579,8 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
             if name == "default":
                 assert st.n_fallback < 0.01 * st.n_pairs
                 assert 6 <= st.n_samples / st.n_pairs < 64       # n_samples counts quadrature nodes in this mode
+                # of the issued FMA lanes, the ones that are neither block padding nor outside the pair's window
+                assert 0.2 * st.n_dfma < st.n_dfma_useful <= st.n_dfma
             if name == "cap12":
                 assert st.n_fallback > 0.3 * st.n_pairs
     finally:
