@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 5
+#define LDSIM_ABI_VERSION 6
 
 /* error codes */
 #define LDSIM_OK 0
@@ -192,7 +192,11 @@ int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimT
 int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                          double* track_starts, int64_t* time_max);
 /* detsim.tracks_current[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response)
- *                                                     -- larndsim/detsim.py:351-453 */
+ *                                                     -- larndsim/detsim.py:351-453
+ * Runs the kernels the options select, exactly like ldsim_charge_chain does for its sorted pair list ("split_kernels",
+ * "weights_mode", "mac_mode": by default the quadrature weights stage + the shifted-window correlation, pairs beyond their
+ * capacities recomputed by the monolithic closed-form kernel), on the dense [S][P] pixel array; pixel id -1 is evaluated
+ * as the reference evaluates it (Python index wrap). */
 int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                          const int32_t* pixels, int32_t max_neigh, float* signals, int32_t n_ticks);
 /* detsim.tracks_current_mc[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response, rng_states) -- larndsim/detsim.py:258-348,
@@ -329,6 +333,11 @@ typedef struct {
                               nor ticks outside the pair's window: sum over pairs of (weights kept) x (window ticks); 0 when
                               another weights stage ran */
 } LdsimChainStats;
+
+/* counters of the last ldsim_tracks_current call (n_segments, n_pairs = S * P, n_fallback, n_wbuf, n_samples, n_dfma,
+ * n_dfma_useful, n_ambiguous; the rest 0): which kernels carried the pairs -- n_wbuf > 0 means the split path's weights
+ * stage ran, n_fallback counts the pairs the monolithic kernel recomputed */
+int ldsim_tracks_current_stats(ldsim_ctx* ctx, LdsimChainStats* stats);
 
 /* Fused a5-a16 (max_pixels .. digitize) on resident segments [seg_begin, seg_end):
  * per unique (batch, pixel), sorted by batch then pixel id exactly like the reference's concatenated

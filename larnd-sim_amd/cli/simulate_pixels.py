@@ -13,7 +13,10 @@ light_dat, light_trig, light_wvfm, light_wvfm_mc_assn and the truth datasets of 
 Module-to-module variation (--mod2mod_variation or a keyword with MOD2MOD_VARIATION, e.g. `2x2`): the driver's module loop --
 per-module constants, pixel layout, response, light LUT, thresholds and gains; per-module light datasets merged at the end.
 
-Not built (a flag that only concerns them is accepted and reported): bad-channel lists by id, memory logging.
+The per-module pointer lists (--pixel_layout_id, --response_id, --light_lut_id, --pixel_thresholds_id, --pixel_gains_id: module m
+uses file ids[m] of the corresponding file list) default to the keyword's <X>_ID entries.
+
+Not built (the flag is accepted and reported): memory logging (--save_memory).
 """
 import argparse
 import os
@@ -33,8 +36,8 @@ from larndsim_amd import config as cfgmod  # noqa: E402
 from larndsim_amd.chain import ChargeChain  # noqa: E402
 
 SEED = int(time())
-IGNORED = ("pixel_thresholds_id", "pixel_gains_id", "save_memory", "pixel_layout_id",
-           "response_id", "light_lut_id")
+IGNORED = ("save_memory",)
+ID_FLAGS = ("pixel_layout_id", "response_id", "light_lut_id", "pixel_thresholds_id", "pixel_gains_id")
 TRUTH_DATASETS = ("trajectories", "vertices", "mc_hdr", "mc_stack")
 
 
@@ -119,15 +122,10 @@ class _Output:
         along the channel axis as `light_wvfm`."""
         names = [f"light_wvfm/light_wvfm_mod{i}" for i in module_indices]
         if self.h5py is not None:
-            with self.h5py.File(self.filename, "a") as f:
-                if not all(n in f for n in names):
-                    return
-                parts = [np.array(f[n]) for n in names]
-                if len({p.shape[0] for p in parts}) != 1:
-                    raise ValueError("The number of triggers should be the same in each module with light trigger mode 1 "
-                                     "(light waveform).")
-                del f["light_wvfm"]
-                f.create_dataset("light_wvfm", data=np.concatenate(parts, axis=1), maxshape=(None, None, None))
+            with self.h5py.File(self.filename, "r") as f:
+                present = all(n in f for n in names)
+            if present:
+                light_sim.merge_module_light_wvfm_same_trigger(self.filename, [i + 1 for i in module_indices])
             return
         if not all(n in self.parts for n in names):
             return
@@ -197,7 +195,9 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
                    light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None,
                    pixel_thresholds_file=None, pixel_gains_file=None, rand_seed=None, config_root=None,
-                   tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, overlap_downloads=None, **ignored):
+                   tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, overlap_downloads=None,
+                   pixel_layout_id=None, response_id=None, light_lut_id=None, pixel_thresholds_id=None, pixel_gains_id=None,
+                   **ignored):
     if not os.path.exists(input_filename):
         raise Exception(f"Input file {input_filename} does not exist.")
     if os.path.exists(output_filename):
@@ -226,6 +226,14 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
         n_modules = len(snapshot) if isinstance(snapshot, list) else 1
     if response_file is None and snapshot is None:
         response_file = cfg.get("RESPONSE")
+    if pixel_thresholds_file is None and cfg.get("PIXEL_THRESHOLDS_FILE"):   # :280-285
+        pixel_thresholds_file = _as_list(cfg["PIXEL_THRESHOLDS_FILE"])
+        if pixel_thresholds_id is None:
+            pixel_thresholds_id = cfg.get("PIXEL_THRESHOLDS_ID")
+    if pixel_gains_file is None and cfg.get("PIXEL_GAINS_FILE"):             # :286-291
+        pixel_gains_file = _as_list(cfg["PIXEL_GAINS_FILE"])
+        if pixel_gains_id is None:
+            pixel_gains_id = cfg.get("PIXEL_GAINS_ID")
     if light_simulated is None:
         light_simulated = bool(cfg.get("LIGHT_SIMULATED", True))
     if light_simulated and light_lut_filename is None:
@@ -233,12 +241,20 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     m2m = cfgmod.module_variation_active(cfg, n_modules, mod2mod_variation,
                                          snapshot if snapshot is not None else pixel_layout, response_file, light_lut_filename)
     if m2m:                                                         # one entry per module (:374-384)
+        # The reference reads the *_id flags (:272-290) and then looks the pointer lists up in the keyword's entry only
+        # (load_mod2mod_variation_properties(cfg, ..), :106-122), so a list given on its command line never takes effect.
+        # Here a given list is the pointer list -- what the flag is documented to be (:147-160) --, the keyword's otherwise.
+        ids = {k: cfgmod.id_list(v) for k, v in (("PIXEL_LAYOUT_ID", pixel_layout_id), ("RESPONSE_ID", response_id),
+                                                   ("LIGHT_LUT_ID", light_lut_id), ("PIXEL_THRESHOLD_ID", pixel_thresholds_id),
+                                                   ("PIXEL_GAIN_ID", pixel_gains_id))}
         if snapshot is None:
-            pixel_layout = cfgmod.module_files(cfg, pixel_layout, "PIXEL_LAYOUT_ID", n_modules, "pixel layout")
-        response_file = cfgmod.module_files(cfg, response_file, "RESPONSE_ID", n_modules, "response files")
-        pixel_thresholds_file = cfgmod.module_files(cfg, pixel_thresholds_file, "PIXEL_THRESHOLD_ID", n_modules, "pixel threshold files")
-        pixel_gains_file = cfgmod.module_files(cfg, pixel_gains_file, "PIXEL_GAIN_ID", n_modules, "pixel gain files")
-        light_lut_filename = cfgmod.module_files(cfg, light_lut_filename, "LIGHT_LUT_ID", n_modules, "light LUT")
+            pixel_layout = cfgmod.module_files(cfg, pixel_layout, "PIXEL_LAYOUT_ID", n_modules, "pixel layout", ids["PIXEL_LAYOUT_ID"])
+        response_file = cfgmod.module_files(cfg, response_file, "RESPONSE_ID", n_modules, "response files", ids["RESPONSE_ID"])
+        pixel_thresholds_file = cfgmod.module_files(cfg, pixel_thresholds_file, "PIXEL_THRESHOLD_ID", n_modules,
+                                                    "pixel threshold files", ids["PIXEL_THRESHOLD_ID"])
+        pixel_gains_file = cfgmod.module_files(cfg, pixel_gains_file, "PIXEL_GAIN_ID", n_modules, "pixel gain files",
+                                               ids["PIXEL_GAIN_ID"])
+        light_lut_filename = cfgmod.module_files(cfg, light_lut_filename, "LIGHT_LUT_ID", n_modules, "light LUT", ids["LIGHT_LUT_ID"])
     else:
         if isinstance(snapshot, list):
             snapshot = snapshot[0]
@@ -382,7 +398,11 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         chain.upload(tracks, bid)
         chain.quench_drift(consts.physics.BIRKS)
         chain.download_segments(tracks)
-    res["tracks"] = tracks
+    # the batch-sorted copy is the device's; the file gets the module's segments in input order, like the reference's
+    # `segments_to_files = tracks` (cli/simulate_pixels.py:1230-1234), with light_dat rows aligned to it (:759-760)
+    file_rows = np.empty_like(tracks)
+    file_rows[order] = tracks
+    res["tracks"] = file_rows
     edges = np.flatnonzero(np.r_[True, bid[1:nsim] != bid[:nsim - 1], True]) if nsim else np.array([0])
     n_groups = int(np.ceil(np.asarray(det_borders).shape[0] / sim.EVENT_BATCH_SIZE))
     batch_of = {}
@@ -468,7 +488,9 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         if len(tracks):
             inc, _ = chain.download_light_incidence(0, len(tracks))
             inc["segment_id"] = tracks["segment_id"][:, None]
-            res["light_dat"] = inc
+            inc_file = np.empty_like(inc)
+            inc_file[order] = inc
+            res["light_dat"] = inc_file
         if raw_arrays and light_rows:
             nt_max = max(r.shape[1] for r in light_rows)           # the tick count follows each batch's arrival times
             out.put("light_sample_inc" + (f"_mod{i_mod - 1}" if m2m else ""),
@@ -582,6 +604,9 @@ def main(argv=None):
     for k in ("pixel_layout", "detector_properties", "simulation_properties", "response_file", "light_lut_filename",
               "light_det_noise_filename", "bad_channels", "pixel_thresholds_file", "pixel_gains_file", *IGNORED):
         ap.add_argument("--" + k, default=None)
+    for k in ID_FLAGS:
+        ap.add_argument("--" + k, default=None, help="module variation: per-module index into the corresponding file list, "
+                                                      "e.g. 0,0,1,0 (default: the keyword's entry)")
     ap.add_argument("--n_events", type=int, default=None)
     ap.add_argument("--rand_seed", type=int, default=None)
     ap.add_argument("--tracks_current_mc", action="store_true",

@@ -49,7 +49,70 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
   a.split_max_items = ctx->split_max_items;
 }
 
-// materialising tracks_current: dense [S][P] pixel array, signals [S][P][T]
+// a9-a12 for the pairs of `a` (sorted pair list of the chain, or the dense [S][P] grid of the stage call) by the configured
+// kernels: tracks_current_mc, the split path (weights stage + correlation, overflowed pairs recomputed by the monolithic
+// kernel) or the monolithic kernel for everything.  counters = the 16 u64 of the misc block, zeroed by the caller.
+static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigned long long* counters, bool* split_timed) {
+  hipStream_t st = ctx->stream;
+  const int64_t n_valid = a.n_pairs;
+  *split_timed = false;
+  size_t ib = 0, hb = 0, cb = 0;
+  if (ctx->mc_current) return current_mc_launch(ctx, a, n_seg);   // the driver's call site (cli/simulate_pixels.py:1016)
+  if (!(ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0)) return current_launch(ctx, a);
+  CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
+  CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));
+  CK(ldsim_ensure(ctx, SB_CORR, (size_t)n_valid * cb));
+  // The weights go to one pool shared by all pairs of the launch (bump allocator, counters[7] = doubles requested).
+  // Which pairs lose when it runs dry depends on scheduling order, and a pair recomputed by the monolithic kernel
+  // agrees only to rounding -- so a launch that exhausted the pool is never used: the pool is grown to the demand
+  // (a lower bound then: an exhausted pair stops requesting) and weights_kernel runs again.  The size per pair is
+  // remembered, so this happens on the first launches of a new detector configuration only.
+  double per_pair = fmax((double)ctx->wbuf_doubles_per_pair, ctx->wbuf_learned);
+  unsigned long long wcap = 0, demand = 0;
+  bool fits = false;
+  for (int attempt = 0; attempt < 6 && !fits; attempt++) {
+    wcap = (unsigned long long)ceil(per_pair * (double)n_valid);
+    CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
+    if (attempt > 0) {
+      HIPCHK(hipMemsetAsync(&counters[0], 0, 16, st));   // ambiguous shifts, samples
+      HIPCHK(hipMemsetAsync(&counters[5], 0, 32, st));   // dfma, overflowed pairs, pool cursor, useful FMAs
+    }
+    int rc = split_launch_weights(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
+                                  (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
+    if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
+    if (rc < 0) return rc;
+    HIPCHK(hipMemcpyAsync(&demand, &counters[7], 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    fits = demand <= wcap;
+    if (!fits) per_pair = 1.5 * (double)(demand > wcap ? demand : wcap) / (double)n_valid;
+  }
+  ctx->wbuf_learned = fmax(ctx->wbuf_learned, 1.25 * (double)demand / (double)n_valid);
+  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  int rc = split_launch_mac(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
+                            (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
+  if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
+  if (rc < 0) return rc;
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  *split_timed = true;
+  // pairs beyond the per-pair item / correction / run capacities (and, after 6 attempts, a pool that still does not
+  // fit): recomputed by the monolithic kernel
+  a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
+  a.flag_stride = (int32_t)(hb / 4);
+  return current_launch(ctx, a);
+}
+
+static void stats_from_counters(LdsimChainStats& s, const unsigned long long* h_cnt) {
+  s.n_ambiguous = (int32_t)h_cnt[0];
+  s.n_samples = (int64_t)h_cnt[1];
+  s.n_dfma = (int64_t)h_cnt[5];
+  s.n_fallback = (int64_t)h_cnt[6];
+  s.n_wbuf = (int64_t)h_cnt[7];
+  s.n_dfma_useful = (int64_t)h_cnt[8];
+}
+
+// materialising tracks_current: dense [S][P] pixel array, signals [S][P][T].  Runs the kernels the options select, like the
+// chain: the per-tick parity tests reach the default (split) kernels through this call; ldsim_tracks_current_stats tells
+// which kernels carried the pairs.
 int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc) {
   CK(ldsim_ensure(ctx, SB_MISC, 4096));
   unsigned long long* counters = (unsigned long long*)((char*)ctx->scratch[SB_MISC].p + 256);
@@ -66,7 +129,25 @@ int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* 
   a.tmax_batch = nullptr;
   a.batch0 = 0;
   a.counters = counters;
-  return mc ? current_mc_launch(ctx, a, ctx->seg.n) : current_launch(ctx, a);
+  a.only_flagged = nullptr;
+  a.flag_stride = 0;
+  ctx->stage_stats = LdsimChainStats{};
+  ctx->stage_stats.n_segments = ctx->seg.n;
+  ctx->stage_stats.n_pairs = a.n_pairs;
+  ctx->stage_stats.max_neigh = P;
+  ctx->stage_stats.max_length = T;
+  if (mc) return current_mc_launch(ctx, a, ctx->seg.n);
+  bool split_timed = false;
+  const int keep_mc = ctx->mc_current;
+  ctx->mc_current = 0;                 // the stage call names its kernel itself
+  int rc = run_tracks_current(ctx, a, ctx->seg.n, counters, &split_timed);
+  ctx->mc_current = keep_mc;
+  if (rc) return rc;
+  unsigned long long h_cnt[9] = {0};
+  HIPCHK(hipMemcpyAsync(h_cnt, counters, 72, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  stats_from_counters(ctx->stage_stats, h_cnt);
+  return 0;
 }
 
 int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions) {
@@ -248,55 +329,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   a.only_flagged = nullptr;
   a.flag_stride = 0;
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  bool split_done = false, split_timed = false;
-  size_t ib = 0, hb = 0, cb = 0;
-  if (ctx->mc_current) {     // the driver's call site (cli/simulate_pixels.py:1016): Monte-Carlo currents, seeded table needed
-    CK(current_mc_launch(ctx, a, n));
-    split_done = true;
-  } else if (ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0) {
-    CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
-    CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));
-    CK(ldsim_ensure(ctx, SB_CORR, (size_t)n_valid * cb));
-    // The weights go to one pool shared by all pairs of the launch (bump allocator, counters[7] = doubles requested).
-    // Which pairs lose when it runs dry depends on scheduling order, and a pair recomputed by the monolithic kernel
-    // agrees only to rounding -- so a launch that exhausted the pool is never used: the pool is grown to the demand
-    // (a lower bound then: an exhausted pair stops requesting) and weights_kernel runs again.  The size per pair is
-    // remembered, so this happens on the first launches of a new detector configuration only.
-    double per_pair = fmax((double)ctx->wbuf_doubles_per_pair, ctx->wbuf_learned);
-    unsigned long long wcap = 0, demand = 0;
-    bool fits = false;
-    for (int attempt = 0; attempt < 6 && !fits; attempt++) {
-      wcap = (unsigned long long)ceil(per_pair * (double)n_valid);
-      CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
-      if (attempt > 0) {
-        HIPCHK(hipMemsetAsync(&counters[0], 0, 16, st));   // ambiguous shifts, samples
-        HIPCHK(hipMemsetAsync(&counters[5], 0, 32, st));   // dfma, overflowed pairs, pool cursor, useful FMAs
-      }
-      int rc = split_launch_weights(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
-                                    (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
-      if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
-      if (rc < 0) return rc;
-      HIPCHK(hipMemcpyAsync(&demand, &counters[7], 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      fits = demand <= wcap;
-      if (!fits) per_pair = 1.5 * (double)(demand > wcap ? demand : wcap) / (double)n_valid;
-    }
-    ctx->wbuf_learned = fmax(ctx->wbuf_learned, 1.25 * (double)demand / (double)n_valid);
-    HIPCHK(hipEventRecord(ctx->ev[5], st));
-    int rc = split_launch_mac(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
-                              (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
-    if (rc > 0) { ldsim_set_error("split path refused a configuration split_sizes accepted"); return LDSIM_ESTATE; }
-    if (rc < 0) return rc;
-    HIPCHK(hipEventRecord(ctx->ev[6], st));
-    split_timed = true;
-    // pairs beyond the per-pair item / correction / run capacities (and, after 6 attempts, a pool that still does not
-    // fit): recomputed by the monolithic kernel
-    a.only_flagged = (const int32_t*)ctx->scratch[SB_HDR].p;
-    a.flag_stride = (int32_t)(hb / 4);
-    CK(current_launch(ctx, a));
-    split_done = true;
-  }
-  if (!split_done) CK(current_launch(ctx, a));
+  bool split_timed = false;
+  CK(run_tracks_current(ctx, a, n, counters, &split_timed));
   HIPCHK(hipEventRecord(ctx->ev[2], st));
 
   // ---- a13-a16 per-pixel sum, trigger scan, digitise ---------------------------------------------------------------------------------
@@ -354,13 +388,8 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipStreamSynchronize(st));
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
-  ctx->stats.n_ambiguous = (int32_t)h_cnt[0];
-  ctx->stats.n_dfma = (int64_t)h_cnt[5];
+  stats_from_counters(ctx->stats, h_cnt);
   ctx->n_fallback = (int64_t)h_cnt[6];
-  ctx->stats.n_fallback = (int64_t)h_cnt[6];
-  ctx->stats.n_samples = (int64_t)h_cnt[1];
-  ctx->stats.n_wbuf = (int64_t)h_cnt[7];
-  ctx->stats.n_dfma_useful = (int64_t)h_cnt[8];
   CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
   CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
                        (int32_t*)ctx->scratch[SB_HITS].p));

@@ -34,6 +34,19 @@ struct PairGeo {
 
 __device__ __forceinline__ double sgn(double x) { return x >= 0 ? 1.0 : -1.0; }
 
+// which (segment, pixel) a pair is: entry of the chain's sorted pair list, or cell [s][p] of the stage call's dense pixel array
+// (pixel id -1 included: the reference indexes with it, see pair_geometry)
+__device__ __forceinline__ void pair_ids(const CurArgs& A, int64_t pair, int64_t& seg, int64_t& pID) {
+  if (A.pair_val) {
+    const int32_t v = A.pair_val[pair];
+    seg = A.seg_begin + v / A.P;
+    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
+  } else {
+    seg = A.seg_begin + pair / A.P;
+    pID = A.pixels[pair];
+  }
+}
+
 // detsim.py:42-112
 // nf32: Numba types f32 (op) f32 as f32 -- with f4 record fields the spots below are single precision
 // (detsim.py:74-79; the oracle's F32SUB / F32MUL / F32DIV, oracle/ldsim_oracle.c:270-291)

@@ -25,14 +25,7 @@ __global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(
 
   // ---- which (segment, pixel) -------------------------------------------------------------------
   int64_t seg, pID;
-  if (A.pair_val) {
-    int32_t v = A.pair_val[pair];
-    seg = A.seg_begin + v / A.P;
-    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
-  } else {
-    seg = A.seg_begin + pair / A.P;
-    pID = A.pixels[pair];
-  }
+  pair_ids(A, pair, seg, pID);
   float* out = A.out + pair * (int64_t)A.T;
   int T = A.T;
   if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);

@@ -19,11 +19,7 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   PairParams P;
   memset(&P, 0, sizeof(P));
   int64_t seg, pID;
-  {
-    int32_t v = A.pair_val[pair];
-    seg = A.seg_begin + v / A.P;
-    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
-  }
+  pair_ids(A, pair, seg, pID);
   int T = A.T;
   if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
   PairGeo g;

@@ -27,11 +27,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
   int32_t* hdr = S.hdr + pair * HDR_INTS;
 
   int64_t seg, pID;
-  {
-    int32_t v = A.pair_val[pair];
-    seg = A.seg_begin + v / A.P;
-    pID = (int64_t)((A.pair_key[pair] >> 4) & 0xFFFFFFFFull);
-  }
+  pair_ids(A, pair, seg, pID);
   int T = A.T;
   if (A.tmax_batch) T = min(T, A.tmax_batch[A.s.batch[seg] - A.batch0]);
 

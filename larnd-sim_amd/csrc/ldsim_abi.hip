@@ -605,6 +605,12 @@ extern "C" int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t 
   return 0;
 }
 
+extern "C" int ldsim_tracks_current_stats(ldsim_ctx* ctx, LdsimChainStats* stats) {
+  NEED(ctx && stats, "null argument");
+  *stats = ctx->stage_stats;
+  return 0;
+}
+
 extern "C" int ldsim_tracks_current_mc(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                        const int32_t* pixels, int32_t P, float* signals, int32_t T) {
   NEED(pixels && signals && P >= 0 && T >= 0, "bad tracks_current_mc arguments");

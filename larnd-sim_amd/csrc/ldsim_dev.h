@@ -168,6 +168,7 @@ struct ldsim_ctx {
   int64_t hits_acc_rows = 0;
   // chain results
   LdsimChainStats stats{};
+  LdsimChainStats stage_stats{};   // counters of the last ldsim_tracks_current stage call (ldsim_tracks_current_stats)
   int64_t chain_U = 0, chain_hits = 0;
   int want_fractions = 0;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -9,8 +9,9 @@ Two sources:
 * without one, the built-in keywords whose constants ship as numbers-only snapshots (``snapshots/*.json``).
 
 A keyword whose entry has ``MOD2MOD_VARIATION: True`` (``2x2``, ``2x2_mpvmpr``, ``2x2_old_response``, ... in the reference's
-config.yaml) describes a detector with per-module pixel layouts / responses / LUTs; that mode is not built, and such a
-keyword is never mapped onto a single-configuration detector: ``check_single_configuration`` raises for it.
+config.yaml) describes a detector with per-module pixel layouts / responses / LUTs / thresholds / gains:
+``module_variation_active`` and ``module_files`` restate the reference's decision and its ``<X>_ID`` pointer lists, and the
+driver (cli/simulate_pixels.py) runs its module loop on them.
 """
 import os
 
@@ -92,13 +93,22 @@ def module_variation_active(cfg, n_modules, mod2mod_variation=None, pixel_layout
     return not (one(pixel_layout) and one(response_file) and one(light_lut))
 
 
-def module_files(cfg, files, id_name, n_modules, message=""):
-    """One file per module from a list of files and the keyword's ``<X>_ID`` pointer list
-    (``load_mod2mod_variation_properties``, cli/simulate_pixels.py:106-122): ``files[ids[m]]`` for module m; without a
+def id_list(value):
+    """A pointer list as the command line gives it ('0,0,1,0', '[0, 0, 1, 0]') or as a list -> list of int; None stays."""
+    if value is None:
+        return None
+    if isinstance(value, str):
+        value = [v for v in value.replace("[", " ").replace("]", " ").replace(",", " ").split()]
+    return [int(v) for v in value]
+
+
+def module_files(cfg, files, id_name, n_modules, message="", ids=None):
+    """One file per module from a list of files and a pointer list -- ``ids`` when given, else the keyword's ``<X>_ID``
+    entry (``load_mod2mod_variation_properties``, cli/simulate_pixels.py:106-122): ``files[ids[m]]`` for module m; without a
     usable pointer list the files must already be one per module."""
     if files is None:
         return None
-    ids = cfg.get(id_name)
+    ids = cfg.get(id_name) if ids is None else ids
     if ids is not None and isinstance(files, list) and len(ids) == n_modules and max(ids) < len(files):
         return [files[i] for i in ids]
     if isinstance(files, list) and len(files) != n_modules:

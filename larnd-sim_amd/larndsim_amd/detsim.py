@@ -42,6 +42,14 @@ def tracks_current(signals, pixels, tracks, response):
                                               C.c_int32(T)))
 
 
+def tracks_current_stats():
+    """Counters of the last ``tracks_current`` call (``LdsimChainStats``): ``n_wbuf`` > 0 = the split path's weights stage
+    ran, ``n_fallback`` = pairs the monolithic kernel recomputed."""
+    st = lib.LdsimChainStats()
+    lib.check(lib.load().ldsim_tracks_current_stats(lib.context(refresh_consts=False), C.byref(st)))
+    return st
+
+
 @kernel
 def tracks_current_mc(signals, pixels, tracks, response, rng_states):
     """``tracks_current_mc[bpg, tpb](signals, pixels, tracks, response, rng_states)`` -- the reference driver's call site

@@ -30,7 +30,7 @@ EXPORTS = [
     "ldsim_set_consts", "ldsim_set_response", "ldsim_set_light_channels", "ldsim_set_light_lut", "ldsim_set_option",
     "ldsim_set_pixel_thresholds", "ldsim_set_pixel_gains", "ldsim_clear_pixel_tables",
     "ldsim_synchronize", "ldsim_quench", "ldsim_drift", "ldsim_max_pixels", "ldsim_get_pixels",
-    "ldsim_time_intervals", "ldsim_tracks_current", "ldsim_tracks_current_mc", "ldsim_track_pixel_map", "ldsim_sum_pixel_signals",
+    "ldsim_time_intervals", "ldsim_tracks_current", "ldsim_tracks_current_stats", "ldsim_tracks_current_mc", "ldsim_track_pixel_map", "ldsim_sum_pixel_signals",
     "ldsim_get_adc_values", "ldsim_digitize", "ldsim_light_incidence", "ldsim_sum_light_signals",
     "ldsim_scintillation_effect", "ldsim_light_detector_response",
     "ldsim_segments_upload", "ldsim_segments_download", "ldsim_segments_reset", "ldsim_dev_quench_drift", "ldsim_charge_chain",

@@ -298,21 +298,43 @@ def export_light_trig_to_hdf5(event_id, start_times, trigger_idx, op_channel_idx
         _append(f, 'light_trig', trig, (None,))
 
 
+def wvfm_dataset_name(i_mod=-1):
+    """Where a call's waveforms go (light_sim.py:668-685): with module variation and the beam trigger every module fills its
+    own ``light_wvfm/light_wvfm_mod<i>`` (merged at the end of the file), otherwise ``light_wvfm``."""
+    if getattr(consts.sim, 'MOD2MOD_VARIATION', False) and consts.light.LIGHT_TRIG_MODE == 1:
+        if not i_mod > 0:
+            raise ValueError("Mod2mod variation is activated, but the module id is not provided correctly.")
+        return f'light_wvfm/light_wvfm_mod{i_mod - 1}'
+    return 'light_wvfm'
+
+
 def export_light_wvfm_to_hdf5(event_id, waveforms, output_filename, waveforms_true_track_id, waveforms_true_photons, i_trig,
                               i_mod=-1):
-    """Append to ``light_wvfm`` and, with ``MAX_MC_TRUTH_IDS > 0``, to ``light_wvfm_mc_assn`` (:647-693).  Module-to-module
-    variation (per-module ``light_wvfm_mod<i>`` datasets) is not built and refused."""
+    """Append to ``light_wvfm`` (per module: ``light_wvfm/light_wvfm_mod<i>``) and, with ``MAX_MC_TRUTH_IDS > 0``, to
+    ``light_wvfm_mc_assn`` (:647-693).  Needs h5py."""
     if np.asarray(event_id).shape[0] == 0:
         return
-    if getattr(consts.sim, 'MOD2MOD_VARIATION', False):
-        raise NotImplementedError("mod2mod variation is not built: per-module light_wvfm datasets are not written")
     import h5py
     with h5py.File(output_filename, 'a') as f:
-        _append(f, 'light_wvfm', np.asarray(waveforms), (None, None, None))
+        _append(f, wvfm_dataset_name(i_mod), np.asarray(waveforms), (None, None, None))
         if consts.sim.MAX_MC_TRUTH_IDS > 0:
             truth = zero_suppress_waveform_truth(waveforms_true_track_id, waveforms_true_photons, event_id[0], i_trig, i_mod)
             if truth.shape[0] > 0:
                 _append(f, 'light_wvfm_mc_assn', truth, (None,))
+
+
+def merge_module_light_wvfm_same_trigger(output_filename, module_ids=None):
+    """The per-module waveform datasets side by side along the channel axis as ``light_wvfm`` (:759-775); the group of
+    per-module datasets is replaced by the merged dataset.  Needs h5py."""
+    import h5py
+    module_ids = consts.detector.MOD_IDS if module_ids is None else module_ids
+    with h5py.File(output_filename, 'a') as f:
+        parts = [np.array(f[f'light_wvfm/light_wvfm_mod{i_mod - 1}']) for i_mod in module_ids]
+        if len({p.shape[0] for p in parts}) != 1:
+            raise ValueError("The number of triggers should be the same in each module with light trigger mode 1 "
+                             "(light waveform).")
+        del f['light_wvfm']
+        f.create_dataset('light_wvfm', data=np.concatenate(parts, axis=1), maxshape=(None, None, None))
 
 
 def export_to_hdf5(event_id, start_times, trigger_idx, op_channel_idx, waveforms, output_filename, event_times,

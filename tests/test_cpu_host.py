@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/ldsim.h but not exported"
     assert set(lib.EXPORTS) == declared
-    assert l.ldsim_abi_version() == abi.ABI_VERSION == 5
+    assert l.ldsim_abi_version() == abi.ABI_VERSION == 6
 
 
 def test_graft_entry_build_succeeds():
@@ -299,13 +299,32 @@ def _random_packet_inputs(rng, n_pix, n_ev, spill):
                 track_ids=seg_ids, traj_ids=traj_ids, event_start_times=t0)
 
 
+def test_packets_unequal_slot_widths_are_refused():
+    """track_ids / traj_ids / current_fractions whose slot count is not MAX_TRACKS_PER_PIXEL: the reference's np.array over
+    the per-packet lists is ragged (fee.py:271-276,297-300) and raises ValueError; so do build_packets and the loop checker."""
+    from larndsim_amd import packets
+    from packets_loop import build_packets_loop
+    H.load_cfg("module0", noise_zero=False)
+    rng = np.random.default_rng(5)
+    inp = _random_packet_inputs(rng, 60, 3, False)
+    w = 7
+    for bad in (dict(inp, traj_ids=inp["traj_ids"][:, :-1]),
+                dict(inp, track_ids=inp["track_ids"][:, :w], traj_ids=inp["traj_ids"][:, :w],
+                     current_fractions=np.ascontiguousarray(inp["current_fractions"][:, :, :w]))):
+        with pytest.raises(ValueError):
+            packets.build_packets(**bad)
+        with pytest.raises(ValueError):
+            build_packets_loop(**bad)
+
+
 @pytest.mark.parametrize("cfg,spill", [("module0", False), ("module0", True), ("2x2_no_modvar", True)])
 def test_packets_array_form_equals_the_hit_loop(cfg, spill):
-    """packets.build_packets (array operations; what the driver calls) against packets.build_packets_loop (the reference's
+    """packets.build_packets (array operations; what the driver calls) against tests/packets_loop.py (the reference's
     loop restated hit by hit, pinned by the goldens): the same bytes, on the golden inputs and on random ones that walk every
     branch -- clock rollovers (events up to 4 s apart), pixels without a chip, a disabled channel, light triggers, module
     selection, trajectory sums of 9 and more terms."""
     from larndsim_amd import packets
+    from packets_loop import build_packets_loop
     H.load_cfg(cfg, noise_zero=False)
     g = H.gold(f"packets_{cfg}.npz")
     n_ev = len(g["event_times"])
@@ -313,7 +332,7 @@ def test_packets_array_form_equals_the_hit_loop(cfg, spill):
     args = (g["event_id_list"], g["adc"], g["ticks"], g["unique_pix"], g["fractions"], g["segment_ids"], g["traj_ids"], g["event_times"])
     kw = dict(light_trigger_times=g["trig_times"], light_trigger_event_id=np.arange(n_ev), light_trigger_modules=np.ones(n_ev),
               bad_channels=bad)
-    a, b = packets.build_packets(*args, **kw), packets.build_packets_loop(*args, **kw)
+    a, b = packets.build_packets(*args, **kw), build_packets_loop(*args, **kw)
     assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and len(a[0]) > 40
     rng = np.random.default_rng(77)
     n_big = 0
@@ -330,7 +349,7 @@ def test_packets_array_form_equals_the_hit_loop(cfg, spill):
             first = a[0][a[0]["packet_type"] == 0][0]
             kw["bad_channels"] = {"%i-%i-%i" % (first["io_group"], first["io_channel"], first["chip_id"]): [int(first["channel_id"])]}
             a = packets.build_packets(**inp, **kw)
-        b = packets.build_packets_loop(**inp, **kw)
+        b = build_packets_loop(**inp, **kw)
         assert len(a[0]) == len(b[0]) > 300, trial
         for name in a[0].dtype.names:
             assert np.array_equal(a[0][name], b[0][name]), (trial, name)

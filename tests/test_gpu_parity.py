@@ -138,26 +138,49 @@ def test_pixels_time_intervals_golden(cfg):
     assert tmax[0] == int(g["max_length"])
 
 
+# The kernels that can carry tracks_current, by option set: the monolithic closed-form kernel (overflow fallback of the others),
+# the round-1 split path (closed form per sample + LDS-staged correlation) and the default (quadrature weights + shifted-window
+# correlation).  Every per-tick test runs through all of them; ldsim_tracks_current_stats tells which kernels really ran.
+CURRENT_PATHS = {"mono": dict(split_kernels=0),
+                 "closed": dict(split_kernels=1, weights_mode=0, mac_mode=0),
+                 "quad": dict(split_kernels=1, weights_mode=1, mac_mode=1)}
+
+
+def _tracks_current_on(path, neigh, r, resp, T, **extra):
+    """signals[S][P][T] of the HIP tracks_current on the named kernels + the call's counters."""
+    lib.context()
+    sig = np.zeros(neigh.shape + (T,), dtype=np.float32)
+    try:
+        for k, v in {**CURRENT_PATHS[path], **extra}.items():
+            lib.set_option(k, v)
+        detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, np.ascontiguousarray(neigh), r, resp)
+        st = detsim.tracks_current_stats()
+    finally:
+        _reset_current_options()
+    assert st.n_pairs == neigh.size
+    if path == "mono":
+        assert st.n_wbuf == 0 and st.n_fallback == 0
+    else:
+        assert st.n_wbuf > 0, "the split path's weights stage did not run"
+    return sig, st
+
+
 @pytest.mark.parametrize("cfg,tag", [(c, "") for c in CFGS] + [
     (c, "corners_") for c in ("module0", "ndlar")
     if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", f"sampled_corners_{c}.npz"))])
 @pytest.mark.parametrize("prune", [23.0, 0.0])
-def test_tracks_current_sampled_golden(cfg, tag, prune):
-    """The HIP tracks_current against the reference's own output at sampled ticks; `corners_` = degenerate geometries
-    (face-hugging, micrometre-short, along / perpendicular to the drift axis, heavily ionising)."""
+@pytest.mark.parametrize("path", list(CURRENT_PATHS))
+def test_tracks_current_sampled_golden(cfg, tag, prune, path):
+    """The HIP tracks_current against the reference's own output at sampled ticks, on each kernel set (module0 / 2x2:
+    TIME_SAMPLING = RESPONSE_SAMPLING, ndlar: twice); `corners_` = degenerate geometries (face-hugging, micrometre-short,
+    along / perpendicular to the drift axis, heavily ionising)."""
     H.load_cfg(cfg)
     g = H.gold(f"sampled_{tag}{cfg}.npz")
     r = H.quench_drift(O, g["segments_in"])
     neigh = np.ascontiguousarray(g["neigh"])
     T = int(g["max_length"])
     resp = H.response_for(g["response_kind"])
-    lib.context()
-    lib.set_option("prune_log", prune)
-    try:
-        sig = np.zeros(neigh.shape + (T,), dtype=np.float32)
-        detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
-    finally:
-        lib.set_option("prune_log", 23.0)
+    sig, st = _tracks_current_on(path, neigh, r, resp, T, prune_log=prune)
     # tolerance is relative to the peak of the FULL waveform, not of the sampled ticks
     peak = np.abs(sig).max(axis=-1, keepdims=True)
     got, ref = sig[:, :, g["ticks"]].astype(np.float64), g["signals"].astype(np.float64)
@@ -165,9 +188,16 @@ def test_tracks_current_sampled_golden(cfg, tag, prune):
     tol = 1e-5 * np.abs(ref) + 1e-7 * peak
     assert (err <= tol).all(), f"max excess {np.max(err - tol)} at {np.unravel_index(np.argmax(err - tol), err.shape)}"
     assert (ref != 0).sum() > (100 if tag else 500)        # the corner sets hold a dozen ticks per pair
+    n_live = int((np.abs(sig).max(axis=-1) > 0).sum())
+    print(f"{cfg} {tag}{path} prune {prune}: {n_live} live pairs, {st.n_fallback} through the fallback, pool {st.n_wbuf}")
+    if path != "mono":
+        # the named kernels, not their fallback, carried the pairs (the corner sets hold the geometries that overflow them,
+        # and with every weight kept -- prune 0 -- a good share of the pairs exceeds the item capacity)
+        assert st.n_fallback <= (0.5 if (tag or prune == 0) else 0.05) * n_live
 
 
-def test_tracks_current_vs_oracle_full_ticks():
+@pytest.mark.parametrize("path", list(CURRENT_PATHS))
+def test_tracks_current_vs_oracle_full_ticks(path):
     """All ticks of a few pairs, incl. long / steep segments, vs the oracle (which is pinned to the reference)."""
     H.load_cfg("module0")
     seg = synth.make_segments(6, seed=11, segs_per_event=6)
@@ -184,10 +214,79 @@ def test_tracks_current_vs_oracle_full_ticks():
     _, T = O.time_intervals(r)
     resp = synth.make_response("golden")
     ref = O.tracks_current(r, neigh, T, resp)
-    sig = np.zeros_like(ref)
-    detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
-    H.assert_wave_close(sig, ref, rtol=1e-5, atol_peak=1e-7, what="tracks_current")
+    sig, st = _tracks_current_on(path, neigh, r, resp, T)
+    H.assert_wave_close(sig, ref, rtol=1e-5, atol_peak=1e-7, what=f"tracks_current[{path}]")
     assert (ref != 0).sum() > 10000
+    if path != "mono":        # (the 1.9 cm steep segment's pairs exceed the item capacity: 4 of 54 on the quadrature path)
+        assert st.n_fallback <= 0.1 * (np.abs(ref).max(axis=-1) > 0).sum()
+
+
+@pytest.mark.parametrize("cfg", ["module0", "ndlar"])
+def test_tracks_current_length_sweep_vs_oracle(cfg):
+    """Segment length from 0 to 165 Gaussian widths along the segment (r), a few hundred micrometres to a centimetre from
+    the anode where sigma_T -> 0: the quadrature's node rule N = ceil(4.8 + 1.6 r) on both sides of the 64-node LDS copy
+    (r = 37) and of the 256-node cap (r = 157, beyond it the monolithic kernel takes the pair), every tick against the
+    oracle's closed form (detsim.py:114-159), sub-threshold waveforms included."""
+    H.load_cfg(cfg)
+    det = consts.detector
+    B = det.TPC_BORDERS[0]
+    sgn = np.sign(B[2][1] - B[2][0])
+    rs = [0.01, 0.8, 4.0, 12.0, 30.0, 36.0, 38.5, 45.0, 70.0, 110.0, 150.0, 156.0, 159.0, 165.0]
+    dists = [0.03, 0.12, 0.6]
+    seg = synth.make_segments(len(rs) * len(dists), seed=23, segs_per_event=len(rs) * len(dists))
+    batching.swap_coordinates(seg)
+    x0, y0 = B[0][0] + 0.37 * (B[0][1] - B[0][0]), B[1][0] + 0.41 * (B[1][1] - B[1][0])
+    k = 0
+    for d in dists:
+        sT = np.sqrt(2 * det.TRAN_DIFF * d / det.V_DRIFT)        # drifting.py:47-52 at drift distance d
+        for rr in rs:
+            L = rr * sT
+            ang = 0.7 + 0.37 * k                                 # direction in the pixel plane, a shallow tilt along the drift
+            a = np.array([x0 + 0.9 * (k % 5), y0 + 0.7 * (k // 5), B[2][0] + sgn * d])
+            # (the shortest ones steeper, so that z_end - z_start survives the f4 fields: the reference divides 0/0 otherwise)
+            tilt = 0.0998 if rr >= 1 else 0.6
+            b = a + L * np.array([np.cos(ang) * np.sqrt(1 - tilt * tilt), np.sin(ang) * np.sqrt(1 - tilt * tilt), sgn * tilt])
+            for i, ax in enumerate("xyz"):
+                seg[ax + "_start"][k] = a[i]; seg[ax + "_end"][k] = b[i]
+                seg[ax][k] = 0.5 * (np.float32(a[i]).astype(np.float64) + np.float32(b[i]))
+            seg["dx"][k] = max(L, 1e-4); seg["dEdx"][k] = 2.1; seg["dE"][k] = 2.1 * seg["dx"][k]
+            k += 1
+    r = H.quench_drift(O, seg)
+    assert (r["pixel_plane"] == 0).all()
+    nmax = O.max_pixels(r)
+    P = 3 * nmax + 6
+    _, neigh, nrad, _ = O.get_pixels(r, nmax, P, 1)
+    _, T = O.time_intervals(r)
+    resp = H.response_for("golden")
+    ref = O.tracks_current(r, neigh, T, resp)
+    assert np.isfinite(ref).all()
+    live = np.abs(ref).max(axis=-1) > 0
+    assert live.sum() > 3 * len(rs) * len(dists)
+    # Weights below exp(-prune_log) = 1e-10 of the segment's on-axis weight are dropped, so a far neighbour pixel that only
+    # sees the Gaussian tail (waveform peak 1e-9 of the segment's main pixel: 1e-6 electrons per tick) comes out as zeros.
+    # With the default pruning the absolute floor of the tolerance is therefore 1e-7 of the SEGMENT's largest waveform peak
+    # (below the f4 resolution of the values the reference stores for that pixel); with every weight kept (prune_log 0) the
+    # floor is 1e-7 of the pair's own peak like everywhere else.
+    def close(got, floor_peak, what):
+        err = np.abs(got.astype(np.float64) - ref)
+        tol = 1e-5 * np.abs(ref) + 1e-7 * floor_peak
+        assert (err <= tol).all(), f"{what}: max excess {np.max(err - tol)} at {np.unravel_index(np.argmax(err - tol), err.shape)}"
+    pair_peak = np.abs(ref).max(axis=-1, keepdims=True)
+    seg_peak = pair_peak.max(axis=1, keepdims=True)
+    sig, st = _tracks_current_on("quad", neigh, r, resp, T)
+    close(sig, seg_peak, f"length sweep {cfg}")
+    main = pair_peak >= 1e-6 * seg_peak                      # every pixel that matters also holds the per-pair bar
+    close(np.where(main, sig, ref), pair_peak, f"length sweep {cfg}, pixels above 1e-6 of the segment's peak")
+    print(f"length sweep {cfg}: {int(live.sum())} live pairs, {st.n_fallback} beyond the node cap / capacities")
+    # both sides of the cap were met: some pairs went to the monolithic kernel, most did not
+    assert 0 < st.n_fallback < 0.5 * live.sum()
+    # ... with the cap lowered to 40 nodes more pairs take the monolithic kernel: the same waveforms
+    sig2, st2 = _tracks_current_on("quad", neigh, r, resp, T, quad_max_nodes=40)
+    close(sig2, seg_peak, f"length sweep {cfg}, 40-node cap")
+    assert st2.n_fallback > st.n_fallback
+    # ... and with every weight kept, per-pair tolerance for every pair
+    sig3, st3 = _tracks_current_on("quad", neigh, r, resp, T, prune_log=0.0)
+    close(sig3, pair_peak, f"length sweep {cfg}, prune_log 0")
 
 
 def test_stage_api_chain_golden():
@@ -1839,6 +1938,7 @@ def test_cli_light_leg(tmp_path):
     cli = _load_cli()
     H.load_cfg("module0")
     seg = synth.make_segments(60, seed=10, segs_per_event=30)
+    seg = seg[np.random.default_rng(4).permutation(len(seg))]      # events interleaved: batch order is not file order
     np.save(tmp_path / "in.npy", seg)
     lut = synth.make_lut((14, 26, 8), 48, 40, 3)
     np.savez(tmp_path / "lut.npz", arr=lut)
@@ -1848,6 +1948,24 @@ def test_cli_light_leg(tmp_path):
     dat = out["light_dat__light_dat_allmodules"]
     assert dat.shape == (out["segments"].shape[0], consts.light.N_OP_CHANNEL)
     assert (dat["n_photons_det"] > 0).any() and np.array_equal(dat["segment_id"][:, 0], out["segments"]["segment_id"])
+    # `segments` and `light_dat` rows: the active-volume subsequence of the input in FILE order, like the reference's
+    # segments_to_files = tracks (cli/simulate_pixels.py:1230-1234, 759-760) -- not the batch order the device works in
+    tr = cli.prepare_tracks(seg.copy())
+    act = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
+    assert np.array_equal(out["segments"]["segment_id"], act["segment_id"])
+    assert not np.array_equal(act["segment_id"], act["segment_id"][batching.assign_batches(act)[1]])
+    hand = act.copy()
+    quenching.quench[1, 64](hand, consts.physics.BIRKS)
+    drifting.drift[1, 64](hand)
+    for f in ("n_electrons", "n_photons", "t", "long_diff"):
+        assert np.array_equal(out["segments"][f], hand[f]), f
+    ch = ChargeChain(synth.make_response("survey"))
+    ch.upload(act.copy(), np.zeros(len(act), dtype=np.int32)); ch.quench_drift()
+    mask = lut["vis"] > 0
+    lut2 = lut.copy(); lut2["vis"][~mask] = lut2["vis"][mask].min()
+    ch.light_incidence(lut2, n_out=consts.light.N_OP_CHANNEL)
+    inc_hand, _ = ch.download_light_incidence(0, len(hand))
+    assert np.array_equal(dat["n_photons_det"], inc_hand["n_photons_det"])
     inc = out["light_sample_inc"]
     assert inc.shape[0] == res["n_batches"] and inc.sum() > 0
     # the waveform chain: one light_wvfm row per trigger (threshold mode: also one light_trig row), LSB-quantised samples;
@@ -1920,7 +2038,8 @@ def test_cli_pixel_threshold_and_gain_files(tmp_path):
         np.testing.assert_allclose(res["adc_list"], ref["adc_list"], rtol=1e-12, atol=0)
 
 
-def test_tracks_current_edge_cases_vs_oracle():
+@pytest.mark.parametrize("path", list(CURRENT_PATHS))
+def test_tracks_current_edge_cases_vs_oracle(path):
     """Degenerate and extreme segments: x_start == x_end (reference returns 0, detsim.py:62-69), z_start == z_end,
     a 6 cm steep segment (many slice chunks, waveform longer than one 2048-tick tile), a segment leaving the pixel
     plane (-1 gaps), and one outside every TPC."""
@@ -1949,8 +2068,7 @@ def test_tracks_current_edge_cases_vs_oracle():
     assert T > 2048                                                      # second tick tile exercised
     resp = synth.make_response("golden")
     ref = O.tracks_current(r, neigh, T, resp)
-    sig = np.zeros_like(ref)
-    detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, neigh, r, resp)
+    sig, st = _tracks_current_on(path, neigh, r, resp, T)
     assert not ref[0].any() and not sig[0].any() and not sig[4].any()
     # z_start == z_end: direction[2] == 0 makes the reference's track_point divide 0/0; its waveform is NaN
     # (0 * NaN accumulates).  Recorded divergence: this build emits zeros for such a pair.
