@@ -34,15 +34,41 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI35
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "r02_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
+def host_cpu():
+    """(physical cores, logical CPUs this process may use, model name) of the box, from /proc/cpuinfo and the affinity mask"""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                elif not k and pid is not None:
+                    phys.add((pid, cid)); pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return (len(phys) or usable), usable, model
+
+
 def cpu_baseline(response, n_seg=400):
-    """The oracle (C port of the reference algorithm) on a bounded sample of the same workload: 400 segments are
-    about 12 s on the GPU box's 16 host threads (the rate does not depend on the sample size: 48 segments give the same)."""
+    """The oracle (C port of the reference algorithm) on a bounded sample of the same workload, OpenMP over the (segment,
+    pixel) pairs of tracks_current on every core this process may use (threads = physical cores, stated)."""
     from larndsim_amd import batching, consts, synth
     from oracle import oracle as O
     O.build()
+    phys, usable, model = host_cpu()
+    cores = max(1, min(phys, usable))
     seg = synth.make_segments(n_seg, seed=synth.SEED_BASE + 2, segs_per_event=n_seg)
     batching.swap_coordinates(seg)
-    cores = min(os.cpu_count() or 1, 16)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     t0 = time.perf_counter()
     O.quench(seg, consts.physics.BIRKS)
@@ -62,8 +88,9 @@ def cpu_baseline(response, n_seg=400):
     O.digitize(adc)
     dt = time.perf_counter() - t0
     return {"value": n_seg / dt, "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": f"{n_seg} segments of the same synthetic set (charge chain), {dt:.1f} s; OpenMP over "
-                      f"(segment,pixel) pairs in tracks_current only"}
+            "physical_cores": phys, "usable_cpus": usable, "cpu_model": model,
+            "sample": f"{n_seg} segments of the same synthetic set (charge chain), {dt:.1f} s; OpenMP ({cores} threads) over "
+                      f"(segment,pixel) pairs in tracks_current, the other stages single-threaded"}
 
 
 def profiled_traffic(config, kernel):
@@ -83,7 +110,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--segments", type=int, default=SEGS_PER_GPU)
+    ap.add_argument("--segments", type=int, default=None, help="segments per GPU (default 100000; 1000000 with --baseline-config 3..5)")
+    ap.add_argument("--baseline-config", type=int, default=None, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[n-1] as SURVEY 8d spells it: 2 = module0 100k (the default contract line), "
+                         "3 = 2x2 1M, 4 = 2x2 1M per GPU (8M on 8 GPUs; seed +4, 10000 segments per event), 5 = ndlar 1M + light")
     ap.add_argument("--response", default="survey", choices=["survey", "dense", "golden"])
     ap.add_argument("--config", default="module0", choices=["module0", "2x2_no_modvar", "ndlar"],
                     help="detector configuration of the synthetic workload (SURVEY 8d seeds); the contract line is the "
@@ -115,10 +145,19 @@ def main():
         result_fd = os.dup(1)
         os.dup2(2, 1)
 
+    if a.baseline_config is not None:
+        a.config = {2: "module0", 3: "2x2_no_modvar", 4: "2x2_no_modvar", 5: "ndlar"}[a.baseline_config]
+        if a.segments is None:
+            a.segments = SEGS_PER_GPU if a.baseline_config == 2 else 1_000_000
+    if a.segments is None:
+        a.segments = SEGS_PER_GPU
     consts.load_snapshot(a.config)
     for k in ("RESET_NOISE_CHARGE", "UNCORRELATED_NOISE_CHARGE", "DISCRIMINATOR_NOISE"):
         setattr(consts.detector, k, 0)     # noise off: the contract workload is the deterministic chain
-    seed_index = {"module0": 2, "2x2_no_modvar": 3, "ndlar": 5}[a.config]      # BASELINE config number
+    # BASELINE config number -> seed and event size.  The 2x2 geometry on more than one GPU is config 4 (seed +4,
+    # 10000 segments per event so that a (event, TPC group) batch is a useful unit of sharding), on one GPU config 3.
+    seed_index = a.baseline_config or {"module0": 2, "2x2_no_modvar": 4 if world > 1 else 3, "ndlar": 5}[a.config]
+    segs_per_event = 10000 if seed_index == 4 else 5000
     light_on = a.light == "on" or (a.light == "auto" and a.config == "ndlar")
     lut = None
     if light_on:
@@ -126,17 +165,34 @@ def main():
             synth.set_synthetic_light(48)                       # ndlar ships no light configuration
         lut = synth.make_lut((14, 26, 8), 48, 100, synth.SEED_BASE + seed_index)
 
-    # ---- workload: global set of world x 100k segments, this rank's shard of its batches ----------------------------
+    # ---- workload: the global set of world x `segments` segments, this rank's shard of its (event, TPC group) batches.  Up to
+    # 2M segments every rank builds the global set and takes its shard (dist.shard_segments: balanced by segment count,
+    # tests/test_cpu_dist.py).  Beyond that (config 4: 8M) building it eight times over would cost minutes before the timed
+    # region: rank r then builds its own `segments` segments as events [r E, (r+1) E) with its own seed -- the same kind of
+    # shard (whole events, hence whole batches), decided before instead of after the generation.
     n_total = a.segments * world
-    seg_all = synth.make_segments(n_total, seed=synth.SEED_BASE + seed_index, segs_per_event=5000,
-                                  spill=bool(consts.sim.IS_SPILL_SIM))
-    if consts.sim.IS_SPILL_SIM:            # the driver subtracts the spill offset again (cli/simulate_pixels.py:574-582)
-        loc = seg_all["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
-        for f in ("t0", "t0_start", "t0_end"):
-            seg_all[f] = seg_all[f] - loc * consts.sim.SPILL_PERIOD
-    batching.swap_coordinates(seg_all)
-    bid_all, order, table = batching.assign_batches(seg_all)
-    idx, bid = ldist.shard_segments(bid_all, order, table, rank, world)
+    own_events = world > 1 and n_total > 2_000_000
+
+    def undo_spill_offset(s):              # the driver subtracts the spill offset again (cli/simulate_pixels.py:574-582)
+        if consts.sim.IS_SPILL_SIM:
+            loc = s["event_id"] % consts.sim.MAX_EVENTS_PER_FILE
+            for f in ("t0", "t0_start", "t0_end"):
+                s[f] = s[f] - loc * consts.sim.SPILL_PERIOD
+    if own_events:
+        ev_per_rank = -(-a.segments // segs_per_event)
+        seg_all = synth.make_segments(a.segments, seed=synth.SEED_BASE + seed_index + 7919 * rank, segs_per_event=segs_per_event,
+                                      spill=bool(consts.sim.IS_SPILL_SIM), event_id0=rank * ev_per_rank)
+        undo_spill_offset(seg_all)
+        batching.swap_coordinates(seg_all)
+        bid_all, order, table = batching.assign_batches(seg_all)
+        idx, bid = ldist.shard_segments(bid_all, order, table, 0, 1)
+    else:
+        seg_all = synth.make_segments(n_total, seed=synth.SEED_BASE + seed_index, segs_per_event=segs_per_event,
+                                      spill=bool(consts.sim.IS_SPILL_SIM))
+        undo_spill_offset(seg_all)
+        batching.swap_coordinates(seg_all)
+        bid_all, order, table = batching.assign_batches(seg_all)
+        idx, bid = ldist.shard_segments(bid_all, order, table, rank, world)
     seg = np.ascontiguousarray(seg_all[idx])
     del seg_all
     response = synth.make_response(a.response)
@@ -157,6 +213,7 @@ def main():
                 "S": 0, "U": 0, "pairs": 0, "launches": 0, "hits": 0, "ambig": 0, "ovf": 0, "inc_ms": 0.0, "inc_n": 0,
                 "sum_ms": 0.0, "sum_n": 0, "photons": 0.0}
     acc = new_acc()
+    gathered = {"rows": 0, "per_rank": []}
 
     def step(record, download=False):
         ch.reset()
@@ -192,7 +249,9 @@ def main():
         if download == "overlapped":
             ch.wait_download()
         if cm is not None:
-            return cm.allgather_hits()[0]
+            total, counts = cm.allgather_hits()
+            gathered["rows"], gathered["per_rank"] = total, counts
+            return total
         return 0
 
     def barrier():
@@ -209,9 +268,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_job = float(len(seg))
+    n_ranks_rccl = None
     if cm is not None:
         elapsed = cm.allreduce(elapsed, "max")
         n_job = cm.allreduce(n_job, "sum")
+        n_ranks_rccl = cm.count()[0]                 # ncclCommCount: the ranks that really joined
 
     # ---- side measurements (one GPU only; never part of `value`) ------------------------------------------------------------
     extras = {}
@@ -281,7 +342,7 @@ def main():
         mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
         tflops = 2.0 * acc["dfma"] / mac_s / 1e12 if mac_s > 0 else 0.0
         nl = max(acc["launches"], 1)
-        default_workload = (a.segments == SEGS_PER_GPU and a.response == "survey" and a.fractions and split)
+        default_workload = (a.segments == SEGS_PER_GPU and a.response == "survey" and a.fractions and split and seed_index == 2)
         traffic, traffic_src = profiled_traffic(a.config, dom_name) if default_workload else (None, "not the profiled workload")
         what = "charge chain quench->drift->pixels->tracks_current->pixel sum->ADC+digitize"
         if light_on:
@@ -292,7 +353,7 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.config}, {a.segments} synthetic straight-track segments per GPU "
-                                   f"(seed {synth.SEED_BASE + seed_index}, 5000/event), {what}, backtracking fractions "
+                                   f"(seed {synth.SEED_BASE + seed_index}, {segs_per_event}/event), {what}, backtracking fractions "
                                    f"{'on' if a.fractions else 'off'}",
                        "response": f"synthetic '{a.response}' (45,45,1950) f64", "noise": "off",
                        "light": (f"synthetic LUT (14,26,8) x 48 ch/TPC x 100 bins, {int(consts.light.N_OP_CHANNEL)} channels, "
@@ -301,6 +362,11 @@ def main():
                        "unique_pixels_per_segment": acc["U"] / max(acc["S"], 1),
                        "hits_per_step": acc["hits"] // max(a.steps, 1),
                        "chunk_segments": CHUNK_SEGMENTS, "parallelism": f"batch-sharded x{world}",
+                       "n_ranks": n_ranks_rccl if n_ranks_rccl is not None else 1,     # as RCCL reports (ncclCommCount)
+                       "hit_rows_per_rank": gathered["per_rank"] if cm is not None else [acc["hits"] // max(a.steps, 1)],
+                       "hit_rows_gathered": gathered["rows"] if cm is not None else acc["hits"] // max(a.steps, 1),
+                       "baseline_config": seed_index, "segments_per_event": segs_per_event,
+                       "sharding": ("every rank builds its own events" if own_events else "global set, dist.shard_segments"),
                        "collective": "RCCL all-gather (counts) + all-gather-v (24-byte hit rows), C-ABI ldsim_comm_*"
                                      if cm is not None else "none (one rank)"},
             "roofline": {"bound": "hbm", "kernel": dom_name,
@@ -336,7 +402,7 @@ def main():
             useful = acc["dfma_useful"] if acc["dfma_useful"] > 0 else acc["dfma"]
             tf_alg = 2.0 * useful / mac_s / 1e12
             out["roofline"].update({
-                "bound": "mfma", "achieved": tf_alg, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "bound": "valu_f64", "achieved": tf_alg, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf_alg / FP64_VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_launch": 2.0 * useful / nl,
                 "issued": {"achieved": tflops, "frac": tflops / FP64_VALU_PEAK_TFLOPS,

@@ -406,6 +406,8 @@ int ldsim_light_response_ms(ldsim_ctx* ctx, double* scint_ms, double* fluct_ms, 
 int ldsim_comm_unique_id(void* id);
 int ldsim_comm_init(ldsim_ctx* ctx, const void* id, int32_t rank, int32_t world);
 int ldsim_comm_destroy(ldsim_ctx* ctx);
+/* ranks in the communicator and this rank's index as RCCL reports them (ncclCommCount, ncclCommUserRank); rank may be NULL */
+int ldsim_comm_count(ldsim_ctx* ctx, int32_t* n_ranks, int32_t* rank);
 /* *value reduced over the ranks (op 0 = sum, 1 = max); also the barrier of the timed region */
 int ldsim_comm_allreduce_f64(ldsim_ctx* ctx, double* value, int32_t op);
 /* append the last ldsim_charge_chain call's compact hit rows to the pass buffer (reset != 0 empties it first) */

@@ -47,6 +47,18 @@ extern "C" int ldsim_comm_init(ldsim_ctx* ctx, const void* id, int32_t rank, int
   return 0;
 }
 
+// ranks in the communicator as RCCL reports them (ncclCommCount / ncclCommUserRank): lets a caller check that every rank of the
+// launch really joined, instead of trusting the environment it was started with
+extern "C" int ldsim_comm_count(ldsim_ctx* ctx, int32_t* n_ranks, int32_t* rank) {
+  NEEDC(ctx && ctx->comm && n_ranks, "no communicator / null argument");
+  int n = 0, r = 0;
+  NCCLCHK(ncclCommCount((ncclComm_t)ctx->comm, &n));
+  NCCLCHK(ncclCommUserRank((ncclComm_t)ctx->comm, &r));
+  *n_ranks = n;
+  if (rank) *rank = r;
+  return 0;
+}
+
 extern "C" int ldsim_comm_destroy(ldsim_ctx* ctx) {
   if (!ctx || !ctx->comm) return 0;
   (void)hipStreamSynchronize(ctx->stream);

@@ -53,20 +53,27 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
     while (g.t_start + cand * dt < 0.) cand++;
     it0 = cand;
   }
+  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
+  const double i2T = 1.0 / (2 * g.sT2), i2L = 1.0 / (2 * g.sL2);
+  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
+  // Pruning is relative to the largest weight the segment can put on a sample: factor dV sqrt(pi / a) on the axis of a
+  // segment much longer than the Gaussian's width along it, factor dV Dr for one much shorter (its charge is q, not the
+  // q / Dr per unit length of the long one).  Thresholds and clips below use exp(-prune_eff) of the on-axis density, with
+  // prune_eff = prune_log + log(sqrt(pi / a) / Dr) for the short ones, so that "1e-10 of the peak weight" holds for
+  // micrometre-long segments as well (tests: test_tracks_current_length_sweep_vs_oracle, r = 0.01).
+  const double peak_len = fmin(sqrt(M_PI / a), g.Dr);
+  const double prune_eff = A.prune_log > 0 ? A.prune_log + log(sqrt(M_PI / a) / peak_len) : 0.0;
   int iz_lo = 0, iz_hi = g.z_steps - 1;
   if (A.prune_log > 0 && g.z_step > 0) {
-    double cz = sqrt(2.0 * A.prune_log) * g.sL;
+    double cz = sqrt(2.0 * prune_eff) * g.sL;
     double zl = g.sz - cz, zh = g.sz + g.Dz + cz;
     double fl = floor((zl - g.z_start_int) / g.z_step) - 1, fh = ceil((zh - g.z_start_int) / g.z_step) + 1;
     if (fl > iz_lo) iz_lo = (int)fmin(fl, (double)g.z_steps);
     if (fh < iz_hi) iz_hi = (int)fmax(fh, -1.0);
   }
-  const double ux = g.Dx / g.Dr, uy = g.Dy / g.Dr, uz = g.Dz / g.Dr;
-  const double i2T = 1.0 / (2 * g.sT2), i2L = 1.0 / (2 * g.sL2);
-  const double a = ux * ux * i2T + uy * uy * i2T + uz * uz * i2L;
   const double factor = g.q / g.Dr / (g.s3 * sqrt(8 * M_PI * M_PI * M_PI));
   // the part of the segment that can reach the sample box (kernels_qweights.hip)
-  const double G = sqrt(2.0 * ((A.prune_log > 0 ? A.prune_log : 43.0) + 7.0));
+  const double G = sqrt(2.0 * ((A.prune_log > 0 ? prune_eff : 43.0) + 7.0));
   double s_lo = 0, s_hi = g.Dr;
   {
     const double z0 = g.z_start_int + iz_lo * g.z_step - g.sz, z1 = g.z_start_int + iz_hi * g.z_step - g.sz;
@@ -116,7 +123,7 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   P.kappa = (ux * ux + uy * uy) * (1.0 - g.rT * g.rT) * i2T + uz * uz * (1.0 - g.rL * g.rL) * i2L;
   P.s_lo = s_lo; P.qlen = qlen;
   P.wscale = factor * g.dV * 0.5 * qlen;
-  P.thr = A.prune_log > 0 ? exp(-A.prune_log) * factor * g.dV * sqrt(M_PI / a) : 0.0;
+  P.thr = A.prune_log > 0 ? exp(-A.prune_log) * factor * g.dV * peak_len : 0.0;
   pp[pair] = P;
 }
 

@@ -24,23 +24,37 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+MAGIC = b"LDSIMID1"          # frames the payload: a foreign service that happens to own a candidate port is not mistaken for rank 0
+PORT_TRIES = 16
+
+
 def exchange_id(payload, rank, world, addr=None, port=None, timeout=300.0):
-    """Rank 0 sends ``payload`` (bytes) to every other rank; returns the payload on every rank."""
+    """Rank 0 sends ``payload`` (bytes) to every other rank; returns the payload on every rank.
+
+    Rank 0 listens on the first free port of ``base .. base + PORT_TRIES - 1`` (base = MASTER_PORT + 1 + LDSIM_PORT_OFFSET: the
+    launcher's own store sits on MASTER_PORT, and whatever else runs on the node may own the next one); the other ranks go
+    round the same candidates until one of them answers with a framed payload."""
     if world == 1:
         return payload
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(port or (int(os.environ.get("MASTER_PORT", "29511")) + 1 + int(os.environ.get("LDSIM_PORT_OFFSET", "0"))))
+    base = int(port or (int(os.environ.get("MASTER_PORT", "29511")) + 1 + int(os.environ.get("LDSIM_PORT_OFFSET", "0"))))
+    ports = [base + k for k in range(PORT_TRIES)]
     deadline = time.time() + timeout
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        while True:
-            try:
-                srv.bind((addr, port))
-                break
-            except OSError:
+        srv = None
+        while srv is None:
+            for p in ports:
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    s.bind((addr, p))
+                    srv = s
+                    break
+                except OSError:
+                    s.close()
+            if srv is None:
                 if time.time() > deadline:
-                    raise
+                    raise lib.LdsimError(f"rank 0: none of the ports {ports[0]}..{ports[-1]} on {addr} could be bound")
                 time.sleep(0.2)
         srv.listen(world)
         srv.settimeout(timeout)
@@ -48,25 +62,28 @@ def exchange_id(payload, rank, world, addr=None, port=None, timeout=300.0):
         while served < world - 1:
             conn, _ = srv.accept()
             with conn:
-                conn.sendall(payload)
+                conn.sendall(MAGIC + payload)
             served += 1
         srv.close()
         return payload
+    need = len(MAGIC) + ID_BYTES
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=10.0) as s:
-                buf = b""
-                while len(buf) < ID_BYTES:
-                    chunk = s.recv(ID_BYTES - len(buf))
-                    if not chunk:
-                        break
-                    buf += chunk
-            if len(buf) == ID_BYTES:
-                return buf
-        except OSError:
-            pass
+        for p in ports:
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as s:
+                    s.settimeout(5.0)
+                    buf = b""
+                    while len(buf) < need:
+                        chunk = s.recv(need - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                if len(buf) == need and buf.startswith(MAGIC):
+                    return buf[len(MAGIC):]
+            except OSError:
+                pass
         if time.time() > deadline:
-            raise lib.LdsimError(f"rank {rank}: no ncclUniqueId from rank 0 at {addr}:{port} within {timeout:.0f} s")
+            raise lib.LdsimError(f"rank {rank}: no ncclUniqueId from rank 0 at {addr}:{ports[0]}..{ports[-1]} within {timeout:.0f} s")
         time.sleep(0.1)
 
 
@@ -83,6 +100,12 @@ class Communicator:
             lib.check(lib.load().ldsim_comm_unique_id(ident))
         payload = exchange_id(ident.raw if self.rank == 0 else b"", self.rank, self.world)
         lib.check(lib.load().ldsim_comm_init(ctx, C.c_char_p(payload), C.c_int32(self.rank), C.c_int32(self.world)))
+
+    def count(self):
+        """(ranks in the communicator, this rank) as RCCL reports them (ncclCommCount / ncclCommUserRank)"""
+        n, r = C.c_int32(), C.c_int32()
+        lib.check(lib.load().ldsim_comm_count(self.ctx, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def allreduce(self, value, op="sum"):
         v = C.c_double(float(value))

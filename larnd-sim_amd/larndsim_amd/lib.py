@@ -40,7 +40,7 @@ EXPORTS = [
     "ldsim_rng_seed", "ldsim_rng_states_download", "ldsim_rng_clear", "ldsim_rng_extend", "ldsim_rng_count",
     "ldsim_stat_fluctuations", "ldsim_light_triggers", "ldsim_light_detector_noise", "ldsim_sim_triggers",
     "ldsim_dev_light_response", "ldsim_dev_light_response_download", "ldsim_light_response_ms",
-    "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
+    "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_count", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
     "ldsim_comm_allgather_hits", "ldsim_comm_gathered_download",
 ]
 

@@ -106,3 +106,45 @@ def test_unique_id_rendezvous_world3():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == res[1] == res[2] == bytes(range(128))
+
+
+def test_unique_id_rendezvous_skips_a_port_someone_else_owns():
+    """MASTER_PORT + 1 may belong to another service on the node: rank 0 then listens on the next candidate, and the other
+    ranks recognise the foreign listener by the missing frame and move on (no retry on a different port)."""
+    import multiprocessing as mp
+    import socket
+    import threading
+    port = _free_port()
+    foreign = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(("127.0.0.1", port))
+    foreign.listen(8)
+    stop = threading.Event()
+
+    def chatter():                      # answers every connection with 136 bytes that are not a framed id
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+            except OSError:
+                continue
+            with c:
+                c.sendall(b"x" * 136)
+
+    th = threading.Thread(target=chatter, daemon=True)
+    th.start()
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_id_worker, args=(r, 2, port, q)) for r in (1, 0)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res[0] == res[1] == bytes(range(128))
+    finally:
+        stop.set()
+        th.join(timeout=5)
+        foreign.close()
