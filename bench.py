@@ -31,7 +31,7 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = 50_000
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "r02_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "r03_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
 def host_cpu():
@@ -125,6 +125,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-response and PCIe-inclusive side measurements")
     ap.add_argument("--fractions", type=int, default=1, help="compute backtracking fractions (reference always does)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-gather path even with one rank")
+    ap.add_argument("--weights-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="tracks_current kernels: 2 = node-separable form (gtables_kernel + gcorr_kernel, default), 1 = qweights_kernel "
+                         "+ mac_shift kernels (round 2), 0 = weights_kernel + mac_shift")
+    ap.add_argument("--trim-response-log", type=float, default=None,
+                    help="response ticks below exp(-v) of the table's largest entry are not read (library default 23; 0 = exact zeros only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +203,9 @@ def main():
     response = synth.make_response(a.response)
 
     ch = ChargeChain(response, device=local_rank)
+    lib.set_option("weights_mode", a.weights_mode, ch.ctx)
+    if a.trim_response_log is not None:
+        lib.set_option("trim_response_log", a.trim_response_log, ch.ctx)
     cm = lcomm.Communicator(ch.ctx, rank, world) if use_dist else None
     t_up = time.perf_counter()
     ch.upload(seg, bid)                      # H2D happens here, outside the timed region
@@ -302,6 +310,22 @@ def main():
         t_ovl = time.perf_counter() - t1
         extras["pcie_inclusive"]["overlapped_value"] = len(seg) / t_ovl
         extras["pcie_inclusive"]["overlapped_ms_per_step"] = 1e3 * t_ovl
+        # (c) the same workload with only exactly-zero response ticks skipped (the library default also skips ticks below 1e-10
+        # of the table's largest entry: DESIGN.md section 4, "trim_response_log")
+        if a.trim_response_log is None:
+            lib.set_option("trim_response_log", 0.0, ch.ctx)
+            step(False)
+            ch.synchronize()
+            t2 = time.perf_counter()
+            nd = max(1, min(3, a.steps))
+            for _ in range(nd):
+                step(False)
+            ch.synchronize()
+            t_exact = (time.perf_counter() - t2) / nd
+            extras["exact_zero_trim"] = {"value": len(seg) / t_exact, "unit": "segments/s", "ms_per_step": 1e3 * t_exact, "steps": nd,
+                                         "note": "trim_response_log 0: every response tick that is not exactly 0.0 is read "
+                                                 "(the survey table's Gaussian tails down to 1e-308)"}
+            lib.set_option("trim_response_log", 23.0, ch.ctx)
         # (b) the same workload on a response table without exact zeros (real response files are dense)
         if a.response != "dense":
             lib.set_response(synth.make_response("dense"), ch.ctx)
@@ -329,12 +353,15 @@ def main():
         value = n_job * a.steps / elapsed
         split = acc["w_ms"] > 0
         M = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
-        mac_name = "mac_shift_kernel" if M == 1 else "mac_shift2_kernel"        # csrc/kernels_macshift.hip
+        gform = a.weights_mode == 2
+        # csrc/kernels_gcorr.hip (node-separable form) or csrc/kernels_macshift.hip
+        mac_name = f"gcorr_kernel<{M}>" if gform else ("mac_shift_kernel" if M == 1 else "mac_shift2_kernel")
+        w_name = f"gtables_kernel<{M}>" if gform else (f"qweights_kernel<{M}>" if a.weights_mode == 1 else f"weights_kernel<{M}>")
         # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
         elif acc["w_ms"] >= acc["m_ms"]:
-            dom_name, dom_ms = f"qweights_kernel<{M}>", acc["w_ms"]
+            dom_name, dom_ms = w_name, acc["w_ms"]
         else:
             dom_name, dom_ms = mac_name, acc["m_ms"]
         dom_s = dom_ms * 1e-3
@@ -378,7 +405,8 @@ def main():
                          "algorithmic_bytes_per_launch": acc["bytes"] / nl,
                          "note": "f64-VALU-bound path: HBM fraction is tiny by construction (SURVEY 8d: ~2 KB of "
                                  "compulsory traffic per segment); see valu_f64 and stage_kernels",
-                         "stage_kernels": {"weights_kernel_ms_avg": acc["w_ms"] / nl, "mac_kernel_ms_avg": acc["m_ms"] / nl,
+                         "stage_kernels": {"weights_kernel": w_name, "mac_kernel": mac_name,
+                                           "weights_kernel_ms_avg": acc["w_ms"] / nl, "mac_kernel_ms_avg": acc["m_ms"] / nl,
                                            "current_kernel_ms_avg": acc["f_ms"] / nl,
                                            "pixel_adc_kernel_ms_avg": acc["adc_ms"] / nl,
                                            "quadrature_nodes_per_pair": acc["samples"] / max(acc["pairs"], 1)},
@@ -402,15 +430,17 @@ def main():
             useful = acc["dfma_useful"] if acc["dfma_useful"] > 0 else acc["dfma"]
             tf_alg = 2.0 * useful / mac_s / 1e12
             out["roofline"].update({
-                "bound": "valu_f64", "achieved": tf_alg, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "bound": "mfma" if gform else "valu_f64", "achieved": tf_alg, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf_alg / FP64_VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_launch": 2.0 * useful / nl,
                 "issued": {"achieved": tflops, "frac": tflops / FP64_VALU_PEAK_TFLOPS,
-                           "note": "every lane of every v_fma_f64 the kernel issues, padding of 8-shift blocks and of the 512-tick "
-                                   "tile included; the VALU pipe is busy all the time at this figure (profiles/r02_sq_counters_final_20k.txt)"},
+                           "note": "every FMA lane the kernel issues (padding included)"},
                 "hbm": hbm_view,
-                "note": "f64-VALU-bound kernel (no MFMA in it: the f64 matrix and vector pipes have the same peak here and are not "
-                        "additive); `traffic` = HBM bytes of this kernel per launch from the PMC passes"})
+                "note": ("f64 matrix-pipe kernel (v_mfma_f64_16x16x4, dense peak 78.6 TFLOP/s): algorithmic flops = 2 x nodes x cells x "
+                         "response ticks + the Toeplitz sum, issued = 2 x 1024 per MFMA (16-row / 4-cell / 16-tick padding included)"
+                         if gform else
+                         "f64-VALU-bound kernel (no MFMA in it: the f64 matrix and vector pipes have the same peak here and are not "
+                         "additive)") + "; `traffic` = HBM bytes of this kernel per launch from the PMC passes"})
         if light_on and acc["inc_n"]:
             n_op = int(consts.light.N_OP_CHANNEL)
             inc_ms = acc["inc_ms"] / acc["inc_n"]

@@ -127,14 +127,17 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * tools/prune_sweep.py; 30 was the default before and costs 16-19 % more correlation work),
  * "tail_log" (split path: charge samples bounded by exp(-v) of the segment's peak density are evaluated in f32,
  * relative error ~3e-7 of a term that small; 0 = every sample in f64),
- * "trim_response" (1 = skip leading/trailing response ticks that are exactly 0.0 for every cell),
+ * "trim_response" (1 = skip leading/trailing response ticks that are empty for every cell), "trim_response_log" (what empty
+ * means: below exp(-v) of the table's largest entry; default 23 = 1e-10, the level the weights are pruned at -- such ticks move a
+ * waveform by less than 1e-10 of its peak; 0 = exactly 0.0 only),
  * "split_kernels" (1 = weights_kernel + mac_kernel, 0 = monolithic current_kernel),
  * "wbuf_doubles_per_pair" (initial average budget of the split path's weight pool; the pool grows to the measured
  * demand and the launch is repeated when it was exhausted, so this only affects the first launches; setting it forgets
  * the size learned so far), "split_max_items" (validation: pairs with more weight items than this are recomputed by
  * the monolithic kernel; 0 = the built-in capacity: 512 items at TIME_SAMPLING/RESPONSE_SAMPLING = 1, 2048 at 2),
- * "weights_mode" (split path, weights stage: 1 = qweights_kernel, Gauss-Legendre quadrature along the segment (default);
- * 0 = weights_kernel, the closed form per charge sample), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
+ * "weights_mode" (split path: 2 = node-separable form, gtables_kernel + gcorr_kernel: the quadrature's tables correlated on the
+ * f64 matrix pipe, no weight pool ("mac_mode" does not apply); 1 = qweights_kernel, Gauss-Legendre quadrature along the
+ * segment, then the correlation kernel of "mac_mode"; 0 = weights_kernel, the closed form per charge sample), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
  * "quad_accuracy_log10" (qweights_kernel: node count for a quadrature error of 1e-10 (default) or 1e-12 of the peak weight),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows

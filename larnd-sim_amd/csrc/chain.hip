@@ -21,6 +21,7 @@ int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, cons
                      int32_t*, int64_t*, int64_t);
 int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
 int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*, unsigned long long*);
+int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out);
 int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
                       const double*, int, int64_t, int32_t*);
 
@@ -58,6 +59,18 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
   *split_timed = false;
   size_t ib = 0, hb = 0, cb = 0;
   if (ctx->mc_current) return current_mc_launch(ctx, a, n_seg);   // the driver's call site (cli/simulate_pixels.py:1016)
+  if (ctx->split_kernels && ctx->weights_mode == 2 && n_valid > 0) {
+    // node-separable form (gform.h): tables, then the correlation on the matrix pipe; no weight pool, no repeat launches
+    int32_t* flags = nullptr;
+    int rc = gform_launch(ctx, a, counters, &flags);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      *split_timed = true;
+      a.only_flagged = flags - 7;          // current_kernel reads only_flagged[pair * flag_stride + 7]
+      a.flag_stride = 1;
+      return current_launch(ctx, a);
+    }
+  }
   if (!(ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0)) return current_launch(ctx, a);
   CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));
   CK(ldsim_ensure(ctx, SB_HDR, (size_t)n_valid * hb));

@@ -1,0 +1,65 @@
+// gform.h -- the node-separable form of a9-a12 (option "weights_mode" 2, default): records handed from gtables_kernel
+// (kernels_gtables.hip) to gcorr_kernel (kernels_gcorr.hip).
+//
+// The quadrature along the segment (kernels_qweights.hip) makes the binned weights a sum over nodes of separable terms,
+//      A[i][j][shift] = sum_n X_n[i] Y_n[j] Z_n[shift],
+// so the waveform of a (segment, pixel) pair is
+//      out[t] = sum_n sum_s Z_n[s] G_n[M t + s],        G_n[k] = sum_(i,j) X_n[i] Y_n[j] R[i][j][k]
+// -- a [16 nodes] x [cells] x [response ticks] matrix product followed by a 16-row Toeplitz sum -- and the weights A are never
+// formed: no weight pool, no item lists.  gtables_kernel writes X, Y, Z (a few KB per pair) and the list of response cells
+// that can carry weight; gcorr_kernel runs the two products on the f64 matrix pipe (v_mfma_f64_16x16x4).
+#pragma once
+#include "qpair.h"
+
+#define G_NODES 16          // quadrature nodes per batch = rows of the matrix product
+#define G_NCOL 40           // distinct response columns i of a pair (<= SAMPLED_POINTS)
+#define G_XS 41             // row strides of the LDS tables (odd: the 16 node rows fall on distinct banks)
+#define G_YS 49
+#define G_NUCAP 128         // response shifts of a pair whose Z table the kernels hold in LDS at once (more: in parts / from L2)
+#define G_ZS (G_NUCAP + 16) // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
+#define G_CELLCAP 1024      // cells of a batch held in LDS (more: the monolithic kernel); a multiple of G_CELLPAD
+#define G_CELLPAD 32        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups)
+#define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
+
+// per pair, written by pair_setup_kernel next to PairParams: what sizes the record before any table exists
+struct GInfo {
+  int32_t ncol, NJ, jmin, u_min, NU, edge_bound, NB, status;   // edge_bound: superset of the edges that need a Z table
+  int32_t NQ, it0, T, it_w0, it_w1;                             // copies of the PairParams fields gcorr_kernel needs
+  int32_t emask;                                                // written by gtables_kernel: the edges some slice is invalid at
+  int32_t pad[2];
+  unsigned long long off;                                       // record offset in doubles (exclusive scan of `size`)
+  unsigned long long size;                                      // record size in doubles
+};
+
+// record layout in doubles from `off`:
+//   per node batch b:
+//     cells     1 + padded / 2              int count padded to a multiple of G_CELLPAD with dummies, int count of real cells,
+//                                           then u32 row | col << 16 | j << 24 per cell
+//     X         16 * ncol                   X[n][col]
+//     Y         16 * NJ                     Y[n][j]
+//     Z         16 * NUr                    Z[n][u]; NUr = NU rounded up to 16
+//     C         popcount(edge_bound) * NUr  per possible window edge: what the slices that are invalid at that edge put on it,
+//                                           per shift bin (gtables_kernel multiplies their Z sums with G_n[edge_k] itself)
+__host__ __device__ __forceinline__ int g_nur(int NU) { return (NU + 15) & ~15; }
+__host__ __device__ __forceinline__ int g_popc3(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1); }
+__host__ __device__ __forceinline__ unsigned long long g_cells_doubles(int ncol, int NJ) {
+  return 1ull + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
+}
+__host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound) {
+  return g_cells_doubles(ncol, NJ) + 16ull * ncol + 16ull * NJ + (16ull + g_popc3(edge_bound)) * g_nur(NU);
+}
+__host__ __device__ __forceinline__ unsigned long long g_record_doubles(int NB, int ncol, int NJ, int NU, int edge_bound) {
+  return G_HDR / 2 + (unsigned long long)NB * g_batch_doubles(ncol, NJ, NU, edge_bound);
+}
+
+struct GArgs {
+  CurArgs c;
+  const PairParams* pp;
+  GInfo* gi;
+  double* rec;                   // record pool
+  int32_t* flags;                // [n_pairs] 1 = the monolithic kernel recomputes this pair
+  const double* resp_pad;        // response rows with RESP_PAD zeros either side, zeros outside the staged range
+  int32_t nkp, k_lo, k_hi;
+  const double* glx;
+  const double* glw;
+};

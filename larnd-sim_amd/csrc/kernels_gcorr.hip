@@ -1,0 +1,277 @@
+// kernels_gcorr.hip -- a9-a12, node-separable form ("weights_mode" 2, gform.h): the correlation stage, and the host glue of
+// the whole form.
+//
+// gcorr_kernel: one 256-thread workgroup per (segment, pixel) pair, on the tables gtables_kernel wrote.  Per 16-tick tile of
+// response indices k a wave forms
+//     G[n][k] = sum_cells X[n][col(cell)] Y[n][j(cell)] R[cell][k]                     (v_mfma_f64_16x16x4: nodes x cells x ticks)
+// with the 16 quadrature nodes of the batch as the M rows, four cells per instruction as the contraction and the response
+// row segments R[cell][k0 .. k0 + 15] streamed from L2 as the B operand (one 8-byte load per lane and instruction, from the
+// zero-padded copy of the table: no range checks); then
+//     P[u][k] = sum_n Z[n][u] G[n][k]                                                  (the same instruction: shifts x nodes x ticks)
+// whose B operand IS the accumulator of the first product -- register r of lane l holds G[4r + l/16][k0 + l%16], which is
+// B[kk = l/16][j = l%16] of contraction step r -- so G never leaves the registers; and the diagonal sum
+//     out[(k - u_min - u) / M] += P[u][k]
+// as ds_add_f64 into a tick array private to the wave (the four arrays are summed in wave order afterwards: results do not
+// depend on timing).  A window edge where some slices are invalid (detsim.py:418-428) subtracts the same product with the
+// Zi table at the one response index it concerns.  No DPP shifts, no 512-tick tile padding, no weight pool: the matrix pipe
+// carries 16 x cells x ticks FMAs per pair where the shifted-window kernels issue (cells x shifts) x 512.
+#include "gform.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define GPF 8            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
+static_assert(G_CELLPAD == 4 * GPF, "the cell list is padded to whole prefetch rounds");
+
+// n doubles (n <= 256 * R) from global memory into registers: all loads issued before the first use
+template <int R>
+__device__ __forceinline__ void gload(const double* __restrict__ g, int n, int tid, double (&v)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) v[r] = (tid + CUR_THREADS * r < n) ? g[tid + CUR_THREADS * r] : 0.0;
+}
+
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT) {
+  const CurArgs& A = GA.c;
+  const LdsimConsts* c = A.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  if (GA.flags[pair]) return;                       // the monolithic kernel writes this pair
+  float* out = A.out + pair * (int64_t)A.T;
+  const GInfo* __restrict__ gip = GA.gi + pair;
+  if (gip->status != 1) {
+    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
+    return;
+  }
+  const double* __restrict__ rec = GA.rec + gip->off;
+  const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
+  const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
+  const int NUr = g_nur(NU), NU16 = NUr >> 4;
+  const bool z_lds = NU <= G_NUCAP;                 // the Z table in LDS; the steepest long segments read it from the record (L2)
+  const unsigned long long cells_d = g_cells_doubles(ncol, NJ), batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
+
+  __shared__ double s_X[G_NODES][G_XS], s_Y[G_NODES][G_YS], s_Z[G_NODES][G_ZS];
+  __shared__ unsigned s_cell[G_CELLCAP];
+  extern __shared__ double s_out[];                 // [NWAVE][TT]
+  double* ow = s_out + wv * TT;
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  const int kk = lane >> 4, jj = lane & 15;
+  const int nkp = GA.nkp;
+  unsigned long long n_mfma = 0, n_useful = 0;
+  int loaded = -1;
+
+  for (int sup0 = it_w0; sup0 < it_w1; sup0 += TT) {
+    const int wlen = min(it_w1 - sup0, TT);
+    for (int i = tid; i < NWAVE * TT; i += CUR_THREADS) s_out[i] = 0;
+    // response indices this tick tile can meet, inside the staged range (zeros outside it)
+    const int kA = max(M * sup0 + u_min, GA.k_lo), kB = min(M * (sup0 + wlen - 1) + u_min + NU - 1, GA.k_hi);
+    const int n32 = kB >= kA ? (kB - kA) / 32 + 1 : 0;
+    for (int b = 0; b < NB && n32 > 0; b++) {
+      const double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
+      const int32_t* cells = (const int32_t*)brec;
+      const double* gX = brec + cells_d;
+      const double* gY = gX + 16 * ncol;
+      const double* gZ = gY + 16 * NJ;
+      const double* gC = gZ + 16 * NUr;
+      if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
+        __syncthreads();
+        // every load of the record in flight before the first one is used: one round trip to HBM, not one per table
+        int cv[4];
+        double xv[3], yv[3], zv[8];
+        const int ncell_l = cells[0];
+#pragma unroll
+        for (int r = 0; r < 4; r++) cv[r] = (tid + CUR_THREADS * r < (int)(2 * cells_d) - 2) ? cells[2 + tid + CUR_THREADS * r] : 0;
+        gload<3>(gX, G_NODES * ncol, tid, xv);
+        gload<3>(gY, G_NODES * NJ, tid, yv);
+        gload<8>(gZ, z_lds ? G_NODES * NUr : 0, tid, zv);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int i = tid + CUR_THREADS * r; if (i < ncell_l) s_cell[i] = (unsigned)cv[r]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * ncol) s_X[i / ncol][i % ncol] = xv[r]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * NJ) s_Y[i / NJ][i % NJ] = yv[r]; }
+        if (z_lds) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * NUr) s_Z[i / NUr][i % NUr] = zv[r]; }
+        }
+        if (tid == 0) s_cell[G_CELLCAP - 1] = (unsigned)ncell_l;      // (the padded list never reaches the last entry)
+        loaded = b;
+      }
+      __syncthreads();
+      const int ncell = (int)s_cell[G_CELLCAP - 1];
+      const int ngrp = ncell >> 2;                 // a multiple of GPF (gtables_kernel pads the list with weightless cells)
+      if (tid == 0)
+        n_useful += (unsigned long long)min(G_NODES, NQ - b * G_NODES) *
+                    ((unsigned long long)cells[1] * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
+      // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k]
+      auto pstep = [&](const d4& acc, int k0) {
+        for (int st = 0; st < NU16; st++) {
+          d4 p = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double za = z_lds ? s_Z[4 * q + kk][16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
+            p = __builtin_amdgcn_mfma_f64_16x16x4f64(za, acc[q], p, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int u = 16 * st + 4 * r + kk;
+            const int num = k0 + jj - (u_min + u);
+            const int idx = (M == 1 ? num : (num >> 1)) - sup0;
+            if (u < NU && (M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) atomicAdd(&ow[idx], p[r]);
+          }
+        }
+        n_mfma += 4 * NU16;
+      };
+      // A wave owns pairs of adjacent 16-tick tiles (the second one may lie past the range: its products meet zeros or ticks
+      // outside the window and are dropped): one A operand (X Y of the lane's node and cell) feeds both products, 2 x GPF
+      // response loads are in flight while GPF groups are multiplied; no branch in the loop.
+      for (int kt = wv; kt < n32 && ngrp > 0 && !(A.debug_phases & 0x100000); kt += NWAVE) {
+        const int k0 = kA + 32 * kt;
+        const double* rp = GA.resp_pad + RESP_PAD + k0 + jj;
+        auto rowoff = [&](int g) { return (A.debug_phases & 0x400000) ? (int64_t)0 : (int64_t)(s_cell[4 * g + kk] & 0xFFFFu) * nkp; };
+        d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        double b0[GPF], b1[GPF];
+#pragma unroll
+        for (int u = 0; u < GPF; u++) {
+          const int64_t o = rowoff(u);
+          b0[u] = rp[o];
+          b1[u] = rp[o + 16];
+        }
+#pragma unroll 1
+        for (int g0 = 0; g0 < ngrp && !(A.debug_phases & 0x800000); g0 += GPF) {
+          const int gn = (g0 + GPF < ngrp) ? g0 + GPF : g0;         // (the last round reloads itself: no branch, values unused)
+#pragma unroll
+          for (int u = 0; u < GPF; u++) {
+            const unsigned ci = s_cell[4 * (g0 + u) + kk];
+            const double a = (ci >> 31) ? 0.0 : s_X[jj][(ci >> 16) & 63u] * s_Y[jj][(ci >> 24) & 63u];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
+            const int64_t o = rowoff(gn + u);          // the registers just consumed take the loads of the group GPF ahead
+            b0[u] = rp[o];
+            b1[u] = rp[o + 16];
+          }
+        }
+        n_mfma += 2 * ngrp;
+        if (!(A.debug_phases & 0x200000)) {
+          pstep(acc0, k0);
+          pstep(acc1, k0 + 16);
+        }
+      }
+      // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to
+      if (emask) {
+        int et = 0;
+        for (int e = 0; e < NEDGE; e++) {
+          if (!(ebound & (1 << e))) continue;
+          const double* ce = gC + (unsigned long long)et * NUr;
+          et++;
+          if (!(emask & (1 << e))) continue;
+          __syncthreads();
+          for (int u = tid; u < NU; u += CUR_THREADS) {
+            const int num = edge_k[e] - (u_min + u);
+            const int idx = (M == 1 ? num : (num >> 1)) - sup0;
+            if (num >= 0 && (M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) s_out[idx] -= ce[u];   // one u per tick
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < wlen; i += CUR_THREADS) {
+      const int it = sup0 + i;
+      if (it < A.T) {
+        const double v = ((s_out[i] + s_out[TT + i]) + s_out[2 * TT + i]) + s_out[3 * TT + i];
+        out[it] = (it >= it0 && it < T) ? (float)v : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  for (int it = tid; it < A.T; it += CUR_THREADS)
+    if (it < it_w0 || it >= it_w1) out[it] = 0.f;
+  if (lane == 0 && n_mfma) atomicAdd(&A.counters[5], n_mfma * 1024ull);
+  if (tid == 0 && n_useful) atomicAdd(&A.counters[8], n_useful);
+}
+
+// ---- record offsets: exclusive scan of the sizes pair_setup_kernel wrote ------------------------------------------------------------
+__global__ void __launch_bounds__(256) gsize_gather_kernel(const GInfo* __restrict__ gi, int64_t n, unsigned long long* __restrict__ sz) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) sz[i] = gi[i].size;
+}
+__global__ void __launch_bounds__(256) goff_scatter_kernel(GInfo* __restrict__ gi, int64_t n, const unsigned long long* __restrict__ off,
+                                                           unsigned long long* __restrict__ total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    gi[i].off = off[i];
+    if (i == n - 1) *total = off[i] + gi[i].size;
+  }
+}
+
+int sort_exclusive_scan_u64(ldsim_ctx*, const unsigned long long*, unsigned long long*, int64_t);
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M);
+extern "C++" int resp_pad_ensure(ldsim_ctx* ctx, const CurArgs& A, int* k_lo, int* k_hi, int* nkp);
+
+// M of the form for these constants, 0 = configuration not covered (caller uses the monolithic kernel)
+extern "C++" int gform_M(const ldsim_ctx* ctx, const CurArgs& args) {
+  const LdsimConsts& h = ctx->h_consts;
+  const double ratio = h.time_sampling / h.response_sampling;
+  const int M = (int)llround(ratio);
+  if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX || args.ni > 64 ||
+      args.ni * args.nj > 65535 || args.n_pairs > 0x7fffffffLL)
+    return 0;
+  return M;
+}
+
+// tables + correlation of all pairs of `a`; *flags = device array [n_pairs] of the pairs left to the monolithic kernel.
+// Returns 0 = done, 1 = configuration not covered, < 0 = error.  One host sync (the size of the record pool).
+extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out) {
+  const int M = gform_M(ctx, a);
+  if (!M) return 1;
+  const int64_t n = a.n_pairs;
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(n)))) return rc;
+  if ((rc = ldsim_ensure(ctx, SB_HDR, (size_t)n * sizeof(GInfo)))) return rc;
+  if ((rc = ldsim_ensure(ctx, SB_ITEMS, (size_t)(n + 16) * 4))) return rc;                    // flags
+  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 2) * 8))) return rc;                 // sizes | offsets (+ total)
+  SplitArgs S{};
+  S.c = a;
+  GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
+  if ((rc = qpair_setup_launch(ctx, S, M, ctx->scratch[SB_PPAR].p, gi))) return rc;
+  unsigned long long* d_sz = (unsigned long long*)ctx->scratch[SB_CORR].p;
+  unsigned long long* d_off = d_sz + n;
+  unsigned long long* d_total = d_off + n;
+  const unsigned g0 = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(gsize_gather_kernel, dim3(g0), dim3(256), 0, st, gi, n, d_sz);
+  if ((rc = sort_exclusive_scan_u64(ctx, d_sz, d_off, n))) return rc;
+  hipLaunchKernelGGL(goff_scatter_kernel, dim3(g0), dim3(256), 0, st, gi, n, d_off, d_total);
+  HIPCHK(hipGetLastError());
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
+  HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));
+  GArgs GA{};
+  GA.c = a;
+  GA.pp = (const PairParams*)ctx->scratch[SB_PPAR].p;
+  GA.gi = gi;
+  GA.rec = (double*)ctx->scratch[SB_WBUF].p;
+  GA.flags = (int32_t*)ctx->scratch[SB_ITEMS].p;
+  GA.glx = ctx->d_glx;
+  GA.glw = ctx->d_glw;
+  if ((rc = resp_pad_ensure(ctx, a, &GA.k_lo, &GA.k_hi, &GA.nkp))) return rc;
+  GA.resp_pad = (const double*)ctx->resp_pad.p;
+  if ((rc = gtables_launch(ctx, GA, M))) return rc;
+  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  // ticks per tile of the correlation: the pairs' windows are as long as the staged response support (over M) plus their
+  // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
+  const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
+  const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
+  const size_t dyn = (size_t)NWAVE * TT * 8;
+  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(CUR_THREADS), dyn, st, GA, TT);
+  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(CUR_THREADS), dyn, st, GA, TT);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  // the pool's size in the statistics slot of the split paths (doubles)
+  HIPCHK(hipMemcpyAsync(&counters[7], d_total, 8, hipMemcpyDeviceToDevice, st));
+  *flags_out = GA.flags;
+  return 0;
+}

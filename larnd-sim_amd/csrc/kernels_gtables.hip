@@ -1,0 +1,414 @@
+// kernels_gtables.hip -- a9-a12, node-separable form ("weights_mode" 2, gform.h): the tables stage.
+//
+// gtables_kernel: one 256-thread workgroup per (segment, pixel) pair.  It does what qweights_kernel does up to its tables --
+// sample -> response-cell maps, response shift and window-edge flags of every z slice (the reference's own expressions,
+// detsim.py:414-446, shared with the other weight kernels), one Gaussian per (table bin, quadrature node) -- and stops there:
+// per node batch it writes X[n][col], Y[n][j], Z[n][shift] (and one Zi[n][shift] table per window edge some slice is invalid
+// at) and the list of response cells whose total weight can exceed the pruning threshold.  The rank-N accumulation into
+// A[cell][shift], the weight pool and the item lists of the other split paths do not exist here; gcorr_kernel
+// (kernels_gcorr.hip) correlates straight from the tables.
+//
+// Deterministic: every table entry has one owner thread and a fixed order of its terms.
+#include "gform.h"
+#include "wave_ops.h"
+
+#define GQN_LDS 64        // nodes of a rule kept in LDS (longer rules read the table)
+
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
+  const CurArgs& A = GA.c;
+  const LdsimConsts* c = A.c;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  GInfo* __restrict__ gip = GA.gi + pair;
+  const int status = (A.debug_phases & 0x100) ? 0 : gip->status;
+  if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
+    if (tid == 0) {
+      GA.flags[pair] = status == 2;
+      if (status == 2) atomicAdd(&A.counters[6], 1ull);
+    }
+    return;
+  }
+  const int ncol_g = gip->ncol, NJ_g = gip->NJ, u_min = gip->u_min, NU = gip->NU, ebound = gip->edge_bound, NB = gip->NB;
+  double* __restrict__ rec = GA.rec + gip->off;
+  const PairParams* __restrict__ P = GA.pp + pair;
+  const int NQ = P->NQ, iz_lo = P->iz_lo, iz_hi = P->iz_hi, it0 = P->it0, T = P->T, it_w0 = P->it_w0, it_w1 = P->it_w1;
+  const int NUr = g_nur(NU);
+
+  __shared__ double s_par[32];
+  __shared__ double s_gl[2][GQN_LDS];
+  __shared__ double s_X[G_NODES][G_XS], s_Y[G_NODES][G_YS], s_Z[G_NODES][G_ZS];
+  __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dz[ZC], s_dzs[ZC], s_zs[G_NODES];
+  __shared__ unsigned char s_invs[ZC], s_zord[ZC];
+  __shared__ int s_inval[ZC];
+  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 1], s_ustart[NU_MAX + 1];
+  __shared__ int s_misc[24], s_wcnt[NWAVE];
+  __shared__ unsigned s_cells[G_CELLCAP];
+  __shared__ double s_qpart[G_NODES][G_NODES + 1], s_Q[G_NODES];
+
+  if (tid < PP_COUNT) s_par[tid] = ((const double*)((const char*)P + 32))[tid];
+  {
+    const int64_t off = (int64_t)NQ * (NQ - 1) / 2;
+    if (tid < NQ && tid < GQN_LDS) {
+      s_gl[0][tid] = GA.glx[off + tid];
+      s_gl[1][tid] = GA.glw[off + tid];
+    }
+  }
+  __syncthreads();
+  const int NS = c->sampled_points;
+  const double bin = c->response_bin_size;
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+
+  // ---- one chunk's slices (<= 64 slices, <= 64 distinct shifts): response shift, edge flags, member lists ordered by shift.
+  // Run by one wave; results in s_dz / s_dzs / s_invs / s_inval / s_zord / s_ustart and s_misc[3..5], [20].
+  auto chunk_setup = [&](int iz_first) {
+    int nmax = min(ZC, iz_hi - iz_first + 1);
+    int sh = 0, inval = 0;
+    double dzv = 0;
+    if (lane < nmax) {
+      double z, t0;
+      bool amb;
+      sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_first + lane, z,
+                             t0, amb);
+      if (amb) atomicAdd(&A.counters[0], 1ull);
+      dzv = z - s_par[PP_SZ];
+      s_dz[lane] = dzv;
+#pragma unroll
+      for (int e = 0; e < NEDGE; e++) {
+        // a table of its own is needed only where the correlation would use this slice's weight at a tick the reference does
+        // not: the edge index inside the staged response range, reachable by this shift (an integer tick), that tick inside
+        // the stored window
+        bool need = false;
+        const int num = edge_k[e] - sh;
+        if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+          const int it_e = num / M;
+          if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+            int64_t kk;
+            need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
+          }
+        }
+        if (need) inval |= 1 << e;
+      }
+      s_inval[lane] = inval;
+    }
+    const int pmin = wave_scan_i32(lane < nmax ? sh : (1 << 30), 0x7fffffff, [](int a, int b) { return a < b ? a : b; });
+    const int pmax = wave_scan_i32(lane < nmax ? sh : -(1 << 30), (int)0x80000000, [](int a, int b) { return a > b ? a : b; });
+    bool fits = (lane < nmax) && (pmax - pmin + 1 <= NU_MAX);
+    unsigned long long fm = __ballot(fits);
+    int n = (fm == ~0ull) ? 64 : __ffsll((long long)~fm) - 1;
+    int lo = __builtin_amdgcn_readlane(pmin, n - 1), hi = __builtin_amdgcn_readlane(pmax, n - 1);
+    int posn = 0, below = 0;
+    {
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bs = lo; bs <= hi; bs++) {                    // the chunk's distinct shifts (<= NU_MAX), one ballot each
+        const unsigned long long bal = __ballot(lane < n && sh == bs);
+        const int cnt = __popcll(bal);
+        if (lane < n && sh > bs) posn += cnt;
+        if (lane < n && sh == bs) posn += __popcll(bal & lane_lt);
+        if (bs < lo + lane) below += cnt;
+      }
+    }
+    if (lane < n) {
+      s_zord[posn] = (unsigned char)lane;
+      s_dzs[posn] = dzv;
+      s_invs[posn] = (unsigned char)inval;
+    }
+    if (lane < hi - lo + 1) s_ustart[lane] = (short)below;
+    if (lane == 0) s_ustart[hi - lo + 1] = (short)n;
+    int anyinv = 0;
+#pragma unroll
+    for (int e = 0; e < NEDGE; e++)
+      if (__ballot(lane < n && (inval & (1 << e)))) anyinv |= 1 << e;
+    if (lane == 0) {
+      s_misc[3] = n; s_misc[4] = lo; s_misc[5] = hi;
+      s_misc[20] = anyinv;
+    }
+  };
+
+  // ---- sample -> response cell maps; member lists ordered by response index (x: wave 0, y: wave 1); first chunk: wave 2 ---------
+  if (wv == 0) {
+    int i = -1;
+    double ddx = 0;
+    if (lane < NS) {
+      double x = s_par[PP_X_START] + s_par[PP_SGNX] * (lane * s_par[PP_X_STEP] - 4 * s_par[PP_ST]);
+      double xd = fabs(s_par[PP_X_P] - x);
+      if (!(xd > bin * A.ni)) {
+        i = (int)py_round(xd / bin - 0.5);
+        if (i < 0 || i >= A.ni) i = -1;
+      }
+      ddx = x - s_par[PP_SX];
+    }
+    const bool valid = lane < NS && i >= 0;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    unsigned long long present = 0;
+    {
+      const int mlo = wave_lane_i32(wave_scan_i32(valid && i < 32 ? (1 << i) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      const int mhi = wave_lane_i32(wave_scan_i32(valid && i >= 32 ? (1 << (i - 32)) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      present = (unsigned long long)(unsigned)mlo | ((unsigned long long)(unsigned)mhi << 32);
+    }
+    const int slot = valid ? __popcll(present & ((1ull << i) - 1ull)) : 0;    // rank of this column's i among the distinct i
+    const int ncol = __popcll(present);
+    int posn = 0;
+    bool is_leader = false;
+    for (unsigned long long m = present; m; m &= m - 1) {
+      const int bcell = __ffsll((long long)m) - 1;
+      const unsigned long long bal = __ballot(valid && i == bcell);
+      if (valid && i > bcell) posn += __popcll(bal);
+      if (valid && i == bcell) {
+        const int before = __popcll(bal & lane_lt);
+        posn += before;
+        is_leader = before == 0;
+      }
+    }
+    if (is_leader) s_coli[slot] = (short)i;
+    if (valid) s_dxs[posn] = ddx;
+    if (is_leader) s_colstart[slot] = (short)posn;
+    int nvalid = __popcll(__ballot(valid));
+    if (lane == 0) {
+      s_colstart[ncol] = (short)nvalid;
+      s_misc[0] = ncol;
+      s_misc[18] = 0;   // overflow / inconsistency -> monolithic kernel
+    }
+  } else if (wv == 1) {
+    int j = -1;
+    double ddy = 0;
+    if (lane < NS) {
+      double y = s_par[PP_Y_START] + s_par[PP_SGNY] * (lane * s_par[PP_Y_STEP] - 4 * s_par[PP_ST]);
+      double yd = fabs(s_par[PP_Y_P] - y);
+      if (!(yd > bin * A.nj)) {
+        j = (int)py_round(yd / bin - 0.5);
+        if (j < 0 || j >= A.nj) j = -1;
+      }
+      ddy = y - s_par[PP_SY];
+    }
+    const int jmin = wave_min_i32((j >= 0) ? j : (1 << 20)), jmax = wave_max_i32(j);
+    int posn = 0, below = 0;
+    if (jmax >= jmin) {
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bj = jmin; bj <= jmax; bj++) {               // the few distinct j, one ballot each
+        const unsigned long long bal = __ballot(j == bj);
+        const int cnt = __popcll(bal);
+        if (j > bj) posn += cnt;
+        if (j == bj) posn += __popcll(bal & lane_lt);
+        if (bj < jmin + lane) below += cnt;
+      }
+    }
+    if (j >= 0) s_dys[posn] = ddy;
+    if (jmax >= jmin && lane <= jmax - jmin + 1 && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
+    if (lane == 0) {
+      s_misc[1] = jmin;
+      s_misc[2] = jmax;
+    }
+  } else if (wv == 2) {
+    chunk_setup(iz_lo);
+  }
+  __syncthreads();
+  const int ncol = s_misc[0], jmin = s_misc[1], jmax = s_misc[2];
+  const int NJ = jmax - jmin + 1;
+  const bool one_chunk = s_misc[3] >= iz_hi - iz_lo + 1;          // every slice in the chunk set up above
+  const bool chunk_ready = true;                                  // (the set-up above is the state a one-chunk pair keeps)
+  // the set-up pass sized the record from the same expressions: anything else is a bug, not a case -- flagged, recomputed by the
+  // monolithic kernel and counted
+  if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin) {
+    if (tid == 0) {
+      GA.flags[pair] = 1;
+      atomicAdd(&A.counters[6], 1ull);
+    }
+    return;
+  }
+
+  const double* gx_tab = NQ <= GQN_LDS ? (const double*)s_gl[0] : GA.glx + (int64_t)NQ * (NQ - 1) / 2;
+  const double* gw_tab = NQ <= GQN_LDS ? (const double*)s_gl[1] : GA.glw + (int64_t)NQ * (NQ - 1) / 2;
+  const bool do_prune = A.prune_log > 0;
+  // numba_f32 (kernels_qweights.hip): centres scaled by r = sigma^2 / (sigma*sigma)_f32, node factor exp(-s^2 kappa)
+  const double uxr = s_par[PP_UXR], uyr = s_par[PP_UYR], uzr = s_par[PP_UZR], i2T = s_par[PP_I2T], i2L = s_par[PP_I2L];
+  const double kappa = s_par[PP_KAPPA], s_lo = s_par[PP_S_LO], qlen = s_par[PP_QLEN], wscale = s_par[PP_WSCALE];
+  const double thr = s_par[PP_THR];
+  const unsigned long long cells_d = g_cells_doubles(ncol, NJ);
+  const unsigned long long batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
+  int emask_seen = 0;
+
+  if (A.debug_phases & 0x1000000) return;      // timing tools: stop after the maps
+  for (int b = 0; b < NB; b++) {
+    const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
+    double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[2 + e])
+    int n_cells_b = 0;
+    double* gX = brec + cells_d;
+    double* gY = gX + 16 * ncol;
+    double* gZ = gY + 16 * NJ;
+    __syncthreads();          // the previous batch's tables are no longer read
+    // ---- X and Y tables of this node batch: one task per (bin, node), node fastest ---------------------------------------------
+    {
+      const int nX = ncol * nb, nY = NJ * nb;
+      for (int task = tid; task < nX + nY && !(A.debug_phases & 0x2000000); task += CUR_THREADS) {
+        const bool isx = task < nX;
+        const int rel = isx ? task : task - nX;
+        const int bb = rel / nb, n = rel - bb * nb;
+        const double sn = s_lo + 0.5 * qlen * (1.0 + gx_tab[n0 + n]);
+        double sum = 0;
+        if (isx) {
+          const double cen = sn * uxr;
+          for (int k = s_colstart[bb]; k < s_colstart[bb + 1]; k++) {
+            const double d = s_dxs[k] - cen;
+            sum += exp_neg(-d * d * i2T);
+          }
+          s_X[n][bb] = sum;
+        } else {
+          const double cen = sn * uyr;
+          for (int k = s_jstart[bb]; k < s_jstart[bb + 1]; k++) {
+            const double d = s_dys[k] - cen;
+            sum += exp_neg(-d * d * i2T);
+          }
+          s_Y[n][bb] = sum;
+        }
+      }
+      // node rows past the batch's last node read as zero in the matrix product
+      for (int i = tid; i < (G_NODES - nb) * (ncol + NJ); i += CUR_THREADS) {
+        const int n = nb + i / (ncol + NJ), bb = i % (ncol + NJ);
+        if (bb < ncol) s_X[n][bb] = 0; else s_Y[n][bb - ncol] = 0;
+      }
+    }
+    // ---- Z tables: slices in chunks, every (shift bin, node) entry owned by one thread; shift range in parts of G_NUCAP bins
+    // (one part for all but the steepest centimetre-long segments).  e < 0: all slices (and the per-node totals for the cell
+    // test); e >= 0: the slices that are invalid at window edge e.
+    auto ztable = [&](int e, double* gdst) {      // gdst: Z[16][NUr] (e < 0) or the correction row C[NUr] of edge e
+      for (int pu0 = 0; pu0 < NU; pu0 += G_NUCAP) {
+        const int pw = min(G_NUCAP, NUr - pu0);                  // columns of this part incl. the zero padding to 16
+        __syncthreads();
+        for (int i = tid; i < G_NODES * pw; i += CUR_THREADS) s_Z[i / pw][i % pw] = 0;
+        for (int iz_next = iz_lo; iz_next <= iz_hi;) {
+          __syncthreads();
+          if (!(one_chunk && chunk_ready)) {
+            if (wv == 0) chunk_setup(iz_next);
+            __syncthreads();
+          }
+          const int n_sl = s_misc[3], lo_c = s_misc[4];
+          const int NUc = s_misc[5] - lo_c + 1;
+          if (e < 0) emask_seen |= s_misc[20];
+          if ((e < 0 || (s_misc[20] & (1 << e))) && !(A.debug_phases & 0x4000000)) {
+            for (int task = tid; task < NUc * nb; task += CUR_THREADS) {
+              const int bb = task / nb, n = task - bb * nb;
+              const int ub = lo_c - u_min + bb - pu0;
+              if (ub < 0 || ub >= G_NUCAP) continue;
+              const double sn = s_lo + 0.5 * qlen * (1.0 + gx_tab[n0 + n]);
+              const double cen = sn * uzr;
+              double sum = 0;
+              for (int k = s_ustart[bb]; k < s_ustart[bb + 1]; k++) {
+                if (e < 0 || (s_invs[k] & (1 << e))) {
+                  const double d = s_dzs[k] - cen;
+                  sum += exp_neg(-d * d * i2L);
+                }
+              }
+              double wn = wscale * gw_tab[n0 + n];
+              if (kappa != 0.0) wn *= exp_neg(-sn * sn * kappa);
+              s_Z[n][ub] += wn * sum;
+            }
+          }
+          iz_next += n_sl;
+        }
+        __syncthreads();
+        if (e < 0) {
+          for (int i = tid; i < G_NODES * pw; i += CUR_THREADS) gdst[(i / pw) * NUr + pu0 + i % pw] = s_Z[i / pw][i % pw];
+          if (tid < G_NODES) {
+            double t = pu0 ? s_zs[tid] : 0.0;
+            for (int u = 0; u < pw; u++) t += s_Z[tid][u];
+            s_zs[tid] = t;
+          }
+        } else {
+          // C_e[u] = sum_n Zi_e[n][u] G_n[edge_k[e]]: what gcorr_kernel takes back from tick (edge_k[e] - u_min - u) / M
+          for (int u = tid; u < pw; u += CUR_THREADS) {
+            double cv = 0;
+            for (int n = 0; n < nb; n++) cv = fma(s_Z[n][u], s_Q[n], cv);
+            gdst[pu0 + u] = cv;
+          }
+        }
+      }
+    };
+    ztable(-1, gZ);
+    __syncthreads();
+    // ---- tables to the record -----------------------------------------------------------------------------------------------------
+    for (int i = tid; i < G_NODES * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
+    for (int i = tid; i < G_NODES * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
+    // ---- cells that can carry weight: sum over the nodes and all shifts of X Y Z above the pruning threshold (every
+    // (cell, shift) bin the weight kernels would keep lies in such a cell); list in (column, j) order ------------------------------------
+    {
+      const int ncand = ncol * NJ;
+      int base = 0;
+      for (int c0 = 0; c0 < ncand && !(A.debug_phases & 0x8000000); c0 += CUR_THREADS) {
+        const int cc = c0 + tid;
+        bool keep = false;
+        int col = 0, jj = 0;
+        if (cc < ncand) {
+          col = cc / NJ; jj = cc - col * NJ;
+          double w = 0;
+#pragma unroll 4
+          for (int n = 0; n < G_NODES; n++) w = fma(s_X[n][col] * s_Y[n][jj], s_zs[n], w);
+          keep = do_prune ? w > thr : w != 0.0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wv; w++) before += s_wcnt[w];
+        if (keep) {
+          const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+          const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
+          cells[2 + pos] = (int)ce;
+          s_cells[pos] = ce;
+        }
+        base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+      }
+      const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
+      if (tid < padded - base) cells[2 + base + tid] = (int)0x80000000u;      // dummy: row 0 of the table, weight 0
+      if (tid == 0) { cells[0] = padded; cells[1] = base; }
+      n_cells_b = base;
+    }
+    // ---- window edges some slice of the pair is invalid at (detsim.py:418-428): the correlation uses every slice's weight at
+    // every tick; here the invalid slices' share of the one tick an edge maps to is computed -- their Z sums (the same table
+    // code over those slices only) times G_n[edge_k] = sum_cells X_n Y_n R[cell][edge_k] over the listed cells -- for gcorr_kernel
+    // to take back.
+    {
+      int et = 0;
+      for (int e = 0; e < NEDGE; e++) {
+        if (!(ebound & (1 << e))) continue;
+        double* gC = gZ + 16ull * NUr + (unsigned long long)et * NUr;
+        et++;
+        __syncthreads();
+        {
+          const int n = tid & 15, ch = tid >> 4;
+          double part = 0;
+          for (int i = ch; i < n_cells_b; i += 16) {
+            const unsigned ce = s_cells[i];
+            const double r = A.resp[(int64_t)(ce & 0xFFFFu) * A.nk + edge_k[e]];
+            part = fma(s_X[n][(ce >> 16) & 63u] * s_Y[n][(ce >> 24) & 63u], r, part);
+          }
+          s_qpart[n][ch] = part;
+        }
+        __syncthreads();
+        if (tid < G_NODES) {
+          double q = 0;
+          for (int ch = 0; ch < 16; ch++) q += s_qpart[tid][ch];
+          s_Q[tid] = q;
+        }
+        ztable(e, gC);       // (its first barrier orders s_Q)
+      }
+    }
+  }
+  if (tid == 0) {
+    gip->emask = emask_seen & ebound;
+    GA.flags[pair] = 0;
+    atomicAdd(&A.counters[1], (unsigned long long)NQ);
+  }
+}
+
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M) {
+  if (GA.c.n_pairs == 0) return 0;
+  if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)GA.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, GA);
+  else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)GA.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, GA);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -362,10 +362,11 @@ __global__ void __launch_bounds__(256) pad_response_kernel(const double* __restr
   out[i] = (k >= k_lo && k <= k_hi && k >= 0 && k < nk) ? resp[c * nk + k] : 0.0;
 }
 
-extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S, int M) {
-  const CurArgs& A = S.c;
+// The zero-padded copy of the response rows (mac_shift kernels, gcorr_kernel): rebuilt when the table or the staged range --
+// the part of the table's support a tick of a window can meet, incl. the partially valid edges (mac_kernel's staging,
+// kernels_split.hip) -- changes.
+extern "C++" int resp_pad_ensure(ldsim_ctx* ctx, const CurArgs& A, int* k_lo_out, int* k_hi_out, int* nkp_out) {
   const LdsimConsts& h = ctx->h_consts;
-  // the staged range of mac_kernel (kernels_split.hip): response support met by the window, incl. the partially valid edges
   const int k_lo = A.k_first > 0 ? A.k_first : 0;
   int k_hi;
   {
@@ -390,6 +391,15 @@ extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S, int M) {
     ctx->resp_pad_lo = k_lo;
     ctx->resp_pad_hi = k_hi;
   }
+  *k_lo_out = k_lo; *k_hi_out = k_hi; *nkp_out = nkp;
+  return 0;
+}
+
+extern "C++" int mac_shift_launch(ldsim_ctx* ctx, SplitArgs S, int M) {
+  const CurArgs& A = S.c;
+  int k_lo, k_hi, nkp;
+  int rc = resp_pad_ensure(ctx, A, &k_lo, &k_hi, &nkp);
+  if (rc) return rc;
   S.resp_pad = (const double*)ctx->resp_pad.p;
   S.nkp = nkp;
   S.k_lo = k_lo;

@@ -6,18 +6,21 @@
 // qweights_kernel (a 256-thread workgroup per pair) used to repeat this in each of its four waves; here 64 different pairs
 // share a wave.  (A wave-per-pair form of the whole weights stage was tried on top of this record and measured slower:
 // DESIGN.md section 4, profiles/r02_qwave_phase_timing.log.)
-#include "qpair.h"
+#include "gform.h"
 
 // =============================================================================================================
 template <int M>
 __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams* __restrict__ pp, int qn_max, double qn0,
-                                                         double qslope) {
+                                                         double qslope, GInfo* __restrict__ gi) {
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (pair >= A.n_pairs) return;
   PairParams P;
   memset(&P, 0, sizeof(P));
+  GInfo Gi;
+  memset(&Gi, 0, sizeof(Gi));
+  if (gi) gi[pair] = Gi;            // overwritten below when the pair has something to compute
   int64_t seg, pID;
   pair_ids(A, pair, seg, pID);
   int T = A.T;
@@ -29,18 +32,20 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   const double dt = c->time_sampling, bin = c->response_bin_size;
   // valid samples of either axis (inside the response table) and their extent relative to the segment start
   double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+  unsigned long long i_present = 0;     // response columns i that hold a sample (ni <= 64), and the j range
+  int j_lo = 1 << 20, j_hi = -1;
   for (int s = 0; s < NS; s++) {
     const double x = g.x_start + g.sgnx * (s * g.x_step - 4 * g.sT);
     const double xd = fabs(g.x_p - x);
     if (!(xd > bin * A.ni)) {
       const int i = (int)py_round(xd / bin - 0.5);
-      if (i >= 0 && i < A.ni) { xlo = fmin(xlo, x - g.sx); xhi = fmax(xhi, x - g.sx); }
+      if (i >= 0 && i < A.ni) { xlo = fmin(xlo, x - g.sx); xhi = fmax(xhi, x - g.sx); i_present |= 1ull << i; }
     }
     const double y = g.y_start + g.sgny * (s * g.y_step - 4 * g.sT);
     const double yd = fabs(g.y_p - y);
     if (!(yd > bin * A.nj)) {
       const int j = (int)py_round(yd / bin - 0.5);
-      if (j >= 0 && j < A.nj) { ylo = fmin(ylo, y - g.sy); yhi = fmax(yhi, y - g.sy); }
+      if (j >= 0 && j < A.nj) { ylo = fmin(ylo, y - g.sy); yhi = fmax(yhi, y - g.sy); j_lo = min(j_lo, j); j_hi = max(j_hi, j); }
     }
   }
   if (xhi < xlo || yhi < ylo) { pp[pair] = P; return; }
@@ -125,12 +130,49 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   P.wscale = factor * g.dV * 0.5 * qlen;
   P.thr = A.prune_log > 0 ? exp(-A.prune_log) * factor * g.dV * peak_len : 0.0;
   pp[pair] = P;
+  if (!gi) return;
+  // ---- node-separable form (gform.h): what sizes the pair's record, and whether the pair fits its kernels ---------------
+  Gi.ncol = __popcll(i_present);
+  Gi.NJ = j_hi - j_lo + 1;
+  Gi.jmin = j_lo;
+  Gi.u_min = sh_min;
+  Gi.NU = sh_max - sh_min + 1;
+  Gi.NB = (P.NQ + G_NODES - 1) / G_NODES;
+  Gi.status = P.status;
+  Gi.NQ = P.NQ; Gi.it0 = it0; Gi.T = T; Gi.it_w0 = it_w0; Gi.it_w1 = it_w1;
+  if (P.status == 1 && (Gi.ncol > G_NCOL || Gi.NJ > NJ_MAX || Gi.ncol * Gi.NJ > G_CELLCAP - G_CELLPAD)) {
+    Gi.status = 2;
+    pp[pair].status = 2;
+  }
+  if (Gi.status == 1) {
+    // the window edges that need a table of their own: a slice's weight would be used at a tick where the reference does not
+    // use it (the predicates of qweights_kernel's chunk set-up)
+    int eb = 0;
+    for (int iz = iz_lo; iz <= iz_hi; iz++) {
+      double z, t0;
+      bool amb;
+      const int sh = slice_shift_of<M>(c, g.z_start_int, g.z_step, g.z_anode, g.t_start, iz, z, t0, amb);
+      for (int e = 0; e < NEDGE; e++) {
+        const int num = edge_k[e] - sh;
+        if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+          const int it_e = num / M;
+          if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+            int64_t kk;
+            if (!(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e])) eb |= 1 << e;
+          }
+        }
+      }
+    }
+    Gi.edge_bound = eb;
+    Gi.size = g_record_doubles(Gi.NB, Gi.ncol, Gi.NJ, Gi.NU, eb);
+  }
+  gi[pair] = Gi;
 }
 
 extern "C++" size_t qpair_params_bytes(int64_t n_pairs) { return (size_t)n_pairs * sizeof(PairParams); }
 
 // the per-pair records of both quadrature weight kernels
-extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params) {
+extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params, void* ginfo) {
   if (S.c.n_pairs == 0) return 0;
   if (!ctx->d_glx || !ctx->d_glw || !params) {
     ldsim_set_error("Gauss-Legendre tables / pair parameter buffer missing");
@@ -138,9 +180,11 @@ extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, v
   }
   PairParams* pp = (PairParams*)params;
   const unsigned g0 = (unsigned)((S.c.n_pairs + 255) / 256);
+  GInfo* gi = (GInfo*)ginfo;
   if (M == 1) hipLaunchKernelGGL(pair_setup_kernel<1>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0,
-                                 ctx->quad_slope);
-  else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0, ctx->quad_slope);
+                                 ctx->quad_slope, gi);
+  else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0, ctx->quad_slope,
+                          gi);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -241,17 +241,24 @@ extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
   return 0;
 }
 
+static void resp_support_update(ldsim_ctx* ctx);
+
 extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) {
   NEED(ctx && name, "null argument");
   if (!strcmp(name, "prune_log")) ctx->prune_log = value;
   else if (!strcmp(name, "tail_log")) ctx->tail_log = value;
   else if (!strcmp(name, "trim_response")) ctx->trim_response = value != 0;
+  else if (!strcmp(name, "trim_response_log")) {
+    if (!(value >= 0)) { ldsim_set_error("trim_response_log must be >= 0"); return LDSIM_EINVAL; }
+    ctx->trim_response_log = value;
+    if (!ctx->h_resp_kmax.empty()) resp_support_update(ctx);
+  }
   else if (!strcmp(name, "debug_phases")) ctx->debug_phases = (int)value;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
   else if (!strcmp(name, "weights_mode")) {
-    if (!(value == 0 || value == 1)) { ldsim_set_error("weights_mode must be 0 or 1"); return LDSIM_EINVAL; }
+    if (!(value == 0 || value == 1 || value == 2)) { ldsim_set_error("weights_mode must be 0, 1 or 2"); return LDSIM_EINVAL; }
     ctx->weights_mode = (int)value;
     ctx->wbuf_learned = 0;
   }
@@ -326,6 +333,22 @@ extern "C" int ldsim_clear_pixel_tables(ldsim_ctx* ctx) {
   return 0;
 }
 
+// Ticks of the response table that are read: [first, last] of the entries above the trim threshold -- exp(-trim_response_log)
+// of the table's largest entry (default exp(-23) = 1e-10, the level the weights are pruned at; 0 = exact zeros only).  The
+// ticks outside contribute less than that fraction of a waveform's peak, below the f4 resolution of the stored currents.
+static void resp_support_update(ldsim_ctx* ctx) {
+  const int nk = (int)ctx->h_resp_kmax.size();
+  double vmax = 0;
+  for (double v : ctx->h_resp_kmax) vmax = v > vmax ? v : vmax;
+  const double thr = ctx->trim_response_log > 0 ? exp(-ctx->trim_response_log) * vmax : 0.0;
+  int first = 0, last = nk - 1;
+  while (first < nk && !(ctx->h_resp_kmax[first] > thr)) first++;
+  while (last >= first && !(ctx->h_resp_kmax[last] > thr)) last--;
+  if (last < first) { first = 0; last = -1; }
+  ctx->resp_k_first = first;
+  ctx->resp_k_last = last;
+}
+
 extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_t ni, int32_t nj, int32_t nk) {
   NEED(ctx && response && ni > 0 && nj > 0 && nk > 0, "bad response table");
   HIPCHK(hipSetDevice(ctx->device));
@@ -334,20 +357,16 @@ extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_
   HIPCHK(hipMalloc((void**)&ctx->d_resp, bytes));
   HIPCHK(hipMemcpy(ctx->d_resp, response, bytes, hipMemcpyHostToDevice));
   ctx->ni = ni; ctx->nj = nj; ctx->nk = nk;
-  // support of the table along k over all cells: entries that are exactly 0.0 for every (i, j)
-  int first = nk, last = -1;
+  // largest |entry| of every tick over all cells: the support of the table along k follows from it for any trim threshold
+  ctx->h_resp_kmax.assign((size_t)nk, 0.0);
   for (int64_t c = 0; c < (int64_t)ni * nj; c++) {
     const double* row = response + c * nk;
-    int f = 0;
-    while (f < first && row[f] == 0.0) f++;
-    if (f < first) first = f;
-    int l = nk - 1;
-    while (l > last && row[l] == 0.0) l--;
-    if (l > last) last = l;
+    for (int k = 0; k < nk; k++) {
+      const double v = fabs(row[k]);
+      if (v > ctx->h_resp_kmax[k]) ctx->h_resp_kmax[k] = v;      // (NaN entries never raise a maximum: such ticks count as empty)
+    }
   }
-  if (last < first) { first = 0; last = -1; }
-  ctx->resp_k_first = first;
-  ctx->resp_k_last = last;
+  resp_support_update(ctx);
   ctx->resp_pad_hi = -2;                     // the padded copy of mac_shift_kernel is rebuilt on the next launch
   return 0;
 }

@@ -120,11 +120,13 @@ struct ldsim_ctx {
   double prune_log = 23.0;                   // exp(-23) = 1e-10 of the pair's peak weight, the accuracy the node rule is fitted for
   double tail_log = 14.0;
   int trim_response = 1;
+  double trim_response_log = 23.0;           // response ticks below exp(-v) of the table's largest entry are not read (0: exact zeros only)
+  std::vector<double> h_resp_kmax;           // largest |entry| of every response tick over all cells (host)
   int debug_phases = 15;
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
   int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
   int split_max_items = 0;          // validation knob, see CurArgs
-  int weights_mode = 1;             // split path, weights stage: 1 = qweights_kernel (Gauss-Legendre along the segment), 0 = weights_kernel (per-sample closed form)
+  int weights_mode = 2;             // split path: 2 = node-separable form (gtables_kernel + gcorr_kernel, gform.h), 1 = qweights_kernel (Gauss-Legendre along the segment) + mac kernel, 0 = weights_kernel (per-sample closed form) + mac kernel
   int mc_current = 0;               // 1: the chain's induced currents come from current_mc_kernel (tracks_current_mc) instead of tracks_current
   int numba_f32 = 0;                // 1: evaluate the sub-expressions Numba types f32 for f4 record fields in float
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2

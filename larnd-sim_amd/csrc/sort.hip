@@ -158,6 +158,17 @@ int sort_exclusive_scan_i32(ldsim_ctx* ctx, const int32_t* in, int32_t* out, int
   return 0;
 }
 
+int sort_exclusive_scan_u64(ldsim_ctx* ctx, const unsigned long long* in, unsigned long long* out, int64_t n) {
+  if (n == 0) return 0;
+  size_t tmp = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, tmp, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, tmp);
+  if (rc) return rc;
+  HIPCHK(rocprim::exclusive_scan(ctx->scratch[SB_SORTTMP].p, tmp, in, out, 0ull, (size_t)n,
+                                 rocprim::plus<unsigned long long>(), ctx->stream));
+  return 0;
+}
+
 int sort_heads(ldsim_ctx* ctx, const unsigned long long* keys, int64_t n_valid, int32_t* heads) {
   if (n_valid == 0) return 0;
   hipLaunchKernelGGL(heads_kernel, dim3(nblk(n_valid, 256)), dim3(256), 0, ctx->stream, keys, n_valid, heads);

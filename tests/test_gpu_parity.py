@@ -143,7 +143,8 @@ def test_pixels_time_intervals_golden(cfg):
 # correlation).  Every per-tick test runs through all of them; ldsim_tracks_current_stats tells which kernels really ran.
 CURRENT_PATHS = {"mono": dict(split_kernels=0),
                  "closed": dict(split_kernels=1, weights_mode=0, mac_mode=0),
-                 "quad": dict(split_kernels=1, weights_mode=1, mac_mode=1)}
+                 "quad": dict(split_kernels=1, weights_mode=1, mac_mode=1),
+                 "gform": dict(split_kernels=1, weights_mode=2)}
 
 
 def _tracks_current_on(path, neigh, r, resp, T, **extra):
@@ -161,7 +162,7 @@ def _tracks_current_on(path, neigh, r, resp, T, **extra):
     if path == "mono":
         assert st.n_wbuf == 0 and st.n_fallback == 0
     else:
-        assert st.n_wbuf > 0, "the split path's weights stage did not run"
+        assert st.n_wbuf > 0, "the split path's tables / weights stage did not run"
     return sig, st
 
 
@@ -222,7 +223,8 @@ def test_tracks_current_vs_oracle_full_ticks(path):
 
 
 @pytest.mark.parametrize("cfg", ["module0", "ndlar"])
-def test_tracks_current_length_sweep_vs_oracle(cfg):
+@pytest.mark.parametrize("path", ["gform", "quad"])
+def test_tracks_current_length_sweep_vs_oracle(cfg, path):
     """Segment length from 0 to 165 Gaussian widths along the segment (r), a few hundred micrometres to a centimetre from
     the anode where sigma_T -> 0: the quadrature's node rule N = ceil(4.8 + 1.6 r) on both sides of the 64-node LDS copy
     (r = 37) and of the 256-node cap (r = 157, beyond it the monolithic kernel takes the pair), every tick against the
@@ -278,7 +280,7 @@ def test_tracks_current_length_sweep_vs_oracle(cfg):
         assert (err <= tol).all(), f"{what}: max excess {np.max(err - tol)} at {np.unravel_index(np.argmax(err - tol), err.shape)}"
     pair_peak = np.abs(ref).max(axis=-1, keepdims=True)
     charge_scale = r["n_electrons"].astype(np.float64)[:, None, None] * np.abs(resp).max()
-    sig, st = _tracks_current_on("quad", neigh, r, resp, T)
+    sig, st = _tracks_current_on(path, neigh, r, resp, T)
     close(sig, charge_scale, f"length sweep {cfg}")
     main = pair_peak >= 1e-5 * charge_scale
     assert main.sum() > 2 * len(rs) * len(dists)
@@ -287,12 +289,12 @@ def test_tracks_current_length_sweep_vs_oracle(cfg):
     # both sides of the cap were met: some pairs went to the monolithic kernel, most did not
     assert 0 < st.n_fallback < 0.5 * live.sum()
     # ... with the cap lowered to 40 nodes more pairs take the monolithic kernel: the same waveforms
-    sig2, st2 = _tracks_current_on("quad", neigh, r, resp, T, quad_max_nodes=40)
+    sig2, st2 = _tracks_current_on(path, neigh, r, resp, T, quad_max_nodes=40)
     close(sig2, charge_scale, f"length sweep {cfg}, 40-node cap")
     assert st2.n_fallback > st.n_fallback
     # ... and with every weight kept, the per-pair tolerance for every pair down to 1e-12 of the charge scale (below that
     # the pairs that overflow to the monolithic kernel show the cancellation noise of its erf differences: 1e-16 absolute)
-    sig3, st3 = _tracks_current_on("quad", neigh, r, resp, T, prune_log=0.0)
+    sig3, st3 = _tracks_current_on(path, neigh, r, resp, T, prune_log=0.0)
     deep = pair_peak >= 1e-12 * charge_scale
     assert deep.sum() > main.sum()
     close(np.where(deep, sig3, ref), pair_peak, f"length sweep {cfg}, prune_log 0")
@@ -1544,14 +1546,14 @@ def _two_event_set(cfg, seed, n=1200):
 
 
 def _reset_current_options():
-    for name, v in (("split_kernels", 1), ("weights_mode", 1), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
+    for name, v in (("split_kernels", 1), ("weights_mode", 2), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
                     ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 23.0), ("mac_mode", 1),
                     ("quad_accuracy_log10", 10)):
         lib.set_option(name, v)
 
 
 @pytest.mark.parametrize("cfg,kind", [("module0", "dense"), ("ndlar", "golden")])
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [2, 1, 0])
 def test_split_kernels_equal_monolithic(cfg, kind, mode):
     """weights stage + mac_kernel (default) vs the monolithic current_kernel on 2 x 600 segments, for both weights stages
     (weights_mode 1 = qweights_kernel, Gauss-Legendre along the segment; 0 = weights_kernel, the closed form per sample):
@@ -1573,9 +1575,9 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
             res[name] = ch.download()
             if name == "split":
                 assert st.n_fallback < 0.01 * st.n_pairs
-            if name == "tiny":
+            if name == "tiny" and mode != 2:
                 assert st.n_wbuf > 50 * st.n_pairs        # the pool was grown past its initial budget
-            if name == "capped":
+            if name == "capped" and mode != 2:            # (the node-separable form has no weight pool and no item lists)
                 assert st.n_fallback > 0.2 * st.n_pairs   # the fallback really carried a good share
     finally:
         _reset_current_options()
@@ -1653,12 +1655,14 @@ def test_mac_shift_kernel_is_bitwise_the_lds_kernel(cfg, kind):
     ch.quench_drift()
     res = {}
     try:
+        lib.set_option("weights_mode", 1)              # the weights stage whose pool and item lists these kernels read
         for mode in (1, 0):
             lib.set_option("mac_mode", mode)
-            ch.run(0, len(seg), want_fractions=True)
+            st = ch.run(0, len(seg), want_fractions=True)
+            assert st.n_dfma > 0 and st.n_wbuf > 0
             res[mode] = ch.download()
     finally:
-        lib.set_option("mac_mode", 1)
+        _reset_current_options()
     assert (res[1]["adc_list"] != 0).sum() > 100
     for k in res[1]:
         assert np.array_equal(res[1][k], res[0][k]), k
@@ -1667,8 +1671,10 @@ def test_mac_shift_kernel_is_bitwise_the_lds_kernel(cfg, kind):
 
 
 @pytest.mark.parametrize("cfg,kind", [("module0", "survey"), ("ndlar", "golden")])
-def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
-    """qweights_kernel hands pairs that need more Gauss-Legendre nodes than "quad_max_nodes" to the monolithic kernel
+@pytest.mark.parametrize("wmode", [2, 1])
+def test_quadrature_weights_node_cap_and_pruning(cfg, kind, wmode):
+    """The quadrature stages (weights_mode 2: gtables_kernel + gcorr_kernel, the default; 1: qweights_kernel + the shifted-window
+    correlation) hand pairs that need more Gauss-Legendre nodes than "quad_max_nodes" to the monolithic kernel
     (the shipped cap of 256 covers segments up to ~130 Gaussian widths long): with a cap of 12 most pairs go that way and
     the result must not change; prune_log = 0 (every bin kept) must not change it either; and two runs are bitwise equal."""
     seg, bid = _two_event_set(cfg, 37)
@@ -1677,6 +1683,7 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
     ch.quench_drift()
     res = {}
     try:
+        lib.set_option("weights_mode", wmode)
         for name, cap, prune in (("default", 256, 23.0), ("again", 256, 23.0), ("cap12", 12, 23.0), ("keepall", 256, 0.0),
                                  ("acc12", 256, 23.0), ("prune30", 256, 30.0)):
             lib.set_option("quad_max_nodes", cap)
@@ -1687,8 +1694,10 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
             if name == "default":
                 assert st.n_fallback < 0.01 * st.n_pairs
                 assert 6 <= st.n_samples / st.n_pairs < 64       # n_samples counts quadrature nodes in this mode
-                # of the issued FMA lanes, the ones that are neither block padding nor outside the pair's window
-                assert 0.2 * st.n_dfma < st.n_dfma_useful <= st.n_dfma
+                # of the issued FMA lanes, the ones that are neither padding (8-shift blocks and the 512-tick tile of the
+                # shifted-window kernels -- a window of the survey table fills a fifth of a tile once the ticks below 1e-10 of
+                # the table's peak are not read; nodes to 16, cells to 4, ticks to 16 in the matrix form) nor outside the window
+                assert (0.1 if wmode == 1 else 0.3) * st.n_dfma < st.n_dfma_useful <= st.n_dfma
             if name == "cap12":
                 assert st.n_fallback > 0.3 * st.n_pairs
     finally:
@@ -1713,7 +1722,7 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind):
         np.testing.assert_allclose(b["current_fractions"], a["current_fractions"], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [2, 1, 0])
 def test_numba_f32_typing_mode_vs_oracle(mode):
     """Option "numba_f32": the sub-expressions Numba types float32 for f4 record fields (detsim.py:74-79,116-118,141,387)
     are evaluated in float, in both weights stages and the monolithic kernel; checked against the oracle's switch
@@ -1738,8 +1747,12 @@ def test_numba_f32_typing_mode_vs_oracle(mode):
     try:
         lib.set_option("numba_f32", 1)
         got = np.zeros_like(typed)
-        detsim.tracks_current[1, 1](got, neigh, ref, response)       # monolithic kernel (materialising stage call)
-        H.assert_wave_close(got, typed, what="numba_f32 stage call")
+        for split in (0, 1):                             # the monolithic kernel, then the weights stage under test
+            lib.set_option("split_kernels", split)
+            lib.set_option("weights_mode", mode)
+            detsim.tracks_current[1, 1](got, neigh, ref, response)
+            H.assert_wave_close(got, typed, what=f"numba_f32 stage call, split_kernels {split}")
+            assert (detsim.tracks_current_stats().n_wbuf > 0) == bool(split)
         # fused chain (weights stage `mode` + mac_kernel) on the same records: compare the pixel charges with a chain
         # assembled from the typed oracle waveforms
         lib.set_option("weights_mode", mode)

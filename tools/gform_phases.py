@@ -1,0 +1,29 @@
+"""Where the time of gtables_kernel / gcorr_kernel goes, by switching parts off (results are wrong in those runs).
+gcorr: 0x100000 no tile loop (prologue + combine + store), 0x200000 no P step, 0x400000 every cell reads response row 0,
+0x800000 no G products.  gtables: 0x1000000 stop after the sample maps, 0x2000000 no X / Y tables, 0x4000000 no Z tables,
+0x8000000 no cell list."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "larnd-sim_amd"), REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "tools")):
+    sys.path.insert(0, p)
+from larndsim_amd import lib, synth          # noqa: E402
+from larndsim_amd.chain import ChargeChain   # noqa: E402
+import helpers as H                          # noqa: E402
+from qweights_check import prepared          # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "module0"
+resp = sys.argv[2] if len(sys.argv) > 2 else "survey"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+seg, bid = prepared(cfg, n, synth.SEED_BASE + 2, 5000)
+ch = ChargeChain(H.response_for(resp))
+ch.upload(seg, bid)
+ch.quench_drift()
+ch.run(0, len(seg), want_fractions=True)
+for mask in (0, 0x100000, 0x200000, 0x400000, 0x800000, 0xA00000, 0x1000000, 0x2000000, 0x4000000, 0x6000000, 0x8000000, 0xE000000, 0):
+    lib.set_option("debug_phases", 15 | mask)
+    st = ch.run(0, len(seg), want_fractions=True)
+    ms = ch.kernel_ms()
+    print(f"{cfg} {resp} debug_phases {mask:#10x}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
+lib.set_option("debug_phases", 15)
