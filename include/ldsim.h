@@ -137,7 +137,10 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * the monolithic kernel; 0 = the built-in capacity: 512 items at TIME_SAMPLING/RESPONSE_SAMPLING = 1, 2048 at 2),
  * "weights_mode" (split path: 2 = node-separable form, gtables_kernel + gcorr_kernel: the quadrature's tables correlated on the
  * f64 matrix pipe, no weight pool ("mac_mode" does not apply); 1 = qweights_kernel, Gauss-Legendre quadrature along the
- * segment, then the correlation kernel of "mac_mode"; 0 = weights_kernel, the closed form per charge sample), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
+ * segment, then the correlation kernel of "mac_mode"; 0 = weights_kernel, the closed form per charge sample),
+ * "gform_max_support" (weights_mode 2 runs the node-separable form for response tables whose staged support is at most this
+ * many time ticks, default 768, and the kernels of weights_mode 1 for wider ones: the matrix form pays per response tick, the
+ * shifted-window kernels per 512-tick tile; 0 = never, 1e9 = always), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
  * "quad_accuracy_log10" (qweights_kernel: node count for a quadrature error of 1e-10 (default) or 1e-12 of the peak weight),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows
@@ -362,6 +365,17 @@ int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, 
 int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch, double* adc_list,
                                double* adc_ticks, double* adc_digit, int64_t* track_pixel_map, double* fractions);
 int ldsim_chain_download_wait(ldsim_ctx* ctx);
+/* The same results in compact form: what the exporter reads (fee.export_to_hdf5, fee.py:143-344: the pixels that hold a hit, their
+ * slots up to the first ADC at the pedestal, the fractions of the track slots the pixel has) gathered in HBM, a few MB instead of
+ * the dense arrays' 13 KB per unique pixel.  ldsim_chain_compact_build: sizes[4] = hit pixels, hits, track entries (sum over
+ * hit pixels of their filled track_pixel_map slots), fraction entries (sum over hits of their pixel's track slots; 0 without
+ * want_fractions).  ldsim_chain_compact_download: hit_pixels [n_hp][5] i32 = {row in the dense arrays, pixel id, batch, hits,
+ * track slots}, hit pixels in row order; track_segments i64, the filled track_pixel_map entries pixel after pixel; hit_rows
+ * [n_hits] 24-byte rows {batch i32, pixel i32, ADC code i32, slot i32, tick f64} and hit_charge f64 (adc_list) in the same
+ * order (pixel after pixel, slot 0 up); fractions f64: per hit, one value per track slot of its pixel.  Any pointer may be NULL. */
+int ldsim_chain_compact_build(ldsim_ctx* ctx, int64_t* sizes);
+int ldsim_chain_compact_download(ldsim_ctx* ctx, int32_t* hit_pixels, int64_t* track_segments, void* hit_rows,
+                                 double* hit_charge, double* fractions);
 /* Device pointers of the last chain call's compact hit list (for a collective without a host round trip):
  * hits are (batch i32, pixel i32, adc u8-as-i32, tick f64) rows for every written ADC slot. */
 int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes);

@@ -558,17 +558,22 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             r["event_id"] = np.array([t[0] for t in table])[r["batch"]]
             parts.append(r)
 
-    # launch k's rows cross PCIe on the library's copy stream (download_async) while its packets' predecessor, launch k - 1,
-    # is turned into packets here; the arrays of a launch are complete once the next download_async (or the final wait) returns
-    # (page-locking the two sets of host arrays costs ~0.5 s: worth it from about eight launches on; shorter runs copy each
-    # launch's rows synchronously into ordinary arrays)
-    overlapped = (nsim >= 8 * chunk_segments) if overlap_downloads is None else bool(overlap_downloads)
+    # What crosses PCIe per launch: the compact form (hit pixels, hits, per-hit fractions: ldsim_chain_compact_*), expanded on the
+    # host to the dense rows of the hit pixels -- the only rows the exporter reads.  --raw_arrays wants every unique pixel's
+    # arrays and takes the dense download: launch k's rows then travel on the library's copy stream (download_async) while
+    # launch k - 1's packets are built (page-locking the two sets of host arrays costs ~0.5 s: from about eight launches on).
+    from larndsim_amd.chain import expand_compact
+    overlapped = raw_arrays and ((nsim >= 8 * chunk_segments) if overlap_downloads is None else bool(overlap_downloads))
     b = 0
     in_flight = None
     for e in edges[1:]:
         if not (e - b >= chunk_segments or e == nsim):
             continue
         chain.run(int(b), int(e), want_fractions=True)
+        if not raw_arrays:
+            export_chunk(expand_compact(chain.download_compact()))
+            b = e
+            continue
         if not overlapped:
             export_chunk(chain.download())
             b = e

@@ -59,7 +59,15 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
   *split_timed = false;
   size_t ib = 0, hb = 0, cb = 0;
   if (ctx->mc_current) return current_mc_launch(ctx, a, n_seg);   // the driver's call site (cli/simulate_pixels.py:1016)
-  if (ctx->split_kernels && ctx->weights_mode == 2 && n_valid > 0) {
+  // The node-separable form pays per response tick of the staged support (16 nodes x cells x ticks on the matrix pipe), the
+  // shifted-window kernels per 512-tick tile: a table whose support is a few hundred ticks (the survey table) is 2x faster in
+  // the former, one with full support (no exact zeros over ~2000 ticks) 20 % faster in the latter -- measured, DESIGN.md
+  // section 4.  "gform_max_support" (ticks of TIME_SAMPLING) is where the default hands over; weights_mode 1 / 0 force the
+  // shifted-window path, a huge gform_max_support forces the matrix form.
+  const int M_ratio = (int)llround(ctx->h_consts.time_sampling / ctx->h_consts.response_sampling);
+  const int support_ticks = (a.k_last - a.k_first + 1) / (M_ratio > 0 ? M_ratio : 1);
+  const bool use_gform = ctx->weights_mode == 2 && support_ticks <= ctx->gform_max_support;
+  if (ctx->split_kernels && use_gform && n_valid > 0) {
     // node-separable form (gform.h): tables, then the correlation on the matrix pipe; no weight pool, no repeat launches
     int32_t* flags = nullptr;
     int rc = gform_launch(ctx, a, counters, &flags);

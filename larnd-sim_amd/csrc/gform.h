@@ -17,7 +17,7 @@
 #define G_YS 49
 #define G_NUCAP 128         // response shifts of a pair whose Z table the kernels hold in LDS at once (more: in parts / from L2)
 #define G_ZS (G_NUCAP + 16) // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
-#define G_CELLCAP 1024      // cells of a batch held in LDS (more: the monolithic kernel); a multiple of G_CELLPAD
+#define G_CELLCAP 2048      // cells of a batch held in LDS as 16-bit (col, j) codes: every pair fits (40 columns x 48 rows)
 #define G_CELLPAD 32        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups)
 #define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
 

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
   const unsigned long long cells_d = g_cells_doubles(ncol, NJ), batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
 
   __shared__ double s_X[G_NODES][G_XS], s_Y[G_NODES][G_YS], s_Z[G_NODES][G_ZS];
-  __shared__ unsigned s_cell[G_CELLCAP];
+  __shared__ unsigned short s_cell[G_CELLCAP];      // col | j << 6 (| 1 << 15: weightless padding)
+  __shared__ int s_rowbase[G_NCOL], s_ncell;        // response row of (col, j = 0)
   extern __shared__ double s_out[];                 // [NWAVE][TT]
   double* ow = s_out + wv * TT;
   int edge_k[NEDGE], k_stage_lo, k_stage_hi;
@@ -77,16 +78,24 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
         // every load of the record in flight before the first one is used: one round trip to HBM, not one per table
-        int cv[4];
+        int cv[8];
         double xv[3], yv[3], zv[8];
         const int ncell_l = cells[0];
 #pragma unroll
-        for (int r = 0; r < 4; r++) cv[r] = (tid + CUR_THREADS * r < (int)(2 * cells_d) - 2) ? cells[2 + tid + CUR_THREADS * r] : 0;
+        for (int r = 0; r < 8; r++) cv[r] = (tid + CUR_THREADS * r < (int)(2 * cells_d) - 2) ? cells[2 + tid + CUR_THREADS * r] : 0;
         gload<3>(gX, G_NODES * ncol, tid, xv);
         gload<3>(gY, G_NODES * NJ, tid, yv);
         gload<8>(gZ, z_lds ? G_NODES * NUr : 0, tid, zv);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const int i = tid + CUR_THREADS * r; if (i < ncell_l) s_cell[i] = (unsigned)cv[r]; }
+        for (int r = 0; r < 8; r++) {
+          const int i = tid + CUR_THREADS * r;
+          if (i < ncell_l) {
+            const unsigned ce = (unsigned)cv[r];
+            const unsigned col = (ce >> 16) & 63u, jc = (ce >> 24) & 63u;
+            s_cell[i] = (unsigned short)(col | (jc << 6) | ((ce >> 31) << 15));
+            if (!(ce >> 31)) s_rowbase[col] = (int)(ce & 0xFFFFu) - (int)jc;      // (the same value from every cell of the column)
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 3; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * ncol) s_X[i / ncol][i % ncol] = xv[r]; }
 #pragma unroll
@@ -95,11 +104,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
 #pragma unroll
           for (int r = 0; r < 8; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * NUr) s_Z[i / NUr][i % NUr] = zv[r]; }
         }
-        if (tid == 0) s_cell[G_CELLCAP - 1] = (unsigned)ncell_l;      // (the padded list never reaches the last entry)
+        if (tid == 0) s_ncell = ncell_l;
         loaded = b;
       }
       __syncthreads();
-      const int ncell = (int)s_cell[G_CELLCAP - 1];
+      const int ncell = s_ncell;
       const int ngrp = ncell >> 2;                 // a multiple of GPF (gtables_kernel pads the list with weightless cells)
       if (tid == 0)
         n_useful += (unsigned long long)min(G_NODES, NQ - b * G_NODES) *
@@ -129,7 +138,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
       for (int kt = wv; kt < n32 && ngrp > 0 && !(A.debug_phases & 0x100000); kt += NWAVE) {
         const int k0 = kA + 32 * kt;
         const double* rp = GA.resp_pad + RESP_PAD + k0 + jj;
-        auto rowoff = [&](int g) { return (A.debug_phases & 0x400000) ? (int64_t)0 : (int64_t)(s_cell[4 * g + kk] & 0xFFFFu) * nkp; };
+        // response row of the lane's cell of group g (a padding cell reads the row of its column 0, j 0: valid memory, weight 0)
+        auto rowoff = [&](int g) {
+          const unsigned ci = s_cell[4 * g + kk];
+          return (int64_t)(s_rowbase[ci & 63u] + (int)((ci >> 6) & 63u)) * nkp;
+        };
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double b0[GPF], b1[GPF];
 #pragma unroll
@@ -144,7 +157,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
             const unsigned ci = s_cell[4 * (g0 + u) + kk];
-            const double a = (ci >> 31) ? 0.0 : s_X[jj][(ci >> 16) & 63u] * s_Y[jj][(ci >> 24) & 63u];
+            const double a = (ci >> 15) ? 0.0 : s_X[jj][ci & 63u] * s_Y[jj][(ci >> 6) & 63u];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
             const int64_t o = rowoff(gn + u);          // the registers just consumed take the loads of the group GPF ahead

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   __shared__ int s_inval[ZC];
   __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 1], s_ustart[NU_MAX + 1];
   __shared__ int s_misc[24], s_wcnt[NWAVE];
-  __shared__ unsigned s_cells[G_CELLCAP];
+  __shared__ unsigned short s_cells[G_CELLCAP];     // col | j << 6 of the listed cells
   __shared__ double s_qpart[G_NODES][G_NODES + 1], s_Q[G_NODES];
 
   if (tid < PP_COUNT) s_par[tid] = ((const double*)((const char*)P + 32))[tid];
@@ -357,13 +357,18 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
           const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
           const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
           cells[2 + pos] = (int)ce;
-          s_cells[pos] = ce;
+          s_cells[pos] = (unsigned short)(col | (jj << 6));
         }
         base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         __syncthreads();
       }
+      __syncthreads();           // (s_cells[0] of another wave)
       const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-      if (tid < padded - base) cells[2 + base + tid] = (int)0x80000000u;      // dummy: row 0 of the table, weight 0
+      if (tid < padded - base && base > 0) {
+        // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
+        const unsigned c0 = s_cells[0] & 63u, j0 = (s_cells[0] >> 6) & 63u;
+        cells[2 + base + tid] = (int)(0x80000000u | (unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) | (c0 << 16) | (j0 << 24));
+      }
       if (tid == 0) { cells[0] = padded; cells[1] = base; }
       n_cells_b = base;
     }
@@ -383,8 +388,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
           double part = 0;
           for (int i = ch; i < n_cells_b; i += 16) {
             const unsigned ce = s_cells[i];
-            const double r = A.resp[(int64_t)(ce & 0xFFFFu) * A.nk + edge_k[e]];
-            part = fma(s_X[n][(ce >> 16) & 63u] * s_Y[n][(ce >> 24) & 63u], r, part);
+            const unsigned cc = ce & 63u, jc = (ce >> 6) & 63u;
+            const double r = A.resp[(int64_t)(s_coli[cc] * A.nj + (jmin + (int)jc)) * A.nk + edge_k[e]];
+            part = fma(s_X[n][cc] * s_Y[n][jc], r, part);
           }
           s_qpart[n][ch] = part;
         }

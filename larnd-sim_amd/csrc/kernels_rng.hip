@@ -100,11 +100,12 @@ int rng_ensure_states(ldsim_ctx* ctx, int64_t n) {
   return rng_append(ctx, n, nullptr);
 }
 
-// upper bound of the normals one pixel's scan can consume (fee.py:557-655): the first reset draw, 2 per loop pass (every
-// tick, plus the busy ticks past the end), 3 per trigger; rounded up to a multiple of 4
+// upper bound of the normals one pixel's scan can consume (fee.py:557-655): the first reset draw, 2 per loop pass -- every
+// tick, plus one busy period past the end of the window for every trigger (a noise trigger in the pass where adc_busy reaches 0
+// starts another one, up to MAX_ADC_VALUES of them) --, 3 per trigger; rounded up to a multiple of 4
 int rng_fee_draws_per_pixel(const LdsimConsts& h, int NT) {
   const int busy = (int)llround(h.adc_busy_delay * h.clock_cycle / h.time_sampling);
-  const int nd = 1 + 2 * (NT + busy + 1) + 3 * h.max_adc_values;
+  const int nd = 1 + 2 * (NT + h.max_adc_values * (busy + 1)) + 3 * h.max_adc_values;
   return (nd + 3) & ~3;
 }
 
@@ -139,7 +140,12 @@ extern "C" int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states) {
   ctx->rng_seeded = 1;
   ctx->light_noise_calls = 0;
   ctx->rng_last_init[0] = ctx->rng_last_init[1] = 0;
-  return n_states ? rng_ensure_states(ctx, n_states) : 0;
+  try {
+    return n_states ? rng_ensure_states(ctx, n_states) : 0;
+  } catch (const std::exception& e) {        // (the host copy of the fresh states: nothing throws across the C ABI)
+    ldsim_set_error("ldsim_rng_seed: %s", e.what());
+    return LDSIM_EINVAL;
+  }
 }
 
 // maybe_create_rng_states(n, seed, rng_states) (cli/simulate_pixels.py:92-104): no table yet -> create n states from `seed`;
@@ -151,7 +157,12 @@ extern "C" int ldsim_rng_extend(ldsim_ctx* ctx, int64_t n_states, uint64_t seed)
   }
   if (!ctx->rng_seeded) return ldsim_rng_seed(ctx, seed, n_states);
   HIPCHK(hipSetDevice(ctx->device));
-  return rng_append(ctx, n_states, &seed);
+  try {
+    return rng_append(ctx, n_states, &seed);
+  } catch (const std::exception& e) {
+    ldsim_set_error("ldsim_rng_extend: %s", e.what());
+    return LDSIM_EINVAL;
+  }
 }
 
 extern "C" int64_t ldsim_rng_count(ldsim_ctx* ctx) { return ctx && ctx->rng_seeded ? ctx->rng_n : -1; }

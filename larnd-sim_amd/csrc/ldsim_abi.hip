@@ -262,6 +262,10 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     ctx->weights_mode = (int)value;
     ctx->wbuf_learned = 0;
   }
+  else if (!strcmp(name, "gform_max_support")) {
+    if (!(value >= 0)) { ldsim_set_error("gform_max_support must be >= 0"); return LDSIM_EINVAL; }
+    ctx->gform_max_support = value > 1e9 ? 1000000000 : (int)value;
+  }
   else if (!strcmp(name, "light_incidence_scalar")) ctx->light_incidence_scalar = value != 0;
   else if (!strcmp(name, "mac_mode")) {
     if (!(value == 0 || value == 1)) { ldsim_set_error("mac_mode must be 0 or 1"); return LDSIM_EINVAL; }
@@ -475,8 +479,10 @@ static int download_tracks(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimT
 extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                      const int32_t* batch_id) {
   NEED(ctx, "null ctx");
+  // validated into a local copy: the ctx keeps describing the segments that are resident until the new ones really are
+  std::vector<int32_t> ids;
   try {
-    ctx->h_batch.assign((size_t)(n > 0 ? n : 0), 0);
+    ids.assign((size_t)(n > 0 ? n : 0), 0);
   } catch (const std::exception&) {
     ldsim_set_error("out of host memory for %lld batch ids", (long long)n);
     return LDSIM_EINVAL;
@@ -491,10 +497,18 @@ extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t
         }
         last = batch_id[i];
       }
-      ctx->h_batch[(size_t)i] = batch_id[i];
+      ids[(size_t)i] = batch_id[i];
     }
   }
-  CK(upload_tracks(ctx, tracks, n, layout, batch_id, true));
+  {
+    const int rc = upload_tracks(ctx, tracks, n, layout, batch_id, true);
+    if (rc) {                 // a failed upload may have overwritten part of the store: nothing is resident any more
+      ctx->seg_owner = 0;
+      ctx->h_batch.clear();
+      return rc;
+    }
+  }
+  ctx->h_batch.swap(ids);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }

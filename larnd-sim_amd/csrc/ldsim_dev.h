@@ -127,6 +127,7 @@ struct ldsim_ctx {
   int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
   int split_max_items = 0;          // validation knob, see CurArgs
   int weights_mode = 2;             // split path: 2 = node-separable form (gtables_kernel + gcorr_kernel, gform.h), 1 = qweights_kernel (Gauss-Legendre along the segment) + mac kernel, 0 = weights_kernel (per-sample closed form) + mac kernel
+  int gform_max_support = 768;      // staged response support (ticks) up to which weights_mode 2 runs the node-separable form; wider tables take the shifted-window kernels
   int mc_current = 0;               // 1: the chain's induced currents come from current_mc_kernel (tracks_current_mc) instead of tracks_current
   int numba_f32 = 0;                // 1: evaluate the sub-expressions Numba types f32 for f4 record fields in float
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2
@@ -139,7 +140,7 @@ struct ldsim_ctx {
   DevBuf seg_block;
   DevBuf raw;          // AoS staging (H2D/D2H)
   LdsimTrackLayout seg_layout{};
-  DevBuf scratch[32];  // named scratch buffers, grown on demand
+  DevBuf scratch[40];  // named scratch buffers, grown on demand
   std::vector<int32_t> h_batch;   // host copy of the resident segments' batch ids (validated non-decreasing at upload)
   int seg_owner = 0;   // who filled the segment store last: 1 = ldsim_segments_upload (resident chain), 2 = a host-buffer stage call
   // device-resident light leg (ldsim_dev_light_incidence / ldsim_dev_sum_light)
@@ -172,6 +173,8 @@ struct ldsim_ctx {
   LdsimChainStats stats{};
   LdsimChainStats stage_stats{};   // counters of the last ldsim_tracks_current stage call (ldsim_tracks_current_stats)
   int64_t chain_U = 0, chain_hits = 0;
+  int64_t cpt_n[4] = {0, 0, 0, 0};   // compact result of the last ldsim_chain_compact_build: hit pixels, hits, track entries, fraction entries
+  int64_t cpt_gen = -1;              // chain launch it was built for
   int want_fractions = 0;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double ms_current = 0, ms_adc = 0, ms_total = 0;
@@ -182,7 +185,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO
 };
 
 void ldsim_set_error(const char* fmt, ...);

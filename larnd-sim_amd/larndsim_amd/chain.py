@@ -151,6 +151,22 @@ class ChargeChain:
                                                   lib.ptr(out['track_pixel_map']), lib.ptr(fr)))
         return out
 
+    def download_compact(self):
+        """The last run()'s results in compact form (``ldsim_chain_compact_build`` / ``_download``): what the exporter reads --
+        hit pixels, their hits and the fractions of the track slots they have -- gathered on the device first: a few MB over
+        PCIe instead of 13 KB per unique pixel.  ``expand_compact`` turns it into the dense rows of the hit pixels."""
+        from .comm import HIT_ROW
+        sizes = (C.c_int64 * 4)()
+        lib.check(lib.load().ldsim_chain_compact_build(self.ctx, sizes))
+        n_hp, n_hits, n_trk, n_frac = (int(v) for v in sizes)
+        out = dict(hit_pixels=np.zeros((n_hp, 5), dtype=np.int32), track_segments=np.zeros(n_trk, dtype=np.int64),
+                   hit_rows=np.zeros(n_hits, dtype=HIT_ROW), hit_charge=np.zeros(n_hits), fractions=np.zeros(n_frac),
+                   has_fractions=bool(self._want_fractions))
+        lib.check(lib.load().ldsim_chain_compact_download(self.ctx, lib.ptr(out["hit_pixels"]), lib.ptr(out["track_segments"]),
+                                                          lib.ptr(out["hit_rows"]), lib.ptr(out["hit_charge"]),
+                                                          lib.ptr(out["fractions"])))
+        return out
+
     def download_async(self, fractions=None):
         """Start copying the results of the last run() to page-locked host arrays on the library's copy stream and return them
         at once (``ldsim_chain_download_async``): the next ``run()`` overlaps with the transfer.  The arrays hold the rows
@@ -294,3 +310,37 @@ class ChargeChain:
         p, n, rb = C.c_void_p(), C.c_int64(), C.c_int32()
         lib.check(lib.load().ldsim_chain_compact_hits(self.ctx, C.byref(p), C.byref(n), C.byref(rb)))
         return p.value, n.value, rb.value
+
+
+def expand_compact(c):
+    """Dense rows of the hit pixels from ``ChargeChain.download_compact()``: the arrays ``download()`` returns, restricted to
+    the unique pixels that hold a hit (``row`` = their index in the full arrays): ``unique_pix``, ``batch``, ``adc_list``,
+    ``adc_ticks_list``, ``adc_digit`` [n][A] (slots past a pixel's last hit: charge 0, tick 0, the pedestal code -- what the dense
+    arrays hold there), ``track_pixel_map`` [n][M] (-1 pad) and ``current_fractions`` [n][A][M] (written slots only: the dense
+    array's un-normalised residue in the slot after the last hit, fee.py:572-573, is not part of the result)."""
+    from . import packets
+    A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
+    hp = c["hit_pixels"]
+    n = hp.shape[0]
+    nh, nt = hp[:, 3].astype(np.int64), hp[:, 4].astype(np.int64)
+    ped = float(packets._digitize0())                   # fee.digitize(0): what an unwritten slot digitises to
+    out = dict(row=hp[:, 0].copy(), unique_pix=hp[:, 1].copy(), batch=hp[:, 2].copy(), adc_list=np.zeros((n, A)),
+               adc_ticks_list=np.zeros((n, A)), adc_digit=np.full((n, A), ped), track_pixel_map=np.full((n, M), -1, dtype=np.int64))
+    # hits: pixel after pixel, slot 0 up
+    pix_of_hit = np.repeat(np.arange(n), nh)
+    slot = c["hit_rows"]["slot"].astype(np.int64)
+    out["adc_list"][pix_of_hit, slot] = c["hit_charge"]
+    out["adc_ticks_list"][pix_of_hit, slot] = c["hit_rows"]["tick"]
+    out["adc_digit"][pix_of_hit, slot] = c["hit_rows"]["adc"]
+    # track slots: pixel after pixel
+    pix_of_trk = np.repeat(np.arange(n), nt)
+    m_of_trk = np.arange(int(nt.sum())) - np.repeat(np.cumsum(nt) - nt, nt)
+    out["track_pixel_map"][pix_of_trk, m_of_trk] = c["track_segments"]
+    if c.get("has_fractions"):
+        fr = np.zeros((n, A, M))
+        per_hit = nt[pix_of_hit]                                    # fraction entries of every hit
+        h_of_f = np.repeat(np.arange(len(pix_of_hit)), per_hit)
+        m_of_f = np.arange(int(per_hit.sum())) - np.repeat(np.cumsum(per_hit) - per_hit, per_hit)
+        fr[pix_of_hit[h_of_f], slot[h_of_f], m_of_f] = c["fractions"]
+        out["current_fractions"] = fr
+    return out

@@ -34,7 +34,7 @@ EXPORTS = [
     "ldsim_get_adc_values", "ldsim_digitize", "ldsim_light_incidence", "ldsim_sum_light_signals",
     "ldsim_scintillation_effect", "ldsim_light_detector_response",
     "ldsim_segments_upload", "ldsim_segments_download", "ldsim_segments_reset", "ldsim_dev_quench_drift", "ldsim_charge_chain",
-    "ldsim_chain_download", "ldsim_chain_download_async", "ldsim_chain_download_wait", "ldsim_chain_compact_hits", "ldsim_chain_kernel_ms", "ldsim_chain_kernel_ms_detail",
+    "ldsim_chain_download", "ldsim_chain_download_async", "ldsim_chain_download_wait", "ldsim_chain_compact_hits", "ldsim_chain_compact_build", "ldsim_chain_compact_download", "ldsim_chain_kernel_ms", "ldsim_chain_kernel_ms_detail",
     "ldsim_dev_light_incidence", "ldsim_dev_light_incidence_download", "ldsim_dev_light_t0_range", "ldsim_dev_sum_light",
     "ldsim_dev_light_download", "ldsim_light_kernel_ms",
     "ldsim_rng_seed", "ldsim_rng_states_download", "ldsim_rng_clear", "ldsim_rng_extend", "ldsim_rng_count",

@@ -144,7 +144,7 @@ def test_pixels_time_intervals_golden(cfg):
 CURRENT_PATHS = {"mono": dict(split_kernels=0),
                  "closed": dict(split_kernels=1, weights_mode=0, mac_mode=0),
                  "quad": dict(split_kernels=1, weights_mode=1, mac_mode=1),
-                 "gform": dict(split_kernels=1, weights_mode=2)}
+                 "gform": dict(split_kernels=1, weights_mode=2, gform_max_support=1e9)}     # (forced for tables of any support)
 
 
 def _tracks_current_on(path, neigh, r, resp, T, **extra):
@@ -685,10 +685,17 @@ def test_boundary_refuses_misuse_and_stays_usable():
         noisy.run(0, len(seg))
     finally:
         consts.detector.RESET_NOISE_CHARGE = 0
-    # decreasing batch ids are refused at upload; the previous upload is what stays resident is not promised, so upload again
+    # decreasing batch ids are refused at upload, before anything of the ctx is touched: the segments of the upload before stay
+    # resident WITH their own batch ids (the ids used to be overwritten first), so the chain still runs on them
     fresh = ChargeChain(resp)
+    fresh.upload(seg, bid)
+    fresh.quench_drift()
     with pytest.raises(lib.LdsimError, match="non-decreasing"):
-        fresh.upload(seg, bid[::-1].copy())
+        fresh.upload(seg[:40], np.r_[np.ones(20), np.zeros(20)].astype(np.int32))
+    fresh.n = len(seg)           # (the Python wrapper's own count follows its last call; the ctx still holds all segments)
+    fresh.run(0, len(seg))
+    kept = fresh.download()
+    assert np.array_equal(kept["unique_pix"], good["unique_pix"]) and np.array_equal(kept["adc_digit"], good["adc_digit"])
     fresh.upload(seg, bid)
     fresh.quench_drift()
     fresh.run(0, len(seg))
@@ -1161,6 +1168,41 @@ def test_resident_light_waveform_chain_vs_oracle():
     assert all(v > 0 for v in ms.values())
 
 
+@pytest.mark.parametrize("cfg,kind,fractions", [("module0", "survey", True), ("ndlar", "golden", True), ("2x2_no_modvar", "survey", False)])
+def test_compact_download_expands_to_the_dense_rows(cfg, kind, fractions):
+    """ldsim_chain_compact_build / _download: hit pixels, hits, track slots and per-hit fractions gathered on the device;
+    chain.expand_compact gives back the dense rows of the hit pixels, equal to the rows ldsim_chain_download returns (the
+    fractions on the written slots -- the slot after a pixel's last hit holds an un-normalised residue in the dense array,
+    fee.py:572-573, which no exporter reads)."""
+    from larndsim_amd.chain import expand_compact
+    seg, bid = _two_event_set(cfg, 43)
+    ch = ChargeChain(H.response_for(kind))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    st = ch.run(0, len(seg), want_fractions=fractions)
+    dense = ch.download()
+    c = ch.download_compact()
+    e = expand_compact(c)
+    rows = e["row"]
+    has_hit = dense["adc_list"][:, 0] != 0
+    assert np.array_equal(np.flatnonzero(has_hit), rows) and len(rows) > 50
+    assert len(c["hit_rows"]) == int((dense["adc_list"] != 0).sum()) == ch.compact_hits()[1]
+    for k in ("unique_pix", "batch", "adc_list", "adc_ticks_list", "adc_digit", "track_pixel_map"):
+        assert np.array_equal(e[k], dense[k][rows]), k
+    if fractions:
+        written = dense["adc_list"][rows] != 0
+        assert np.array_equal(e["current_fractions"][written], dense["current_fractions"][rows][written])
+        assert not e["current_fractions"][~written].any()
+        nbytes = sum(v.nbytes for v in c.values() if hasattr(v, "nbytes"))
+        assert nbytes < 0.02 * sum(v.nbytes for v in dense.values())          # a few percent of the dense arrays at most
+    else:
+        assert "current_fractions" not in e and len(c["fractions"]) == 0
+    # built for the last launch only
+    ch.run(0, len(seg) // 2, want_fractions=fractions)
+    with pytest.raises(lib.LdsimError, match="compact_build"):
+        lib.check(lib.load().ldsim_chain_compact_download(ch.ctx, None, None, None, None, None))
+
+
 def test_compact_hit_rows_decode_to_the_downloaded_arrays():
     """The 24-byte rows the multi-GPU exchange moves ({batch, pixel, adc, slot, tick}: ldsim_chain_compact_hits ->
     ldsim_hits_accumulate -> ldsim_comm_allgather_hits -> ldsim_comm_gathered_download, here through a one-rank RCCL
@@ -1548,7 +1590,7 @@ def _two_event_set(cfg, seed, n=1200):
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 2), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
                     ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 23.0), ("mac_mode", 1),
-                    ("quad_accuracy_log10", 10)):
+                    ("quad_accuracy_log10", 10), ("gform_max_support", 768), ("trim_response_log", 23.0)):
         lib.set_option(name, v)
 
 
@@ -1566,6 +1608,7 @@ def test_split_kernels_equal_monolithic(cfg, kind, mode):
     res = {}
     try:
         lib.set_option("weights_mode", mode)
+        lib.set_option("gform_max_support", 1e9)       # mode 2: the matrix form whatever the table's support
         for name, split, cap, max_items in (("mono", 0, 6144, 0), ("split", 1, 65536, 0), ("tiny", 1, 50, 0),
                                             ("capped", 1, 6144, 60)):
             lib.set_option("split_kernels", split)
@@ -1684,6 +1727,7 @@ def test_quadrature_weights_node_cap_and_pruning(cfg, kind, wmode):
     res = {}
     try:
         lib.set_option("weights_mode", wmode)
+        lib.set_option("gform_max_support", 1e9)
         for name, cap, prune in (("default", 256, 23.0), ("again", 256, 23.0), ("cap12", 12, 23.0), ("keepall", 256, 0.0),
                                  ("acc12", 256, 23.0), ("prune30", 256, 30.0)):
             lib.set_option("quad_max_nodes", cap)
@@ -1750,6 +1794,7 @@ def test_numba_f32_typing_mode_vs_oracle(mode):
         for split in (0, 1):                             # the monolithic kernel, then the weights stage under test
             lib.set_option("split_kernels", split)
             lib.set_option("weights_mode", mode)
+            lib.set_option("gform_max_support", 1e9)
             detsim.tracks_current[1, 1](got, neigh, ref, response)
             H.assert_wave_close(got, typed, what=f"numba_f32 stage call, split_kernels {split}")
             assert (detsim.tracks_current_stats().n_wbuf > 0) == bool(split)
@@ -1953,6 +1998,15 @@ def test_cli_overlapped_downloads_write_the_same_file(tmp_path):
                     assert np.array_equal(a[f], b[f], equal_nan=True), (k, f)
             else:
                 assert np.array_equal(a, b, equal_nan=True), k
+    # the default driver path downloads the compact form (hit pixels only) instead of every unique pixel's arrays: the same
+    # packets, association rows and segments
+    res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "compact.npz"), config="module0", rand_seed=4,
+                             response_file=str(tmp_path / "resp.npy"), chunk_segments=40)
+    cpt = dict(np.load(tmp_path / "compact.npz"))
+    assert res["n_packets"] == len(outs[0]["packets"]) and not any(k.startswith("raw") for k in cpt)
+    for k in ("packets", "mc_packets_assn", "segments"):
+        for f in cpt[k].dtype.names:
+            assert np.array_equal(cpt[k][f], outs[0][k][f], equal_nan=True), (k, f)
 
 
 def test_cli_light_leg(tmp_path):
