@@ -370,7 +370,7 @@ int ldsim_chain_download_wait(ldsim_ctx* ctx);
  * the dense arrays' 13 KB per unique pixel.  ldsim_chain_compact_build: sizes[4] = hit pixels, hits, track entries (sum over
  * hit pixels of their filled track_pixel_map slots), fraction entries (sum over hits of their pixel's track slots; 0 without
  * want_fractions).  ldsim_chain_compact_download: hit_pixels [n_hp][5] i32 = {row in the dense arrays, pixel id, batch, hits,
- * track slots}, hit pixels in row order; track_segments i64, the filled track_pixel_map entries pixel after pixel; hit_rows
+ * track slots + 256 if the pixel is the first row of its batch in the dense arrays}, hit pixels in row order; track_segments i64, the filled track_pixel_map entries pixel after pixel; hit_rows
  * [n_hits] 24-byte rows {batch i32, pixel i32, ADC code i32, slot i32, tick f64} and hit_charge f64 (adc_list) in the same
  * order (pixel after pixel, slot 0 up); fractions f64: per hit, one value per track slot of its pixel.  Any pointer may be NULL. */
 int ldsim_chain_compact_build(ldsim_ctx* ctx, int64_t* sizes);

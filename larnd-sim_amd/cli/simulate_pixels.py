@@ -537,17 +537,23 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             lo = int(np.searchsorted(bid[:nsim], bb, side="left"))
             seg_ids, trj_ids = seg_ids_all[lo:], trj_ids_all[lo:]
             tpm = r["track_pixel_map"][m]
+            digit, ticks_b, upix_b, frac_b = r["adc_digit"][m], r["adc_ticks_list"][m], r["unique_pix"][m], r["current_fractions"][m]
+            if "first_of_batch" in r and len(tpm) and not r["first_of_batch"][m][0]:
+                # compact form: the batch's first unique pixel holds no hit and is not among the rows.  The reference's exporter
+                # keeps its clock-rollover state in row 0 of what it is handed (fee.py:164-183, 267-277): hand it that hit-less row.
+                pad = lambda a, v: np.concatenate([np.full((1,) + a.shape[1:], v, dtype=a.dtype), a])      # noqa: E731
+                tpm, digit, ticks_b, frac_b = pad(tpm, -1), pad(digit, packets._digitize0()), pad(ticks_b, 0), pad(frac_b, 0)
+                upix_b = pad(upix_b, upix_b[0])
             track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
             traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
             event = table[int(bb)][0]
             announce_until(event)
-            ev_ids = np.full(r["adc_digit"][m].shape, event)
+            ev_ids = np.full(digit.shape, event)
             ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
             # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger
             lt_times, lt_events, lt_mods = light_trig_of.get((int(event), int(table[int(bb)][1])),
                                                              (np.zeros(1), np.array([event]), np.ones(1)))
-            pk, assn = packets.build_packets(ev_ids, r["adc_digit"][m], r["adc_ticks_list"][m], r["unique_pix"][m],
-                                             r["current_fractions"][m], track_ids, traj_ids, ev_time,
+            pk, assn = packets.build_packets(ev_ids, digit, ticks_b, upix_b, frac_b, track_ids, traj_ids, ev_time,
                                              light_trigger_times=lt_times, light_trigger_event_id=lt_events,
                                              light_trigger_modules=lt_mods, bad_channels=bad_list, i_mod=i_mod)
             out.append_packets(pk, assn)

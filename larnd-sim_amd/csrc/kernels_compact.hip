@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256) compact_fill_kernel(const int32_t* __rest
   if (nh <= 0) return;
   const int nt = c_trk[u];
   int32_t* r = hp_rows + (int64_t)o_hp[u] * 5;
-  r[0] = (int32_t)u; r[1] = upix[u]; r[2] = ubatch[u]; r[3] = nh; r[4] = nt;
+  // (bit 8 of the last word: the pixel is the first row of its batch in the dense arrays -- the exporter's clock-rollover
+  // bookkeeping treats row 0 of what it is handed specially, fee.py:164-183,267-277)
+  r[0] = (int32_t)u; r[1] = upix[u]; r[2] = ubatch[u]; r[3] = nh; r[4] = nt | ((u == 0 || ubatch[u - 1] != ubatch[u]) ? 256 : 0);
   for (int m = 0; m < nt; m++) trk_seg[o_trk[u] + m] = tpm[u * M + m];
   for (int h = 0; h < nh; h++) {
     hit_charge[hit_off[u] + h] = adc_list[u * A + h];

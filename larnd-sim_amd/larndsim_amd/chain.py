@@ -315,16 +315,18 @@ class ChargeChain:
 def expand_compact(c):
     """Dense rows of the hit pixels from ``ChargeChain.download_compact()``: the arrays ``download()`` returns, restricted to
     the unique pixels that hold a hit (``row`` = their index in the full arrays): ``unique_pix``, ``batch``, ``adc_list``,
-    ``adc_ticks_list``, ``adc_digit`` [n][A] (slots past a pixel's last hit: charge 0, tick 0, the pedestal code -- what the dense
+    ``first_of_batch`` (the pixel is row 0 of its batch in the full arrays: the exporter's clock-rollover bookkeeping looks at the
+    first row it is handed), ``adc_ticks_list``, ``adc_digit`` [n][A] (slots past a pixel's last hit: charge 0, tick 0, the pedestal code -- what the dense
     arrays hold there), ``track_pixel_map`` [n][M] (-1 pad) and ``current_fractions`` [n][A][M] (written slots only: the dense
     array's un-normalised residue in the slot after the last hit, fee.py:572-573, is not part of the result)."""
     from . import packets
     A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
     hp = c["hit_pixels"]
     n = hp.shape[0]
-    nh, nt = hp[:, 3].astype(np.int64), hp[:, 4].astype(np.int64)
+    nh, nt = hp[:, 3].astype(np.int64), (hp[:, 4] & 255).astype(np.int64)
     ped = float(packets._digitize0())                   # fee.digitize(0): what an unwritten slot digitises to
-    out = dict(row=hp[:, 0].copy(), unique_pix=hp[:, 1].copy(), batch=hp[:, 2].copy(), adc_list=np.zeros((n, A)),
+    out = dict(row=hp[:, 0].copy(), first_of_batch=(hp[:, 4] & 256) != 0, unique_pix=hp[:, 1].copy(), batch=hp[:, 2].copy(),
+               adc_list=np.zeros((n, A)),
                adc_ticks_list=np.zeros((n, A)), adc_digit=np.full((n, A), ped), track_pixel_map=np.full((n, M), -1, dtype=np.int64))
     # hits: pixel after pixel, slot 0 up
     pix_of_hit = np.repeat(np.arange(n), nh)

@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
-subs = sys.argv[2:] or ["mac_", "qweights", "pixel_adc"]
+subs = sys.argv[2:] or ["gcorr", "gtables", "mac_", "qweights", "pixel_adc"]
 acc = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(set)
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

@@ -1,6 +1,6 @@
 """HBM bytes per launch of the chain's kernels from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, rocprofv3 PMC slots).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
-coalesced read (same guide, HBM), so it is doubled.  Writes profiles/r02_traffic.json, which bench.py reads for
+coalesced read (same guide, HBM), so it is doubled.  Writes profiles/r03_traffic.json (LDSIM_TRAFFIC_FILE names another), which bench.py reads for
 `roofline.traffic`, and copies the per-kernel averages next to it.
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
@@ -65,7 +65,7 @@ def main():
         return kernel_stats(sys.argv[2], sys.argv[3])
     config, d_fetch, d_write = sys.argv[1:4]
     fetch, write = per_kernel(d_fetch, "FETCH_SIZE"), per_kernel(d_write, "WRITE_SIZE")
-    path = os.path.join(REPO, "profiles", "r02_traffic.json")
+    path = os.path.join(REPO, "profiles", os.environ.get("LDSIM_TRAFFIC_FILE", "r03_traffic.json"))
     tab = json.load(open(path)) if os.path.exists(path) else {}
     entry = {}
     for k in sorted(set(fetch) | set(write)):
