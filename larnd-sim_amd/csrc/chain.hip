@@ -95,8 +95,8 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
     wcap = (unsigned long long)ceil(per_pair * (double)n_valid);
     CK(ldsim_ensure(ctx, SB_WBUF, (size_t)wcap * 8));
     if (attempt > 0) {
-      HIPCHK(hipMemsetAsync(&counters[0], 0, 16, st));   // ambiguous shifts, samples
-      HIPCHK(hipMemsetAsync(&counters[5], 0, 32, st));   // dfma, overflowed pairs, pool cursor, useful FMAs
+      HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));                      // pool cursor
+      HIPCHK(hipMemsetAsync(&counters[16], 0, STAT_BYTES - 128, st));     // the kernels' stripes (nothing earlier adds to them)
     }
     int rc = split_launch_weights(ctx, a, ctx->scratch[SB_ITEMS].p, ctx->scratch[SB_HDR].p, ctx->scratch[SB_CORR].p,
                                   (double*)ctx->scratch[SB_WBUF].p, wcap, &counters[7]);
@@ -135,9 +135,9 @@ static void stats_from_counters(LdsimChainStats& s, const unsigned long long* h_
 // chain: the per-tick parity tests reach the default (split) kernels through this call; ldsim_tracks_current_stats tells
 // which kernels carried the pairs.
 int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc) {
-  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
   unsigned long long* counters = (unsigned long long*)((char*)ctx->scratch[SB_MISC].p + 256);
-  HIPCHK(hipMemsetAsync(counters, 0, 128, ctx->stream));
+  HIPCHK(hipMemsetAsync(counters, 0, STAT_BYTES, ctx->stream));
   CurArgs a{};
   fill_cur_common(ctx, a);
   a.pair_val = nullptr; a.pair_key = nullptr;
@@ -164,9 +164,10 @@ int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* 
   int rc = run_tracks_current(ctx, a, ctx->seg.n, counters, &split_timed);
   ctx->mc_current = keep_mc;
   if (rc) return rc;
-  unsigned long long h_cnt[9] = {0};
-  HIPCHK(hipMemcpyAsync(h_cnt, counters, 72, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long h_cnt[16], h_raw[STAT_WORDS];
+  HIPCHK(hipMemcpyAsync(h_raw, counters, STAT_BYTES, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  stat_sum(h_raw, h_cnt);
   stats_from_counters(ctx->stage_stats, h_cnt);
   return 0;
 }
@@ -203,10 +204,10 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipEventRecord(ctx->ev[0], st));
 
   // ---- misc block: [0] err, [8] nmax i32, [16] tran bits u64, [256..] counters u64[16] ----------------------------
-  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
   char* misc = (char*)ctx->scratch[SB_MISC].p;
   unsigned long long* counters = (unsigned long long*)(misc + 256);
-  HIPCHK(hipMemsetAsync(misc, 0, 512, st));
+  HIPCHK(hipMemsetAsync(misc, 0, 256 + STAT_BYTES, st));
 
   // batch id range of this call: the non-negative ids are non-decreasing (checked at upload against the host copy kept
   // in the ctx), so the first and the last one are the range; negative = not simulated
@@ -404,9 +405,10 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
 
   // ---- compact hit rows (payload of the multi-GPU all-gather) -----------------------------------------------------------------------------
   CK(sort_exclusive_scan_i32(ctx, d_hitcnt, d_hitoff, U));
-  unsigned long long h_cnt[9] = {0};
-  HIPCHK(hipMemcpyAsync(h_cnt, counters, 72, hipMemcpyDeviceToHost, st));
+  unsigned long long h_cnt[16], h_raw[STAT_WORDS];
+  HIPCHK(hipMemcpyAsync(h_raw, counters, STAT_BYTES, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  stat_sum(h_raw, h_cnt);
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
   stats_from_counters(ctx->stats, h_cnt);

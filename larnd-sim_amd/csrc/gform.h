@@ -62,4 +62,5 @@ struct GArgs {
   int32_t nkp, k_lo, k_hi;
   const double* glx;
   const double* glw;
+  int32_t dbg;                   // timing tools (option debug_gform)
 };

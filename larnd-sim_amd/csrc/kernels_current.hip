@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(
     double tt = g.t_start + it_ref * dt;
     double val = (tt - t0) / dtr;
     double kr = py_round(val);
-    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
+    if (count && fabs(val - kr) > 0.5 - 1e-7) stat_add(A.counters, 0, 1ull);
     return (int)kr - M * it_ref;
   };
 
@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(
   // ticks outside the response-visible window are exactly zero
   for (int it = tid; it < A.T; it += CUR_THREADS)
     if (it < it_w0 || it >= it_w1) out[it] = 0.f;
-  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
-  if (lane == 0 && n_surv) atomicAdd(&A.counters[1], n_surv);
+  if (lane == 0 && n_blocks) stat_add(A.counters, 5, n_blocks * 64ull * 64ull);
+  if (lane == 0 && n_surv) stat_add(A.counters, 1, n_surv);
 }
 
 extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {

@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   }
   if (tid == 0) {
     F.hit_count[u] = nh;
-    if (overflow) atomicAdd(&F.counters[2], 1ull);
-    if (nh) atomicAdd(&F.counters[3], (unsigned long long)nh);
+    if (overflow) stat_add(F.counters, 2, 1ull);
+    if (nh) stat_add(F.counters, 3, (unsigned long long)nh);
   }
   // ---- backtracking fractions (fee.py:572-573, 633-635): sum_jc sig_k[jc]*G[min(ntap, b-jc)] / true_q ------------
   if (F.fractions && !(F.debug & 0x40000)) {

@@ -21,39 +21,61 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define GPF 8            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
 static_assert(G_CELLPAD == 4 * GPF, "the cell list is padded to whole prefetch rounds");
 
-// n doubles (n <= 256 * R) from global memory into registers: all loads issued before the first use
-template <int R>
-__device__ __forceinline__ void gload(const double* __restrict__ g, int n, int tid, double (&v)[R]) {
-#pragma unroll
-  for (int r = 0; r < R; r++) v[r] = (tid + CUR_THREADS * r < n) ? g[tid + CUR_THREADS * r] : 0.0;
+#define GT 128           // threads of a gcorr workgroup: two waves per pair, twice the pairs in flight per CU of a four-wave one
+#define GW 2             //   (the kernel waits on a chain of dependent latencies: DESIGN.md section 4, profiles/r03_occupancy*.log)
+
+// LDS of a pair, carved from the dynamic block by its real dimensions (a typical pair needs 12 KB; sized for the caps it would
+// be 38 KB and four pairs per CU).  Two size classes: pairs that fit `small` run 8 per CU, the others in a second launch.
+struct GLds {
+  int xs, ys, zs, cellcap, bytes;
+  bool z_lds;
+};
+__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT) {
+  GLds L;
+  L.xs = ncol | 1;                                   // odd strides: the 16 node rows fall on distinct banks
+  L.ys = NJ | 1;
+  const int nur = g_nur(NU);
+  L.z_lds = NU <= G_NUCAP;                           // the steepest long segments read Z from the record (L2)
+  L.zs = L.z_lds ? ((nur & 31) == 16 ? nur : nur + 16) : 0;      // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
+  L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
+  L.bytes = 8 * (GW * TT + G_NODES * (L.xs + L.ys + L.zs)) + 4 * ((ncol + 1) & ~1) + 2 * L.cellcap + 16;
+  return L;
 }
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT) {
+__global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_budget, const int32_t* __restrict__ big_list) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t pair = blockIdx.x;
+  const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
   if (GA.flags[pair]) return;                       // the monolithic kernel writes this pair
   float* out = A.out + pair * (int64_t)A.T;
   const GInfo* __restrict__ gip = GA.gi + pair;
   if (gip->status != 1) {
-    for (int it = tid; it < A.T; it += CUR_THREADS) out[it] = 0.f;
+    if (!big_list)
+      for (int it = tid; it < A.T; it += GT) out[it] = 0.f;
     return;
   }
-  const double* __restrict__ rec = GA.rec + gip->off;
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
+  const GLds L = g_lds_layout(ncol, NJ, NU, TT);
+  if ((L.bytes > lds_budget) != (big_list != nullptr)) return;      // the other launch's pair
+  const double* __restrict__ rec = GA.rec + gip->off;
   const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
   const int NUr = g_nur(NU), NU16 = NUr >> 4;
-  const bool z_lds = NU <= G_NUCAP;                 // the Z table in LDS; the steepest long segments read it from the record (L2)
+  const bool z_lds = L.z_lds;
   const unsigned long long cells_d = g_cells_doubles(ncol, NJ), batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
 
-  __shared__ double s_X[G_NODES][G_XS], s_Y[G_NODES][G_YS], s_Z[G_NODES][G_ZS];
-  __shared__ unsigned short s_cell[G_CELLCAP];      // col | j << 6 (| 1 << 15: weightless padding)
-  __shared__ int s_rowbase[G_NCOL], s_ncell;        // response row of (col, j = 0)
-  extern __shared__ double s_out[];                 // [NWAVE][TT]
+  extern __shared__ double s_dyn[];
+  double* s_out = s_dyn;                            // [GW][TT]
+  double* s_X = s_out + GW * TT;                    // [16][xs]
+  double* s_Y = s_X + G_NODES * L.xs;               // [16][ys]
+  double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
+  int* s_rowbase = (int*)(s_Z + G_NODES * L.zs);    // [ncol]: response row of (col, j = 0)
+  unsigned short* s_cell = (unsigned short*)(s_rowbase + ((ncol + 1) & ~1));      // col | j << 6 (| 1 << 15: weightless padding)
+  __shared__ int s_ncell;
+  const int xs = L.xs, ys = L.ys, zs = L.zs;
   double* ow = s_out + wv * TT;
   int edge_k[NEDGE], k_stage_lo, k_stage_hi;
   edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
@@ -64,7 +86,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
 
   for (int sup0 = it_w0; sup0 < it_w1; sup0 += TT) {
     const int wlen = min(it_w1 - sup0, TT);
-    for (int i = tid; i < NWAVE * TT; i += CUR_THREADS) s_out[i] = 0;
+    for (int i = tid; i < GW * TT; i += GT) s_out[i] = 0;
     // response indices this tick tile can meet, inside the staged range (zeros outside it)
     const int kA = max(M * sup0 + u_min, GA.k_lo), kB = min(M * (sup0 + wlen - 1) + u_min + NU - 1, GA.k_hi);
     const int n32 = kB >= kA ? (kB - kA) / 32 + 1 : 0;
@@ -77,32 +99,39 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
       const double* gC = gZ + 16 * NUr;
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
-        // every load of the record in flight before the first one is used: one round trip to HBM, not one per table
-        int cv[8];
-        double xv[3], yv[3], zv[8];
+        // the record's loads in flight four rounds at a time before their first use
         const int ncell_l = cells[0];
+        auto stage = [&](const double* g, int n, int rowlen, double* dst, int stride) {
+          for (int i0 = 0; i0 < n; i0 += 4 * GT) {
+            double v[4];
 #pragma unroll
-        for (int r = 0; r < 8; r++) cv[r] = (tid + CUR_THREADS * r < (int)(2 * cells_d) - 2) ? cells[2 + tid + CUR_THREADS * r] : 0;
-        gload<3>(gX, G_NODES * ncol, tid, xv);
-        gload<3>(gY, G_NODES * NJ, tid, yv);
-        gload<8>(gZ, z_lds ? G_NODES * NUr : 0, tid, zv);
+            for (int r = 0; r < 4; r++) v[r] = (i0 + tid + GT * r < n) ? g[i0 + tid + GT * r] : 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const int i = tid + CUR_THREADS * r;
-          if (i < ncell_l) {
-            const unsigned ce = (unsigned)cv[r];
-            const unsigned col = (ce >> 16) & 63u, jc = (ce >> 24) & 63u;
-            s_cell[i] = (unsigned short)(col | (jc << 6) | ((ce >> 31) << 15));
-            if (!(ce >> 31)) s_rowbase[col] = (int)(ce & 0xFFFFu) - (int)jc;      // (the same value from every cell of the column)
+            for (int r = 0; r < 4; r++) {
+              const int i = i0 + tid + GT * r;
+              if (i < n) dst[(i / rowlen) * stride + i % rowlen] = v[r];
+            }
+          }
+        };
+        for (int i0 = 0; i0 < ncell_l; i0 += 4 * GT) {
+          int cv[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) cv[r] = (i0 + tid + GT * r < ncell_l) ? cells[2 + i0 + tid + GT * r] : 0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = i0 + tid + GT * r;
+            if (i < ncell_l) {
+              const unsigned ce = (unsigned)cv[r];
+              const unsigned col = (ce >> 16) & 63u, jc = (ce >> 24) & 63u;
+              s_cell[i] = (unsigned short)(col | (jc << 6) | ((ce >> 31) << 15));
+              if (!(ce >> 31)) s_rowbase[col] = (int)(ce & 0xFFFFu) - (int)jc;      // (the same value from every cell of the column)
+            }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 3; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * ncol) s_X[i / ncol][i % ncol] = xv[r]; }
-#pragma unroll
-        for (int r = 0; r < 3; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * NJ) s_Y[i / NJ][i % NJ] = yv[r]; }
-        if (z_lds) {
-#pragma unroll
-          for (int r = 0; r < 8; r++) { const int i = tid + CUR_THREADS * r; if (i < G_NODES * NUr) s_Z[i / NUr][i % NUr] = zv[r]; }
+        if (!(GA.dbg & 4)) {
+        stage(gX, G_NODES * ncol, ncol, s_X, xs);
+        stage(gY, G_NODES * NJ, NJ, s_Y, ys);
+        if (z_lds) stage(gZ, G_NODES * NUr, NUr, s_Z, zs);
         }
         if (tid == 0) s_ncell = ncell_l;
         loaded = b;
@@ -119,7 +148,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
           d4 p = {0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const double za = z_lds ? s_Z[4 * q + kk][16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
+            const double za = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
             p = __builtin_amdgcn_mfma_f64_16x16x4f64(za, acc[q], p, 0, 0, 0);
           }
 #pragma unroll
@@ -135,10 +164,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
       // A wave owns pairs of adjacent 16-tick tiles (the second one may lie past the range: its products meet zeros or ticks
       // outside the window and are dropped): one A operand (X Y of the lane's node and cell) feeds both products, 2 x GPF
       // response loads are in flight while GPF groups are multiplied; no branch in the loop.
-      for (int kt = wv; kt < n32 && ngrp > 0 && !(A.debug_phases & 0x100000); kt += NWAVE) {
+      for (int kt = wv; kt < n32 && ngrp > 0 && !(A.debug_phases & 0x100000); kt += GW) {
         const int k0 = kA + 32 * kt;
         const double* rp = GA.resp_pad + RESP_PAD + k0 + jj;
-        // response row of the lane's cell of group g (a padding cell reads the row of its column 0, j 0: valid memory, weight 0)
+        // response row of the lane's cell of group g (a padding cell repeats a listed cell: valid memory, weight 0)
         auto rowoff = [&](int g) {
           const unsigned ci = s_cell[4 * g + kk];
           return (int64_t)(s_rowbase[ci & 63u] + (int)((ci >> 6) & 63u)) * nkp;
@@ -152,12 +181,12 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
           b1[u] = rp[o + 16];
         }
 #pragma unroll 1
-        for (int g0 = 0; g0 < ngrp && !(A.debug_phases & 0x800000); g0 += GPF) {
+        for (int g0 = 0; g0 < ngrp; g0 += GPF) {
           const int gn = (g0 + GPF < ngrp) ? g0 + GPF : g0;         // (the last round reloads itself: no branch, values unused)
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
             const unsigned ci = s_cell[4 * (g0 + u) + kk];
-            const double a = (ci >> 15) ? 0.0 : s_X[jj][ci & 63u] * s_Y[jj][(ci >> 6) & 63u];
+            const double a = (ci >> 15) ? 0.0 : s_X[jj * xs + (ci & 63u)] * s_Y[jj * ys + ((ci >> 6) & 63u)];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
             const int64_t o = rowoff(gn + u);          // the registers just consumed take the loads of the group GPF ahead
@@ -172,7 +201,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
         }
       }
       // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to
-      if (emask) {
+      if (emask && !(GA.dbg & 2)) {
         int et = 0;
         for (int e = 0; e < NEDGE; e++) {
           if (!(ebound & (1 << e))) continue;
@@ -180,7 +209,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
           et++;
           if (!(emask & (1 << e))) continue;
           __syncthreads();
-          for (int u = tid; u < NU; u += CUR_THREADS) {
+          for (int u = tid; u < NU; u += GT) {
             const int num = edge_k[e] - (u_min + u);
             const int idx = (M == 1 ? num : (num >> 1)) - sup0;
             if (num >= 0 && (M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) s_out[idx] -= ce[u];   // one u per tick
@@ -189,19 +218,29 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gcorr_kernel(GArgs GA, int TT)
       }
     }
     __syncthreads();
-    for (int i = tid; i < wlen; i += CUR_THREADS) {
+    for (int i = tid; i < wlen; i += GT) {
       const int it = sup0 + i;
-      if (it < A.T) {
-        const double v = ((s_out[i] + s_out[TT + i]) + s_out[2 * TT + i]) + s_out[3 * TT + i];
+      if (it < A.T && !(GA.dbg & 8)) {
+        const double v = s_out[i] + s_out[TT + i];
         out[it] = (it >= it0 && it < T) ? (float)v : 0.f;
       }
     }
     __syncthreads();
   }
-  for (int it = tid; it < A.T; it += CUR_THREADS)
-    if (it < it_w0 || it >= it_w1) out[it] = 0.f;
-  if (lane == 0 && n_mfma) atomicAdd(&A.counters[5], n_mfma * 1024ull);
-  if (tid == 0 && n_useful) atomicAdd(&A.counters[8], n_useful);
+  if (!(A.debug_phases & 0x10000000))             // (timing tools)
+    for (int it = tid; it < A.T; it += GT)
+      if (it < it_w0 || it >= it_w1) out[it] = 0.f;
+  if (GA.dbg & 1) return;
+  if (lane == 0 && n_mfma) stat_add(A.counters, 5, n_mfma * 1024ull);
+  if (tid == 0 && n_useful) stat_add(A.counters, 8, n_useful);
+}
+
+// pairs whose LDS need exceeds the small budget, for the second launch
+__global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict__ gi, int64_t n, int TT, int lds_budget,
+                                                        int32_t* __restrict__ list, unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || gi[i].status != 1) return;
+  if (g_lds_layout(gi[i].ncol, gi[i].NJ, gi[i].NU, TT).bytes > lds_budget) list[atomicAdd(count, 1ull)] = (int32_t)i;
 }
 
 // ---- record offsets: exclusive scan of the sizes pair_setup_kernel wrote ------------------------------------------------------------
@@ -244,7 +283,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if ((rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(n)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_HDR, (size_t)n * sizeof(GInfo)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_ITEMS, (size_t)(n + 16) * 4))) return rc;                    // flags
-  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 2) * 8))) return rc;                 // sizes | offsets (+ total)
+  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 2) * 8 + (size_t)(n + 2) * 4))) return rc;      // sizes | offsets | total, n_big | big list
   SplitArgs S{};
   S.c = a;
   GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
@@ -257,31 +296,44 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if ((rc = sort_exclusive_scan_u64(ctx, d_sz, d_off, n))) return rc;
   hipLaunchKernelGGL(goff_scatter_kernel, dim3(g0), dim3(256), 0, st, gi, n, d_off, d_total);
   HIPCHK(hipGetLastError());
-  unsigned long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
+  GArgs GA{};
+  if ((rc = resp_pad_ensure(ctx, a, &GA.k_lo, &GA.k_hi, &GA.nkp))) return rc;
+  // ticks per tile of the correlation: the pairs' windows are as long as the staged response support (over M) plus their
+  // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
+  const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
+  const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
+  // Two launches of the correlation by LDS need: pairs that fit 19.5 KB run eight to a CU, the rest -- listed here, counted on
+  // the host together with the pool size -- three to a CU.
+  const int lds_small = 19968 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT).bytes;
+  int32_t* d_big = (int32_t*)(d_total + 2);
+  HIPCHK(hipMemsetAsync(d_total + 1, 0, 8, st));
+  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, lds_small, d_big, d_total + 1);
+  HIPCHK(hipGetLastError());
+  unsigned long long h_tot[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h_tot, d_total, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  const unsigned long long total = h_tot[0], n_big = h_tot[1];
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));
-  GArgs GA{};
   GA.c = a;
+  GA.dbg = ctx->debug_gform;
   GA.pp = (const PairParams*)ctx->scratch[SB_PPAR].p;
   GA.gi = gi;
   GA.rec = (double*)ctx->scratch[SB_WBUF].p;
   GA.flags = (int32_t*)ctx->scratch[SB_ITEMS].p;
   GA.glx = ctx->d_glx;
   GA.glw = ctx->d_glw;
-  if ((rc = resp_pad_ensure(ctx, a, &GA.k_lo, &GA.k_hi, &GA.nkp))) return rc;
   GA.resp_pad = (const double*)ctx->resp_pad.p;
   if ((rc = gtables_launch(ctx, GA, M))) return rc;
   HIPCHK(hipEventRecord(ctx->ev[5], st));
-  // ticks per tile of the correlation: the pairs' windows are as long as the staged response support (over M) plus their
-  // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
-  const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
-  const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
-  const size_t dyn = (size_t)NWAVE * TT * 8;
-  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(CUR_THREADS), dyn, st, GA, TT);
-  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(CUR_THREADS), dyn, st, GA, TT);
+  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);
+  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
+  if (n_big > 0) {
+    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, d_big);
+    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, d_big);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   // the pool's size in the statistics slot of the split paths (doubles)
   HIPCHK(hipMemcpyAsync(&counters[7], d_total, 8, hipMemcpyDeviceToDevice, st));

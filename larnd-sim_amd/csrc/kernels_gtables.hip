@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
     if (tid == 0) {
       GA.flags[pair] = status == 2;
-      if (status == 2) atomicAdd(&A.counters[6], 1ull);
+      if (status == 2) stat_add(A.counters, 6, 1ull);
     }
     return;
   }
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
       bool amb;
       sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_first + lane, z,
                              t0, amb);
-      if (amb) atomicAdd(&A.counters[0], 1ull);
+      if (amb) stat_add(A.counters, 0, 1ull);
       dzv = z - s_par[PP_SZ];
       s_dz[lane] = dzv;
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin) {
     if (tid == 0) {
       GA.flags[pair] = 1;
-      atomicAdd(&A.counters[6], 1ull);
+      stat_add(A.counters, 6, 1ull);
     }
     return;
   }
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   if (tid == 0) {
     gip->emask = emask_seen & ebound;
     GA.flags[pair] = 0;
-    atomicAdd(&A.counters[1], (unsigned long long)NQ);
+    if (!(GA.dbg & 1)) stat_add(A.counters, 1, (unsigned long long)NQ);
   }
 }
 

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 5) mac_shift_kernel(SplitArgs S) 
   }
   for (int it = tid; it < A.T; it += CUR_THREADS)
     if (it < it_w0 || it >= it_w1) out[it] = 0.f;
-  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+  if (lane == 0 && n_blocks) stat_add(A.counters, 5, n_blocks * 64ull * 64ull);
 }
 
 // ---- M = 2 (TIME_SAMPLING = 2 RESPONSE_SAMPLING, ndlar): tick t of lane L reads R[kb + 16L + 2j + u] -------------------------
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) mac_shift2_kernel(SplitArgs S)
   }
   for (int it = tid; it < A.T; it += CUR_THREADS)
     if (it < it_w0 || it >= it_w1) out[it] = 0.f;
-  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+  if (lane == 0 && n_blocks) stat_add(A.counters, 5, n_blocks * 64ull * 64ull);
 }
 
 // rows of the response table with RESP_PAD zeros in front and behind, and zeros where mac_kernel's staging would put them

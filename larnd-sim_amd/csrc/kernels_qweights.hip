@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
   const int status = (A.debug_phases & 0x100) ? 0 : P->status;
   if (status != 1) {           // nothing to emit, or handed to the monolithic kernel
     if (tid < HDR_INTS) hdr[tid] = (status == 2 && tid == 7) ? 1 : 0;
-    if (status == 2 && tid == 0) atomicAdd(&A.counters[6], 1ull);
+    if (status == 2 && tid == 0) stat_add(A.counters, 6, 1ull);
     return;
   }
   const int NQ = P->NQ, iz_lo = P->iz_lo, iz_hi = P->iz_hi, it0 = P->it0, T = P->T, it_w0 = P->it_w0, it_w1 = P->it_w1;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
       bool amb;
       sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_first + lane, z,
                              t0, amb);
-      if (amb) atomicAdd(&A.counters[0], 1ull);
+      if (amb) stat_add(A.counters, 0, 1ull);
       dzv = z - s_par[PP_SZ];
       s_dz[lane] = dzv;
       s_shift[lane] = sh;
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     }
     iz_next += n_sl;
   }
-  if (tid == 0) atomicAdd(&A.counters[1], (unsigned long long)NQ);
+  if (tid == 0) stat_add(A.counters, 1, (unsigned long long)NQ);
   __syncthreads();
   if (tid == 0) {
     hdr[0] = s_misc[18] ? 0 : s_misc[16];
@@ -563,10 +563,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
     hdr[7] = s_misc[18];            // 1 = capacity overflow: the monolithic kernel recomputes this pair
     int r = min(s_misc[19], RUNS_MAX);
     hdr[8 + r] = s_misc[16];
-    if (s_misc[18]) atomicAdd(&A.counters[6], 1ull);
+    if (s_misc[18]) stat_add(A.counters, 6, 1ull);
     else {
       const int ticks = min(T, it_w1) - max(it0, it_w0);
-      if (ticks > 0 && s_misc[21] > 0) atomicAdd(&A.counters[8], (unsigned long long)s_misc[21] * (unsigned long long)ticks);
+      if (ticks > 0 && s_misc[21] > 0) stat_add(A.counters, 8, (unsigned long long)s_misc[21] * (unsigned long long)ticks);
     }
   }
 }

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
     double tt = g.t_start + it_ref * dt;
     double val = (tt - t0) / dtr;
     double kr = py_round(val);
-    if (count && fabs(val - kr) > 0.5 - 1e-7) atomicAdd(&A.counters[0], 1ull);
+    if (count && fabs(val - kr) > 0.5 - 1e-7) stat_add(A.counters, 0, 1ull);
     return (int)kr - M * it_ref;
   };
   {
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
     }
     iz_next += n_sl;
   }
-  if (lane == 0 && n_surv) atomicAdd(&A.counters[1], n_surv);
+  if (lane == 0 && n_surv) stat_add(A.counters, 1, n_surv);
   __syncthreads();
   if (tid == 0) {
     hdr[0] = s_misc[18] ? 0 : s_misc[16];
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) weights_kernel(SplitArgs S) {
     hdr[7] = s_misc[18];            // 1 = capacity overflow: the monolithic kernel recomputes this pair
     int r = min(s_misc[19], RUNS_MAX);
     hdr[8 + r] = s_misc[16];
-    if (s_misc[18]) atomicAdd(&A.counters[6], 1ull);
+    if (s_misc[18]) stat_add(A.counters, 6, 1ull);
   }
 }
 
@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 4 : 3)) mac_kernel(Spli
   }
   for (int it = tid; it < A.T; it += CUR_THREADS)
     if (it < it_w0 || it >= it_w1) out[it] = 0.f;
-  if (lane == 0 && n_blocks) atomicAdd(&A.counters[5], n_blocks * 64ull * 64ull);
+  if (lane == 0 && n_blocks) stat_add(A.counters, 5, n_blocks * 64ull * 64ull);
 }
 
 // =============================================================================================================

@@ -9,7 +9,7 @@
 #include <new>
 #include <vector>
 
-#include "ldsim_dev.h"
+#include "ldsim_args.h"
 
 // ---- launchers defined in the kernel translation units ----------------------------------------------------
 struct CurArgs;
@@ -254,6 +254,8 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     if (!ctx->h_resp_kmax.empty()) resp_support_update(ctx);
   }
   else if (!strcmp(name, "debug_phases")) ctx->debug_phases = (int)value;
+  else if (!strcmp(name, "debug_lds_pad_kb")) ctx->debug_lds_pad_kb = value >= -40 && value <= 16 ? (int)value : 0;
+  else if (!strcmp(name, "debug_gform")) ctx->debug_gform = (int)value;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;
@@ -529,7 +531,7 @@ extern "C" int ldsim_segments_reset(ldsim_ctx* ctx) {
 }
 
 static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {
-  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
   int* d_err = (int*)ctx->scratch[SB_MISC].p;
   HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
   CK(seg_launch_quench_drift(ctx, mode, do_q, do_d, d_err));
@@ -570,7 +572,7 @@ extern "C" int ldsim_max_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, c
                                 int64_t* n_max_pixels) {
   NEED(n_max_pixels, "null output");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
-  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
   char* m = (char*)ctx->scratch[SB_MISC].p;
   HIPCHK(hipMemsetAsync(m, 0, 64, ctx->stream));
   CK(seg_launch_max_pixels(ctx, 0, n, (int32_t*)(m + 8), (unsigned long long*)(m + 16)));
@@ -610,7 +612,7 @@ extern "C" int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t 
   NEED(track_starts && time_max, "null output");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8 + 8));
-  CK(ldsim_ensure(ctx, SB_MISC, 4096));
+  CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
   char* m = (char*)ctx->scratch[SB_MISC].p;
   HIPCHK(hipMemsetAsync(m, 0, 64, ctx->stream));
   CK(seg_launch_time_intervals(ctx, 0, n, (double*)ctx->scratch[SB_STARTS].p, (int32_t*)(m + 24)));

@@ -2,6 +2,26 @@
 #pragma once
 #include "ldsim_dev.h"
 
+// Statistics of a launch: 16 u64 at `counters`, then STAT_STRIPES copies of the block that the kernels add to -- one
+// workgroup, one stripe (blockIdx mod STAT_STRIPES).  A single address took 1.6 M device-scope atomics per launch from
+// gcorr_kernel alone and cost it 2.7 ms of 11 (profiles/r03_phases_gform.log); the host sums the stripes after the download.
+// Values read on the device or by a direct copy (sort: [4], pool cursor: [7]) stay in the flat block.
+#define STAT_STRIPES 64
+#define STAT_WORDS (16 * (1 + STAT_STRIPES))
+#define STAT_BYTES (8 * STAT_WORDS)
+#define MISC_BYTES (256 + STAT_BYTES + 256)
+#ifdef __HIPCC__
+__device__ __forceinline__ void stat_add(unsigned long long* counters, int i, unsigned long long v) {
+  atomicAdd(&counters[16 * (1 + (blockIdx.x & (STAT_STRIPES - 1))) + i], v);
+}
+#endif
+static inline void stat_sum(const unsigned long long* raw, unsigned long long* sum16) {
+  for (int i = 0; i < 16; i++) {
+    sum16[i] = raw[i];
+    for (int s = 0; s < STAT_STRIPES; s++) sum16[i] += raw[16 * (1 + s) + i];
+  }
+}
+
 struct CurArgs {
   SegStore s;
   const LdsimConsts* c;

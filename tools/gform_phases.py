@@ -21,9 +21,15 @@ ch = ChargeChain(H.response_for(resp))
 ch.upload(seg, bid)
 ch.quench_drift()
 ch.run(0, len(seg), want_fractions=True)
-for mask in (0, 0x100000, 0x200000, 0x400000, 0x800000, 0xA00000, 0x1000000, 0x2000000, 0x4000000, 0x6000000, 0x8000000, 0xE000000, 0):
+# pad: KB off the LDS budget of gcorr's small class (19.5 KB); dbg: option debug_gform (1 no counter atomics, 2 no edge rows,
+# 4 no X / Y / Z staging in gcorr, 8 no stores of the result)
+for mask, pad, dbg in ((0, 0, 0), (0, 0, 1), (0, 0, 3), (0x100000, 0, 0), (0x100000, 0, 1), (0x100000, 0, 3), (0x100000, 0, 7),
+                       (0x10100000, 0, 15), (0x200000, 0, 0), (0x1000000, 0, 0), (0, 0, 0)):
     lib.set_option("debug_phases", 15 | mask)
+    lib.set_option("debug_lds_pad_kb", pad)
+    lib.set_option("debug_gform", dbg)
     st = ch.run(0, len(seg), want_fractions=True)
     ms = ch.kernel_ms()
-    print(f"{cfg} {resp} debug_phases {mask:#10x}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
+    print(f"{cfg} {resp} debug_phases {mask:#10x} lds pad {pad:2d} KB dbg {dbg:2d}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
 lib.set_option("debug_phases", 15)
+lib.set_option("debug_gform", 0)
