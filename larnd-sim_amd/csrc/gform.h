@@ -38,15 +38,16 @@ struct GInfo {
 //     X         16 * ncol                   X[n][col]
 //     Y         16 * NJ                     Y[n][j]
 //     Z         16 * NUr                    Z[n][u]; NUr = NU rounded up to 16
-//     C         popcount(edge_bound) * NUr  per possible window edge: what the slices that are invalid at that edge put on it,
-//                                           per shift bin (gtables_kernel multiplies their Z sums with G_n[edge_k] itself)
+//     Zi        popcount(edge_bound) * 16 * NUr   per possible window edge: Z over the slices that are invalid at that edge only
+//                                           (gcorr_kernel takes their share of the one tick the edge maps to back: one more
+//                                           16-node product against the column G_n[edge_k] it holds anyway)
 __host__ __device__ __forceinline__ int g_nur(int NU) { return (NU + 15) & ~15; }
 __host__ __device__ __forceinline__ int g_popc3(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1); }
 __host__ __device__ __forceinline__ unsigned long long g_cells_doubles(int ncol, int NJ) {
   return 1ull + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
 }
 __host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound) {
-  return g_cells_doubles(ncol, NJ) + 16ull * ncol + 16ull * NJ + (16ull + g_popc3(edge_bound)) * g_nur(NU);
+  return g_cells_doubles(ncol, NJ) + 16ull * ncol + 16ull * NJ + 16ull * (1 + g_popc3(edge_bound)) * g_nur(NU);
 }
 __host__ __device__ __forceinline__ unsigned long long g_record_doubles(int NB, int ncol, int NJ, int NU, int edge_bound) {
   return G_HDR / 2 + (unsigned long long)NB * g_batch_doubles(ncol, NJ, NU, edge_bound);

@@ -38,7 +38,7 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   L.z_lds = NU <= G_NUCAP;                           // the steepest long segments read Z from the record (L2)
   L.zs = L.z_lds ? ((nur & 31) == 16 ? nur : nur + 16) : 0;      // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
   L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-  L.bytes = 8 * (GW * TT + G_NODES * (L.xs + L.ys + L.zs)) + 4 * ((ncol + 1) & ~1) + 2 * L.cellcap + 16;
+  L.bytes = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys + L.zs)) + 4 * ((ncol + 1) & ~1) + 2 * L.cellcap + 16;
   return L;
 }
 
@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
 
   extern __shared__ double s_dyn[];
   double* s_out = s_dyn;                            // [GW][TT]
-  double* s_X = s_out + GW * TT;                    // [16][xs]
+  double* s_gs = s_out + GW * TT;                   // [GW][16]: a wave's column G_n[edge_k]
+  double* s_X = s_gs + GW * G_NODES;                // [16][xs]
   double* s_Y = s_X + G_NODES * L.xs;               // [16][ys]
   double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
   int* s_rowbase = (int*)(s_Z + G_NODES * L.zs);    // [ncol]: response row of (col, j = 0)
@@ -96,7 +97,6 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
       const double* gX = brec + cells_d;
       const double* gY = gX + 16 * ncol;
       const double* gZ = gY + 16 * NJ;
-      const double* gC = gZ + 16 * NUr;
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
         // the record's loads in flight four rounds at a time before their first use
@@ -198,21 +198,39 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
         if (!(A.debug_phases & 0x200000)) {
           pstep(acc0, k0);
           pstep(acc1, k0 + 16);
-        }
-      }
-      // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to
-      if (emask && !(GA.dbg & 2)) {
-        int et = 0;
-        for (int e = 0; e < NEDGE; e++) {
-          if (!(ebound & (1 << e))) continue;
-          const double* ce = gC + (unsigned long long)et * NUr;
-          et++;
-          if (!(emask & (1 << e))) continue;
-          __syncthreads();
-          for (int u = tid; u < NU; u += GT) {
-            const int num = edge_k[e] - (u_min + u);
-            const int idx = (M == 1 ? num : (num >> 1)) - sup0;
-            if (num >= 0 && (M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) s_out[idx] -= ce[u];   // one u per tick
+          // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to,
+          // sum_n Zi_e[n][u] G_n[edge_k[e]] per shift u.  The column of G sits in four lanes of this wave's accumulators
+          // (register r of lane 16 q + col = G[4 r + q][k0 + col]): through LDS to all lanes, one shift per lane.
+          if (emask && !(GA.dbg & 2)) {
+            int et = 0;
+            for (int e = 0; e < NEDGE; e++) {
+              if (!(ebound & (1 << e))) continue;
+              const double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
+              et++;
+              const int ke = edge_k[e];
+              if (!(emask & (1 << e)) || ke < k0 || ke >= k0 + 32) continue;
+              const bool hi = ke >= k0 + 16;
+              if (jj == ((ke - k0) & 15)) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_gs[wv * G_NODES + 4 * r + kk] = hi ? acc1[r] : acc0[r];
+              }
+              wsync();
+              for (int u = lane; u < NU; u += 64) {
+                double cv = 0;
+#pragma unroll 1
+                for (int n0 = 0; n0 < G_NODES; n0 += 4) {       // (four loads in flight: more would spill)
+                  double zv[4];
+#pragma unroll
+                  for (int n = 0; n < 4; n++) zv[n] = gZi[(n0 + n) * NUr + u];
+#pragma unroll
+                  for (int n = 0; n < 4; n++) cv = fma(zv[n], s_gs[wv * G_NODES + n0 + n], cv);
+                }
+                const int num = ke - (u_min + u);
+                const int idx = (M == 1 ? num : (num >> 1)) - sup0;
+                if ((M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) atomicAdd(&ow[idx], -cv);
+              }
+              wsync();
+            }
           }
         }
       }

@@ -45,7 +45,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 1], s_ustart[NU_MAX + 1];
   __shared__ int s_misc[24], s_wcnt[NWAVE];
   __shared__ unsigned short s_cells[G_CELLCAP];     // col | j << 6 of the listed cells
-  __shared__ double s_qpart[G_NODES][G_NODES + 1], s_Q[G_NODES];
 
   if (tid < PP_COUNT) s_par[tid] = ((const double*)((const char*)P + 32))[tid];
   {
@@ -274,7 +273,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
     // ---- Z tables: slices in chunks, every (shift bin, node) entry owned by one thread; shift range in parts of G_NUCAP bins
     // (one part for all but the steepest centimetre-long segments).  e < 0: all slices (and the per-node totals for the cell
     // test); e >= 0: the slices that are invalid at window edge e.
-    auto ztable = [&](int e, double* gdst) {      // gdst: Z[16][NUr] (e < 0) or the correction row C[NUr] of edge e
+    auto ztable = [&](int e, double* gdst) {      // gdst: Z[16][NUr] (e < 0: all slices) or Zi_e[16][NUr]
       for (int pu0 = 0; pu0 < NU; pu0 += G_NUCAP) {
         const int pw = min(G_NUCAP, NUr - pu0);                  // columns of this part incl. the zero padding to 16
         __syncthreads();
@@ -310,28 +309,22 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
           iz_next += n_sl;
         }
         __syncthreads();
-        if (e < 0) {
+        if (!(GA.dbg & 16))
           for (int i = tid; i < G_NODES * pw; i += CUR_THREADS) gdst[(i / pw) * NUr + pu0 + i % pw] = s_Z[i / pw][i % pw];
-          if (tid < G_NODES) {
-            double t = pu0 ? s_zs[tid] : 0.0;
-            for (int u = 0; u < pw; u++) t += s_Z[tid][u];
-            s_zs[tid] = t;
-          }
-        } else {
-          // C_e[u] = sum_n Zi_e[n][u] G_n[edge_k[e]]: what gcorr_kernel takes back from tick (edge_k[e] - u_min - u) / M
-          for (int u = tid; u < pw; u += CUR_THREADS) {
-            double cv = 0;
-            for (int n = 0; n < nb; n++) cv = fma(s_Z[n][u], s_Q[n], cv);
-            gdst[pu0 + u] = cv;
-          }
+        if (e < 0 && tid < G_NODES) {
+          double t = pu0 ? s_zs[tid] : 0.0;
+          for (int u = 0; u < pw; u++) t += s_Z[tid][u];
+          s_zs[tid] = t;
         }
       }
     };
     ztable(-1, gZ);
     __syncthreads();
     // ---- tables to the record -----------------------------------------------------------------------------------------------------
-    for (int i = tid; i < G_NODES * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
-    for (int i = tid; i < G_NODES * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
+    if (!(GA.dbg & 16)) {
+      for (int i = tid; i < G_NODES * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
+      for (int i = tid; i < G_NODES * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
+    }
     // ---- cells that can carry weight: sum over the nodes and all shifts of X Y Z above the pruning threshold (every
     // (cell, shift) bin the weight kernels would keep lies in such a cell); list in (column, j) order ------------------------------------
     {
@@ -373,34 +366,16 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
       n_cells_b = base;
     }
     // ---- window edges some slice of the pair is invalid at (detsim.py:418-428): the correlation uses every slice's weight at
-    // every tick; here the invalid slices' share of the one tick an edge maps to is computed -- their Z sums (the same table
-    // code over those slices only) times G_n[edge_k] = sum_cells X_n Y_n R[cell][edge_k] over the listed cells -- for gcorr_kernel
-    // to take back.
+    // every tick; the Z table over the invalid slices alone (the same table code) lets gcorr_kernel take their share of the one
+    // tick an edge maps to back.
     {
       int et = 0;
       for (int e = 0; e < NEDGE; e++) {
-        if (!(ebound & (1 << e))) continue;
-        double* gC = gZ + 16ull * NUr + (unsigned long long)et * NUr;
+        if (!(ebound & (1 << e)) || (GA.dbg & 32)) continue;
+        double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
         et++;
-        __syncthreads();
-        {
-          const int n = tid & 15, ch = tid >> 4;
-          double part = 0;
-          for (int i = ch; i < n_cells_b; i += 16) {
-            const unsigned ce = s_cells[i];
-            const unsigned cc = ce & 63u, jc = (ce >> 6) & 63u;
-            const double r = A.resp[(int64_t)(s_coli[cc] * A.nj + (jmin + (int)jc)) * A.nk + edge_k[e]];
-            part = fma(s_X[n][cc] * s_Y[n][jc], r, part);
-          }
-          s_qpart[n][ch] = part;
-        }
-        __syncthreads();
-        if (tid < G_NODES) {
-          double q = 0;
-          for (int ch = 0; ch < 16; ch++) q += s_qpart[tid][ch];
-          s_Q[tid] = q;
-        }
-        ztable(e, gC);       // (its first barrier orders s_Q)
+        if (!(emask_seen & (1 << e))) continue;      // (gcorr_kernel skips the table)
+        ztable(e, gZi);
       }
     }
   }
