@@ -140,7 +140,9 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * segment, then the correlation kernel of "mac_mode"; 0 = weights_kernel, the closed form per charge sample),
  * "gform_max_support" (weights_mode 2 runs the node-separable form for response tables whose staged support is at most this
  * many time ticks, default 768, and the kernels of weights_mode 1 for wider ones: the matrix form pays per response tick, the
- * shifted-window kernels per 512-tick tile; 0 = never, 1e9 = always), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
+ * shifted-window kernels per 512-tick tile; 0 = never, 1e9 = always), "gform_wave_tables" (weights_mode 2, tables stage: 1 =
+ * gtables_wave_kernel, one wave per pair, for the pairs that fit it and gtables_kernel, one workgroup per pair, for the rest
+ * (default); 0 = gtables_kernel for all: same tables entry for entry), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
  * "quad_accuracy_log10" (qweights_kernel: node count for a quadrature error of 1e-10 (default) or 1e-12 of the peak weight),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows

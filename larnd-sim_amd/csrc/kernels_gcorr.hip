@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) goff_scatter_kernel(GInfo* __restrict__ g
 }
 
 int sort_exclusive_scan_u64(ldsim_ctx*, const unsigned long long*, unsigned long long*, int64_t);
-extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M);
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* list, int64_t n_list);
+extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* list, unsigned long long* count);
 extern "C++" int resp_pad_ensure(ldsim_ctx* ctx, const CurArgs& A, int* k_lo, int* k_hi, int* nkp);
 
 // M of the form for these constants, 0 = configuration not covered (caller uses the monolithic kernel)
@@ -301,7 +302,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if ((rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(n)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_HDR, (size_t)n * sizeof(GInfo)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_ITEMS, (size_t)(n + 16) * 4))) return rc;                    // flags
-  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 2) * 8 + (size_t)(n + 2) * 4))) return rc;      // sizes | offsets | total, n_big | big list
+  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 4) * 8 + (size_t)(2 * n + 2) * 4))) return rc;      // sizes | offsets | total, n_big, n_wg | big list | wg list
   SplitArgs S{};
   S.c = a;
   GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
@@ -323,18 +324,22 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // Two launches of the correlation by LDS need: pairs that fit 19.5 KB run eight to a CU, the rest -- listed here, counted on
   // the host together with the pool size -- three to a CU.
   const int lds_small = 19968 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT).bytes;
-  int32_t* d_big = (int32_t*)(d_total + 2);
-  HIPCHK(hipMemsetAsync(d_total + 1, 0, 8, st));
+  int32_t* d_big = (int32_t*)(d_total + 4);
+  int32_t* d_wg = d_big + n;                       // the pairs the tables stage gives to its workgroup kernel
+  HIPCHK(hipMemsetAsync(d_total + 1, 0, 16, st));
   hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, lds_small, d_big, d_total + 1);
   HIPCHK(hipGetLastError());
-  unsigned long long h_tot[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(h_tot, d_total, 16, hipMemcpyDeviceToHost, st));
+  GA.gi = gi;
+  GA.dbg = (ctx->debug_gform & ~64) | (ctx->gform_wave_tables ? 0 : 64);
+  GA.c.n_pairs = n;
+  if ((rc = gtables_list_launch(ctx, GA, d_wg, d_total + 2))) return rc;
+  unsigned long long h_tot[3] = {0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h_tot, d_total, 24, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  const unsigned long long total = h_tot[0], n_big = h_tot[1];
+  const unsigned long long total = h_tot[0], n_big = h_tot[1], n_wg = h_tot[2];
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));
   GA.c = a;
-  GA.dbg = ctx->debug_gform;
   GA.pp = (const PairParams*)ctx->scratch[SB_PPAR].p;
   GA.gi = gi;
   GA.rec = (double*)ctx->scratch[SB_WBUF].p;
@@ -342,7 +347,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   GA.glx = ctx->d_glx;
   GA.glw = ctx->d_glw;
   GA.resp_pad = (const double*)ctx->resp_pad.p;
-  if ((rc = gtables_launch(ctx, GA, M))) return rc;
+  if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg))) return rc;
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);
   else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);

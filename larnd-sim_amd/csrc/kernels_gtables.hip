@@ -15,15 +15,15 @@
 #define GQN_LDS 64        // nodes of a rule kept in LDS (longer rules read the table)
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
+__global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const int32_t* __restrict__ list) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t pair = blockIdx.x;
+  const int64_t pair = list[blockIdx.x];       // the pairs gtables_wave_kernel does not take (it also flags the ones without a record)
   if (pair >= A.n_pairs) return;
   GInfo* __restrict__ gip = GA.gi + pair;
   const int status = (A.debug_phases & 0x100) ? 0 : gip->status;
-  if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
+  if (status != 1) {
     if (tid == 0) {
       GA.flags[pair] = status == 2;
       if (status == 2) stat_add(A.counters, 6, 1ull);
@@ -386,10 +386,379 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA) {
   }
 }
 
-extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M) {
-  if (GA.c.n_pairs == 0) return 0;
-  if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)GA.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, GA);
-  else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)GA.c.n_pairs), dim3(CUR_THREADS), 0, ctx->stream, GA);
+
+// ---- one wave per pair ---------------------------------------------------------------------------------------------------------
+// gtables_wave_kernel: the same tables for the pairs whose slices fit one chunk (<= 64 slices, <= 64 shifts) and whose X and Y
+// bins together fit 40 columns (GInfo.wave_ok: all but the longest segments).  A wave owns the pair: no workgroup barrier
+// anywhere, 16 pairs in flight per CU instead of 4, and every phase fills its 64 lanes as (16 table bins) x (4 nodes), each lane
+// carrying nodes q, 4 + q, 8 + q, 12 + q of its bin -- so a bin's member loop is shared by four nodes, the invalid-slice tables
+// of the window edges accumulate in the same pass as Z from the same Gaussians, and no index needs a division.
+// Entry for entry the same expressions and term order as gtables_kernel (the cell test sums the Z totals in another order).
+#define GW_XYS 41         // row stride of the joint X | Y table
+
+template <int M>
+__global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
+  const CurArgs& A = GA.c;
+  const LdsimConsts* c = A.c;
+  const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
+  const int64_t pair = blockIdx.x;
+  if (pair >= A.n_pairs) return;
+  GInfo* __restrict__ gip = GA.gi + pair;
+  const int status = (A.debug_phases & 0x100) ? 0 : gip->status;
+  if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
+    if (lane == 0) {
+      GA.flags[pair] = status == 2;
+      if (status == 2) stat_add(A.counters, 6, 1ull);
+    }
+    return;
+  }
+  if (!gip->wave_ok || (GA.dbg & 64)) return;      // gtables_kernel's pair
+  const int ncol_g = gip->ncol, NJ_g = gip->NJ, u_min = gip->u_min, NU = gip->NU, ebound = gip->edge_bound, NB = gip->NB;
+  double* __restrict__ rec = GA.rec + gip->off;
+  const PairParams* __restrict__ P = GA.pp + pair;
+  const int NQ = P->NQ, iz_lo = P->iz_lo, iz_hi = P->iz_hi, it0 = P->it0, T = P->T, it_w0 = P->it_w0, it_w1 = P->it_w1;
+  const int NUr = g_nur(NU);
+
+  __shared__ double s_par[32];
+  __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
+  __shared__ double s_XY[G_NODES][GW_XYS], s_zs[G_NODES];
+  __shared__ unsigned char s_invs[ZC];
+  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[NU_MAX + 1];
+
+  if (lane < PP_COUNT) s_par[lane] = ((const double*)((const char*)P + 32))[lane];
+  wsync();
+  const int NS = c->sampled_points;
+  const double bin = c->response_bin_size;
+  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
+  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  bool bad = false;          // (wave-uniform) inconsistent with the set-up pass: monolithic kernel
+
+  // ---- sample -> response cell maps, member lists ordered by response index ----------------------------------------------------------
+  int ncol, jmin, NJ;
+  {
+    int i = -1;
+    double ddx = 0;
+    if (lane < NS) {
+      double x = s_par[PP_X_START] + s_par[PP_SGNX] * (lane * s_par[PP_X_STEP] - 4 * s_par[PP_ST]);
+      double xd = fabs(s_par[PP_X_P] - x);
+      if (!(xd > bin * A.ni)) {
+        i = (int)py_round(xd / bin - 0.5);
+        if (i < 0 || i >= A.ni) i = -1;
+      }
+      ddx = x - s_par[PP_SX];
+    }
+    const bool valid = lane < NS && i >= 0;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    unsigned long long present = 0;
+    {
+      const int mlo = wave_lane_i32(wave_scan_i32(valid && i < 32 ? (1 << i) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      const int mhi = wave_lane_i32(wave_scan_i32(valid && i >= 32 ? (1 << (i - 32)) : 0, 0, [](int a, int b) { return a | b; }), 63);
+      present = (unsigned long long)(unsigned)mlo | ((unsigned long long)(unsigned)mhi << 32);
+    }
+    const int slot = valid ? __popcll(present & ((1ull << i) - 1ull)) : 0;    // rank of this column's i among the distinct i
+    ncol = __popcll(present);
+    int posn = 0;
+    bool is_leader = false;
+    for (unsigned long long m = present; m; m &= m - 1) {
+      const int bcell = __ffsll((long long)m) - 1;
+      const unsigned long long bal = __ballot(valid && i == bcell);
+      if (valid && i > bcell) posn += __popcll(bal);
+      if (valid && i == bcell) {
+        const int before = __popcll(bal & lane_lt);
+        posn += before;
+        is_leader = before == 0;
+      }
+    }
+    if (is_leader) s_coli[slot] = (short)i;
+    if (valid) s_dxs[posn] = ddx;
+    if (is_leader) s_colstart[slot] = (short)posn;
+    const int nvalid = __popcll(__ballot(valid));
+    if (lane == 0) s_colstart[ncol] = (short)nvalid;
+  }
+  {
+    int j = -1;
+    double ddy = 0;
+    if (lane < NS) {
+      double y = s_par[PP_Y_START] + s_par[PP_SGNY] * (lane * s_par[PP_Y_STEP] - 4 * s_par[PP_ST]);
+      double yd = fabs(s_par[PP_Y_P] - y);
+      if (!(yd > bin * A.nj)) {
+        j = (int)py_round(yd / bin - 0.5);
+        if (j < 0 || j >= A.nj) j = -1;
+      }
+      ddy = y - s_par[PP_SY];
+    }
+    jmin = wave_min_i32((j >= 0) ? j : (1 << 20));
+    const int jmax = wave_max_i32(j);
+    NJ = jmax - jmin + 1;
+    int posn = 0, below = 0;
+    if (jmax >= jmin) {
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bj = jmin; bj <= jmax; bj++) {               // the few distinct j, one ballot each
+        const unsigned long long bal = __ballot(j == bj);
+        const int cnt = __popcll(bal);
+        if (j > bj) posn += cnt;
+        if (j == bj) posn += __popcll(bal & lane_lt);
+        if (bj < jmin + lane) below += cnt;
+      }
+    }
+    if (j >= 0) s_dys[posn] = ddy;
+    if (jmax >= jmin && lane <= NJ && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
+  }
+  if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin || ncol + NJ > GW_XYS - 1) bad = true;
+
+  // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
+  int n_sl, lo_c, NUc, anyinv = 0;
+  {
+    const int nmax = min(ZC, iz_hi - iz_lo + 1);
+    int sh = 0, inval = 0;
+    double dzv = 0;
+    if (lane < nmax) {
+      double z, t0;
+      bool amb;
+      sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_lo + lane, z, t0,
+                             amb);
+      if (amb) stat_add(A.counters, 0, 1ull);
+      dzv = z - s_par[PP_SZ];
+#pragma unroll
+      for (int e = 0; e < NEDGE; e++) {
+        bool need = false;      // (as gtables_kernel's chunk set-up)
+        const int num = edge_k[e] - sh;
+        if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
+          const int it_e = num / M;
+          if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
+            int64_t kk;
+            need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
+          }
+        }
+        if (need) inval |= 1 << e;
+      }
+    }
+    const int lo = wave_min_i32(lane < nmax ? sh : (1 << 30)), hi = wave_max_i32(lane < nmax ? sh : -(1 << 30));
+    n_sl = nmax;
+    lo_c = lo;
+    NUc = hi - lo + 1;
+    if (nmax != iz_hi - iz_lo + 1 || NUc > NU_MAX || NUc != NU || lo != u_min) bad = true;
+    if (!bad) {
+      int posn = 0, below = 0;
+      const unsigned long long lane_lt = (1ull << lane) - 1ull;
+      for (int bs = lo; bs <= hi; bs++) {                    // the distinct shifts (<= NU_MAX), one ballot each
+        const unsigned long long bal = __ballot(lane < nmax && sh == bs);
+        const int cnt = __popcll(bal);
+        if (lane < nmax && sh > bs) posn += cnt;
+        if (lane < nmax && sh == bs) posn += __popcll(bal & lane_lt);
+        if (bs < lo + lane) below += cnt;
+      }
+      if (lane < nmax) {
+        s_dzs[posn] = dzv;
+        s_invs[posn] = (unsigned char)inval;
+      }
+      if (lane < NUc) s_ustart[lane] = (short)below;
+      if (lane == 0) s_ustart[NUc] = (short)nmax;
+#pragma unroll
+      for (int e = 0; e < NEDGE; e++)
+        if (__ballot(lane < nmax && (inval & (1 << e)))) anyinv |= 1 << e;
+    }
+  }
+  if (bad) {
+    if (lane == 0) {
+      GA.flags[pair] = 1;
+      stat_add(A.counters, 6, 1ull);
+    }
+    return;
+  }
+  wsync();
+  if (A.debug_phases & 0x1000000) return;      // timing tools: stop after the maps
+
+  const double* gx_tab = GA.glx + (int64_t)NQ * (NQ - 1) / 2;
+  const double* gw_tab = GA.glw + (int64_t)NQ * (NQ - 1) / 2;
+  const bool do_prune = A.prune_log > 0;
+  const double uxr = s_par[PP_UXR], uyr = s_par[PP_UYR], uzr = s_par[PP_UZR], i2T = s_par[PP_I2T], i2L = s_par[PP_I2L];
+  const double kappa = s_par[PP_KAPPA], s_lo = s_par[PP_S_LO], qlen = s_par[PP_QLEN], wscale = s_par[PP_WSCALE];
+  const double thr = s_par[PP_THR];
+  const unsigned long long cells_d = g_cells_doubles(ncol, NJ);
+  const unsigned long long batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
+  const int emask = anyinv & ebound;
+  const int nbins = ncol + NJ;
+  const unsigned nj_inv = (1u << 20) / (unsigned)NJ + 1u;      // cc / NJ = cc * nj_inv >> 20 for cc < 2048, NJ <= 48
+
+  for (int b = 0; b < NB; b++) {
+    const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
+    double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[2 + e])
+    double* gX = brec + cells_d;
+    double* gY = gX + 16 * ncol;
+    double* gZ = gY + 16 * NJ;
+    // this lane's four nodes: position along the segment and weight (a node past the batch's last one: rows of zeros)
+    double sn[4], wn[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int n = 4 * m + q;
+      const bool on = n < nb;
+      const double gx = on ? gx_tab[n0 + n] : 0.0, gw = on ? gw_tab[n0 + n] : 0.0;
+      sn[m] = s_lo + 0.5 * qlen * (1.0 + gx);
+      double w = wscale * gw;
+      if (kappa != 0.0) w *= exp_neg(-sn[m] * sn[m] * kappa);
+      wn[m] = on ? w : 0.0;
+    }
+    wsync();          // the previous batch's tables are no longer read
+    // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
+    for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
+      const int bi = b0 + u16;
+      const bool act = bi < nbins, isx = bi < ncol;
+      const int bb = isx ? bi : bi - ncol;
+      int k = 0, ke = 0;
+      if (act) {
+        k = isx ? s_colstart[bb] : s_jstart[bb];
+        ke = isx ? s_colstart[bb + 1] : s_jstart[bb + 1];
+      }
+      const double* src = isx ? s_dxs : s_dys;
+      const double ur = isx ? uxr : uyr;
+      double cen[4], sum[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; m++) cen[m] = sn[m] * ur;
+      for (; __ballot(k < ke); k++) {
+        if (k < ke) {
+          const double dd = src[k];
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const double d = dd - cen[m];
+            sum[m] += exp_neg(-d * d * i2T);
+          }
+        }
+      }
+      if (act) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int n = 4 * m + q;
+          const double v = n < nb ? sum[m] : 0.0;
+          s_XY[n][bi] = v;
+          if (!(GA.dbg & 16)) {
+            if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
+          }
+        }
+      }
+    }
+    // ---- Z and, from the same Gaussians, the tables over the slices that are invalid at a window edge -----------------------------------------
+    double zsp[4] = {0, 0, 0, 0};
+    {
+      double cen[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) cen[m] = sn[m] * uzr;
+      for (int u0 = 0; u0 < NUr; u0 += 16) {
+        const int ub = u0 + u16;
+        int k = 0, ke = 0;
+        if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
+        double z[4] = {0, 0, 0, 0}, zi[NEDGE][4];
+#pragma unroll
+        for (int e = 0; e < NEDGE; e++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) zi[e][m] = 0;
+        for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+          if (k < ke) {
+            const double dd = s_dzs[k];
+            const int inv = s_invs[k];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+              const double d = dd - cen[m];
+              const double g = exp_neg(-d * d * i2L);
+              z[m] += g;
+#pragma unroll
+              for (int e = 0; e < NEDGE; e++)
+                if (emask & (1 << e)) zi[e][m] += (inv & (1 << e)) ? g : 0.0;
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int n = 4 * m + q;
+          const double v = 0.0 + wn[m] * z[m];
+          zsp[m] += v;
+          if (!(GA.dbg & 16)) gZ[n * NUr + ub] = v;
+        }
+        int et = 0;
+#pragma unroll
+        for (int e = 0; e < NEDGE; e++) {
+          if (!(ebound & (1 << e))) continue;
+          double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
+          et++;
+          if (!(emask & (1 << e)) || (GA.dbg & 48)) continue;      // (gcorr_kernel skips the table)
+#pragma unroll
+          for (int m = 0; m < 4; m++) gZi[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[e][m];
+        }
+      }
+    }
+    // per-node totals over the shifts (cell test): row sums over the 16 lanes of a node group
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      double v = zsp[m];
+      v += wdpp_f64<0x111, 0xF>(0.0, v);
+      v += wdpp_f64<0x112, 0xF>(0.0, v);
+      v += wdpp_f64<0x114, 0xF>(0.0, v);
+      v += wdpp_f64<0x118, 0xF>(0.0, v);
+      if (u16 == 15) s_zs[4 * m + q] = v;
+    }
+    wsync();
+    // ---- cells that can carry weight (as gtables_kernel), in (column, j) order ----------------------------------------------------------------
+    {
+      const int ncand = ncol * NJ;
+      int base = 0;
+      unsigned first_code = 0;
+      for (int c0 = 0; c0 < ncand && !(A.debug_phases & 0x8000000); c0 += 64) {
+        const int cc = c0 + lane;
+        bool keep = false;
+        int col = 0, jj = 0;
+        if (cc < ncand) {
+          col = (int)(((unsigned)cc * nj_inv) >> 20); jj = cc - col * NJ;
+          double w = 0;
+#pragma unroll 4
+          for (int n = 0; n < G_NODES; n++) w = fma(s_XY[n][col] * s_XY[n][ncol + jj], s_zs[n], w);
+          keep = do_prune ? w > thr : w != 0.0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
+        if (keep) cells[2 + base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)ce;
+        if (base == 0 && bal) first_code = (unsigned)__builtin_amdgcn_readlane((int)ce, __ffsll((long long)bal) - 1);
+        base += __popcll(bal);
+      }
+      const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
+      // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
+      if (lane < padded - base && base > 0) cells[2 + base + lane] = (int)(0x80000000u | first_code);
+      if (lane == 0) { cells[0] = padded; cells[1] = base; }
+    }
+  }
+  if (lane == 0) {
+    gip->emask = emask;
+    GA.flags[pair] = 0;
+    if (!(GA.dbg & 1)) stat_add(A.counters, 1, (unsigned long long)NQ);
+  }
+}
+
+// the pairs gtables_wave_kernel leaves to gtables_kernel
+__global__ void __launch_bounds__(256) gtables_list_kernel(const GInfo* __restrict__ gi, int64_t n, int all, int32_t* __restrict__ list,
+                                                          unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || gi[i].status != 1) return;
+  if (all || !gi[i].wave_ok) list[atomicAdd(count, 1ull)] = (int32_t)i;
+}
+
+extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* list, unsigned long long* count) {
+  const int64_t n = GA.c.n_pairs;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gtables_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, GA.gi, n, (GA.dbg & 64) ? 1 : 0, list, count);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// wave kernel over all pairs, then the workgroup kernel over the `n_list` listed ones
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* list, int64_t n_list) {
+  if (GA.c.n_pairs == 0) return 0;
+  if (M == 1) hipLaunchKernelGGL(gtables_wave_kernel<1>, dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA);
+  else hipLaunchKernelGGL(gtables_wave_kernel<2>, dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA);
+  HIPCHK(hipGetLastError());
+  if (n_list > 0) {
+    if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)n_list), dim3(CUR_THREADS), 0, ctx->stream, GA, list);
+    else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)n_list), dim3(CUR_THREADS), 0, ctx->stream, GA, list);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }

@@ -144,7 +144,9 @@ def test_pixels_time_intervals_golden(cfg):
 CURRENT_PATHS = {"mono": dict(split_kernels=0),
                  "closed": dict(split_kernels=1, weights_mode=0, mac_mode=0),
                  "quad": dict(split_kernels=1, weights_mode=1, mac_mode=1),
-                 "gform": dict(split_kernels=1, weights_mode=2, gform_max_support=1e9)}     # (forced for tables of any support)
+                 "gform": dict(split_kernels=1, weights_mode=2, gform_max_support=1e9),     # (forced for tables of any support)
+                 # the tables stage's workgroup kernel for every pair (by default it gets what the wave kernel cannot take)
+                 "gform_wg": dict(split_kernels=1, weights_mode=2, gform_max_support=1e9, gform_wave_tables=0)}
 
 
 def _tracks_current_on(path, neigh, r, resp, T, **extra):
@@ -1590,7 +1592,8 @@ def _two_event_set(cfg, seed, n=1200):
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 2), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
                     ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 23.0), ("mac_mode", 1),
-                    ("quad_accuracy_log10", 10), ("gform_max_support", 768), ("trim_response_log", 23.0)):
+                    ("quad_accuracy_log10", 10), ("gform_max_support", 768), ("trim_response_log", 23.0),
+                    ("gform_wave_tables", 1)):
         lib.set_option(name, v)
 
 
