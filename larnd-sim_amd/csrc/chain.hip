@@ -53,11 +53,16 @@ static void fill_cur_common(ldsim_ctx* ctx, CurArgs& a) {
 // a9-a12 for the pairs of `a` (sorted pair list of the chain, or the dense [S][P] grid of the stage call) by the configured
 // kernels: tracks_current_mc, the split path (weights stage + correlation, overflowed pairs recomputed by the monolithic
 // kernel) or the monolithic kernel for everything.  counters = the 16 u64 of the misc block, zeroed by the caller.
-static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigned long long* counters, bool* split_timed) {
+// a.win set: *win_used tells whether the kernels that ran wrote the windows (else every row is complete and a.win is unset).
+static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigned long long* counters, bool* split_timed,
+                              bool* win_used = nullptr) {
   hipStream_t st = ctx->stream;
   const int64_t n_valid = a.n_pairs;
   *split_timed = false;
   size_t ib = 0, hb = 0, cb = 0;
+  int32_t* win = a.win;
+  a.win = nullptr;
+  if (win_used) *win_used = false;
   if (ctx->mc_current) return current_mc_launch(ctx, a, n_seg);   // the driver's call site (cli/simulate_pixels.py:1016)
   // The node-separable form pays per response tick of the staged support (16 nodes x cells x ticks on the matrix pipe), the
   // shifted-window kernels per 512-tick tile: a table whose support is a few hundred ticks (the survey table) is 2x faster in
@@ -70,10 +75,13 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
   if (ctx->split_kernels && use_gform && n_valid > 0) {
     // node-separable form (gform.h): tables, then the correlation on the matrix pipe; no weight pool, no repeat launches
     int32_t* flags = nullptr;
+    a.win = win;
     int rc = gform_launch(ctx, a, counters, &flags);
+    a.win = nullptr;                       // (the monolithic kernel writes its rows in full)
     if (rc < 0) return rc;
     if (rc == 0) {
       *split_timed = true;
+      if (win_used) *win_used = win != nullptr;
       a.only_flagged = flags - 7;          // current_kernel reads only_flagged[pair * flag_stride + 7]
       a.flag_stride = 1;
       return current_launch(ctx, a);
@@ -350,9 +358,11 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   a.counters = counters;
   a.only_flagged = nullptr;
   a.flag_stride = 0;
+  CK(ldsim_ensure(ctx, SB_WIN, (size_t)n_valid * 8 + 8));
+  a.win = (int32_t*)ctx->scratch[SB_WIN].p;
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  bool split_timed = false;
-  CK(run_tracks_current(ctx, a, n, counters, &split_timed));
+  bool split_timed = false, win_used = false;
+  CK(run_tracks_current(ctx, a, n, counters, &split_timed, &win_used));
   HIPCHK(hipEventRecord(ctx->ev[2], st));
 
   // ---- a13-a16 per-pixel sum, trigger scan, digitise ---------------------------------------------------------------------------------
@@ -372,6 +382,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   F.P = P;
   F.track_starts = d_starts;
   F.waves = d_waves;
+  F.win = win_used ? (const int32_t*)ctx->scratch[SB_WIN].p : nullptr;
   F.T = T;
   F.batch_first = d_first_b;
   F.batch0 = batch0;

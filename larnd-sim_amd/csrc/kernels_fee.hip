@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
 
   extern __shared__ double S[];          // [n_time_ticks]: sized at launch, so LDS (not VGPRs) stops at 8 pixels per CU
   __shared__ HitRec hits[A_MAX];
-  __shared__ int s_start[M_MAX];
+  __shared__ int s_start[M_MAX], s_w0[M_MAX], s_w1[M_MAX];
   __shared__ int64_t s_row[M_MAX];
   __shared__ double wtap[64], G[64];
   __shared__ int s_nh;
@@ -208,6 +208,8 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
     int r = v / F.P;
     s_start[tid] = (int)py_round(F.track_starts[r] / dt);   // detsim.py:506
     s_row[tid] = p0 + tid;
+    s_w0[tid] = F.win ? F.win[2 * (p0 + tid)] : 0;         // the ticks of the row tracks_current wrote
+    s_w1[tid] = F.win ? F.win[2 * (p0 + tid) + 1] : F.T;
     F.tpm[u * M + tid] = r - bfirst;
   } else if (tid < M) {
     F.tpm[u * M + tid] = -1;
@@ -226,14 +228,14 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
       G[d] = acc;
     }
   }
-  // ---- summed waveform: each thread owns ticks tid, tid+256, ...  (detsim.py:516-520) -----------------------------
-  for (int t = tid; t < NT; t += FEE_THREADS) {
-    double acc = 0;
-    for (int k = 0; k < n_slots && !(F.debug & 0x10000); k++) {
-      int it = t - s_start[k];
-      if (it >= 0 && it < F.T) acc += (double)F.waves[s_row[k] * (int64_t)F.T + it];
-    }
-    S[t] = acc;
+  // ---- summed waveform: each thread owns ticks tid, tid+256, ... and adds the slots' rows in slot order, each over the ticks
+  // its window puts on the pixel's time axis (detsim.py:516-520) ------------------------------------------------------------
+  for (int t = tid; t < NT; t += FEE_THREADS) S[t] = 0;
+  for (int k = 0; k < n_slots && !(F.debug & 0x10000); k++) {
+    const int st = s_start[k];
+    const int lo = max(st + s_w0[k], 0), hi = min(st + s_w1[k], NT);
+    const float* wf = F.waves + s_row[k] * (int64_t)F.T - st;
+    for (int t = lo + ((tid - lo) & (FEE_THREADS - 1)); t < hi; t += FEE_THREADS) S[t] += (double)wf[t];
   }
   __syncthreads();
   // ---- trigger scan on wave 0 ----------------------------------------------------------------------------------------
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
         double acc = 0;
         for (int jc = lr + lane; jc <= hi; jc += 64) {
           int it = jc - st;
-          if (it >= 0 && it < F.T) {
+          if (it >= s_w0[k] && it < s_w1[k]) {
             int d = b - jc;
             acc += (double)wf[it] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
           }

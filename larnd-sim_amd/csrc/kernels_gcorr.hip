@@ -50,12 +50,20 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
-  if (GA.flags[pair]) return;                       // the monolithic kernel writes this pair
+  if (GA.flags[pair]) {                             // the monolithic kernel writes this pair, in full
+    if (A.win && !big_list && tid == 0) { A.win[2 * pair] = 0; A.win[2 * pair + 1] = A.T; }
+    return;
+  }
   float* out = A.out + pair * (int64_t)A.T;
   const GInfo* __restrict__ gip = GA.gi + pair;
-  if (gip->status != 1) {
-    if (!big_list)
-      for (int it = tid; it < A.T; it += GT) out[it] = 0.f;
+  if (gip->status != 1) {                           // (nothing to emit: status 2 pairs are flagged)
+    if (!big_list) {
+      if (A.win) {
+        if (tid == 0) { A.win[2 * pair] = 0; A.win[2 * pair + 1] = 0; }
+      } else {
+        for (int it = tid; it < A.T; it += GT) out[it] = 0.f;
+      }
+    }
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
@@ -245,9 +253,12 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
     }
     __syncthreads();
   }
-  if (!(A.debug_phases & 0x10000000))             // (timing tools)
+  if (A.win) {
+    if (tid == 0) { A.win[2 * pair] = min(it_w0, A.T); A.win[2 * pair + 1] = min(it_w1, A.T); }
+  } else if (!(A.debug_phases & 0x10000000)) {    // (timing tools)
     for (int it = tid; it < A.T; it += GT)
       if (it < it_w0 || it >= it_w1) out[it] = 0.f;
+  }
   if (GA.dbg & 1) return;
   if (lane == 0 && n_mfma) stat_add(A.counters, 5, n_mfma * 1024ull);
   if (tid == 0 && n_useful) stat_add(A.counters, 8, n_useful);

@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
 #pragma unroll
           for (int m = 0; m < 4; m++) {
             const double d = dd - cen[m];
-            sum[m] += exp_neg(-d * d * i2T);
+            sum[m] += exp_neg_sel(-d * d * i2T);
           }
         }
       }
@@ -644,27 +644,29 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
       double cen[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) cen[m] = sn[m] * uzr;
+      // the (up to) two edges carried with Z, and where their tables go (an edge of the bound without invalid slices has a
+      // table nobody reads)
+      const int e0 = emask ? __ffs(emask) - 1 : 0, m1 = emask & (emask - 1), e1 = m1 ? __ffs(m1) - 1 : -1;
+      const int m2 = m1 & (m1 - 1), e2 = m2 ? __ffs(m2) - 1 : -1;
+      double* gZi0 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e0) - 1)));
+      double* gZi1 = gZ + 16ull * NUr * (unsigned long long)(1 + (e1 >= 0 ? g_popc3(ebound & ((1 << e1) - 1)) : 0));
       for (int u0 = 0; u0 < NUr; u0 += 16) {
         const int ub = u0 + u16;
         int k = 0, ke = 0;
         if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
-        double z[4] = {0, 0, 0, 0}, zi[NEDGE][4];
-#pragma unroll
-        for (int e = 0; e < NEDGE; e++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) zi[e][m] = 0;
+        double z[4] = {0, 0, 0, 0}, zi[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
           if (k < ke) {
             const double dd = s_dzs[k];
             const int inv = s_invs[k];
+            const bool i0 = (inv >> e0) & 1, i1 = e1 >= 0 && ((inv >> e1) & 1);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
               const double d = dd - cen[m];
-              const double g = exp_neg(-d * d * i2L);
+              const double g = exp_neg_sel(-d * d * i2L);
               z[m] += g;
-#pragma unroll
-              for (int e = 0; e < NEDGE; e++)
-                if (emask & (1 << e)) zi[e][m] += (inv & (1 << e)) ? g : 0.0;
+              zi[0][m] += i0 ? g : 0.0;
+              zi[1][m] += i1 ? g : 0.0;
             }
           }
         }
@@ -675,15 +677,34 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
           zsp[m] += v;
           if (!(GA.dbg & 16)) gZ[n * NUr + ub] = v;
         }
-        int et = 0;
+        if (!(GA.dbg & 48)) {
 #pragma unroll
-        for (int e = 0; e < NEDGE; e++) {
-          if (!(ebound & (1 << e))) continue;
-          double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
-          et++;
-          if (!(emask & (1 << e)) || (GA.dbg & 48)) continue;      // (gcorr_kernel skips the table)
+          for (int m = 0; m < 4; m++) {
+            if (emask) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
+            if (e1 >= 0) gZi1[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[1][m];
+          }
+        }
+      }
+      // a third edge (a response staged down to index 0 and up to the window's end): its table in a pass of its own
+      if (e2 >= 0) {
+        double* gZi2 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e2) - 1)));
+        for (int u0 = 0; u0 < NUr; u0 += 16) {
+          const int ub = u0 + u16;
+          int k = 0, ke = 0;
+          if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
+          double zi2[4] = {0, 0, 0, 0};
+          for (; __ballot(k < ke); k++) {
+            if (k < ke && ((s_invs[k] >> e2) & 1)) {
+              const double dd = s_dzs[k];
 #pragma unroll
-          for (int m = 0; m < 4; m++) gZi[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[e][m];
+              for (int m = 0; m < 4; m++) {
+                const double d = dd - cen[m];
+                zi2[m] += exp_neg_sel(-d * d * i2L);
+              }
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < 4; m++) gZi2[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi2[m];
         }
       }
     }

@@ -44,6 +44,9 @@ struct CurArgs {
   int32_t numba_f32;      // 1: the sub-expressions Numba types f32 for f4 record fields are evaluated in float (oracle: o_set_numba_f32)
   int32_t split_max_items;   // validation knob: pairs with more items than this take the monolithic kernel (0 = capacity)
   unsigned long long* counters;  // [0] ambiguous-rounding slices, [5] DFMA lanes, [6] pairs sent to the fallback
+  int32_t* win;                  // [n_pairs][2] or NULL.  Set: a kernel that knows a pair's response-visible tick window writes it here
+                                 // and leaves the ticks outside it unwritten (the chain's pixel sum reads the window only); NULL: every
+                                 // row is written in full (zeros outside the window)
   const int32_t* only_flagged;   // if set: run only pairs whose only_flagged[pair*flag_stride + 7] != 0
   int32_t flag_stride;
 };
@@ -61,6 +64,7 @@ struct FeeArgs {
   int32_t P;
   const double* track_starts; // [n_seg] relative index r
   const float* waves;         // [n_pairs][T]
+  const int32_t* win;         // [n_pairs][2]: the ticks of a row that were written, or NULL = all
   int32_t T;
   const int32_t* batch_first; // [n_batches] first relative segment index of each batch
   int32_t batch0;

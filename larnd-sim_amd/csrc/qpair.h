@@ -46,6 +46,30 @@ __device__ __forceinline__ double exp_neg(double x) {
   return ldexp(p, (int)k);
 }
 
+// the same value without a branch (x < -708 selects 0 at the end): several of these in a row interleave in the schedule
+__device__ __forceinline__ double exp_neg_sel(double x) {
+  const double xc = x < -708.0 ? -708.0 : x;
+  const double k = rint(xc * 1.4426950408889634074);
+  double r = fma(-k, 6.93147180369123816490e-01, xc);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double v = ldexp(p, (int)k);
+  return x < -708.0 ? 0.0 : v;
+}
+
 // response shift of slice iz (k - M * it for the tick in the middle of the slice's window), as weights_kernel / qweights_kernel
 template <int M>
 __device__ __forceinline__ int slice_shift_of(const LdsimConsts* c, double z_start_int, double z_step, double z_anode,
