@@ -20,6 +20,7 @@
 #define G_CELLCAP 2048      // cells of a batch held in LDS as 16-bit (col, j) codes: every pair fits (40 columns x 48 rows)
 #define G_CELLPAD 32        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups)
 #define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
+#define G_CELL0 4           // ints before the first cell entry of a batch (counts; four, so that every table starts 16-byte aligned)
 
 // per pair, written by pair_setup_kernel next to PairParams: what sizes the record before any table exists
 struct GInfo {
@@ -34,8 +35,8 @@ struct GInfo {
 
 // record layout in doubles from `off`:
 //   per node batch b:
-//     cells     1 + padded / 2              int count padded to a multiple of G_CELLPAD with dummies, int count of real cells,
-//                                           then u32 row | col << 16 | j << 24 per cell
+//     cells     2 + padded / 2              int count padded to a multiple of G_CELLPAD with dummies, int count of real cells,
+//                                           two unused, then u32 row | col << 16 | j << 24 per cell
 //     X         16 * ncol                   X[n][col]
 //     Y         16 * NJ                     Y[n][j]
 //     Z         16 * NUr                    Z[n][u]; NUr = NU rounded up to 16
@@ -45,7 +46,7 @@ struct GInfo {
 __host__ __device__ __forceinline__ int g_nur(int NU) { return (NU + 15) & ~15; }
 __host__ __device__ __forceinline__ int g_popc3(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1); }
 __host__ __device__ __forceinline__ unsigned long long g_cells_doubles(int ncol, int NJ) {
-  return 1ull + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
+  return G_CELL0 / 2 + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
 }
 __host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound) {
   return g_cells_doubles(ncol, NJ) + 16ull * ncol + 16ull * NJ + 16ull * (1 + g_popc3(edge_bound)) * g_nur(NU);

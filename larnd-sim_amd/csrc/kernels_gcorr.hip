@@ -1,7 +1,7 @@
 // kernels_gcorr.hip -- a9-a12, node-separable form ("weights_mode" 2, gform.h): the correlation stage, and the host glue of
 // the whole form.
 //
-// gcorr_kernel: one 256-thread workgroup per (segment, pixel) pair, on the tables gtables_kernel wrote.  Per 16-tick tile of
+// gcorr_kernel: one 128-thread workgroup per (segment, pixel) pair, on the tables gtables_kernel wrote.  Per 16-tick tile of
 // response indices k a wave forms
 //     G[n][k] = sum_cells X[n][col(cell)] Y[n][j(cell)] R[cell][k]                     (v_mfma_f64_16x16x4: nodes x cells x ticks)
 // with the 16 quadrature nodes of the batch as the M rows, four cells per instruction as the contraction and the response
@@ -18,32 +18,37 @@
 #include "gform.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-#define GPF 8            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
-static_assert(G_CELLPAD == 4 * GPF, "the cell list is padded to whole prefetch rounds");
+#define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
+static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padded to whole prefetch rounds");
 
 #define GT 128           // threads of a gcorr workgroup: two waves per pair, twice the pairs in flight per CU of a four-wave one
 #define GW 2             //   (the kernel waits on a chain of dependent latencies: DESIGN.md section 4, profiles/r03_occupancy*.log)
 
 // LDS of a pair, carved from the dynamic block by its real dimensions (a typical pair needs 12 KB; sized for the caps it would
-// be 38 KB and four pairs per CU).  Two size classes: pairs that fit `small` run 8 per CU, the others in a second launch.
+// be 54 KB and two pairs per CU).  Two size classes: pairs that fit `small` (16 KB; measured: 10 pairs per CU at 96 VGPRs
+// beat 8 at 128 and 12 at 80 with spills, profiles/r03_gcorr_occupancy.log) run 10 per CU, the others in a second launch.
 struct GLds {
   int xs, ys, zs, cellcap, bytes;
   bool z_lds;
 };
-__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT) {
+__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT, int budget) {
   GLds L;
-  L.xs = ncol | 1;                                   // odd strides: the 16 node rows fall on distinct banks
-  L.ys = NJ | 1;
+  L.xs = (ncol + 1) | 1;                             // odd strides: the 16 node rows fall on distinct banks; column `ncol` of X
+  L.ys = NJ | 1;                                     //   holds zeros (the weightless padding cells of the list point at it)
   const int nur = g_nur(NU);
-  L.z_lds = NU <= G_NUCAP;                           // the steepest long segments read Z from the record (L2)
-  L.zs = L.z_lds ? ((nur & 31) == 16 ? nur : nur + 16) : 0;      // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
   L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-  L.bytes = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys + L.zs)) + 4 * ((ncol + 1) & ~1) + 2 * L.cellcap + 16;
+  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys) + L.cellcap) + 16;
+  // Z in LDS where the pair's budget has room for it; else (and for the steepest long segments, NU > G_NUCAP) the P step reads
+  // it from the record: a pair never drops to the low-occupancy class because of its Z table
+  const int zs = (nur & 31) == 16 ? nur : nur + 16;  // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
+  L.z_lds = NU <= G_NUCAP && rest + 8 * G_NODES * zs <= budget;
+  L.zs = L.z_lds ? zs : 0;
+  L.bytes = rest + 8 * G_NODES * L.zs;
   return L;
 }
 
 template <int M>
-__global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_budget, const int32_t* __restrict__ big_list) {
+__global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int lds_budget, int lds_big, const int32_t* __restrict__ big_list) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -67,8 +72,9 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
-  const GLds L = g_lds_layout(ncol, NJ, NU, TT);
-  if ((L.bytes > lds_budget) != (big_list != nullptr)) return;      // the other launch's pair
+  const bool small = g_lds_layout(ncol, NJ, NU, TT, lds_budget).bytes <= lds_budget;
+  if (small != (big_list == nullptr)) return;      // the other launch's pair
+  const GLds L = g_lds_layout(ncol, NJ, NU, TT, small ? lds_budget : lds_big);
   const double* __restrict__ rec = GA.rec + gip->off;
   const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
   const int NUr = g_nur(NU), NU16 = NUr >> 4;
@@ -81,8 +87,8 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
   double* s_X = s_gs + GW * G_NODES;                // [16][xs]
   double* s_Y = s_X + G_NODES * L.xs;               // [16][ys]
   double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
-  int* s_rowbase = (int*)(s_Z + G_NODES * L.zs);    // [ncol]: response row of (col, j = 0)
-  unsigned short* s_cell = (unsigned short*)(s_rowbase + ((ncol + 1) & ~1));      // col | j << 6 (| 1 << 15: weightless padding)
+  // per listed cell: response row offset (doubles into the padded table) | byte offsets of its X column and Y row << 32, << 48
+  unsigned long long* s_info = (unsigned long long*)(s_Z + G_NODES * L.zs);
   __shared__ int s_ncell;
   const int xs = L.xs, ys = L.ys, zs = L.zs;
   double* ow = s_out + wv * TT;
@@ -107,39 +113,27 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
       const double* gZ = gY + 16 * NJ;
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
-        // the record's loads in flight four rounds at a time before their first use
+        // tables: thread (row n = tid / 8, lane of 8) copies its row's columns -- no index division; Z two doubles at a time
         const int ncell_l = cells[0];
-        auto stage = [&](const double* g, int n, int rowlen, double* dst, int stride) {
-          for (int i0 = 0; i0 < n; i0 += 4 * GT) {
-            double v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = (i0 + tid + GT * r < n) ? g[i0 + tid + GT * r] : 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int i = i0 + tid + GT * r;
-              if (i < n) dst[(i / rowlen) * stride + i % rowlen] = v[r];
-            }
+        {
+          const int n = tid >> 3, c8 = tid & 7;
+          if (!(GA.dbg & 4)) {
+            for (int cc = c8; cc < ncol; cc += 8) s_X[n * xs + cc] = gX[n * ncol + cc];
+            for (int cc = c8; cc < NJ; cc += 8) s_Y[n * ys + cc] = gY[n * NJ + cc];
+            if (z_lds)
+              for (int cc = 2 * c8; cc < NUr; cc += 16) {
+                const double2 v = *(const double2*)(gZ + n * NUr + cc);
+                s_Z[n * zs + cc] = v.x;
+                s_Z[n * zs + cc + 1] = v.y;
+              }
           }
-        };
-        for (int i0 = 0; i0 < ncell_l; i0 += 4 * GT) {
-          int cv[4];
-#pragma unroll
-          for (int r = 0; r < 4; r++) cv[r] = (i0 + tid + GT * r < ncell_l) ? cells[2 + i0 + tid + GT * r] : 0;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int i = i0 + tid + GT * r;
-            if (i < ncell_l) {
-              const unsigned ce = (unsigned)cv[r];
-              const unsigned col = (ce >> 16) & 63u, jc = (ce >> 24) & 63u;
-              s_cell[i] = (unsigned short)(col | (jc << 6) | ((ce >> 31) << 15));
-              if (!(ce >> 31)) s_rowbase[col] = (int)(ce & 0xFFFFu) - (int)jc;      // (the same value from every cell of the column)
-            }
-          }
+          if (c8 == 0) s_X[n * xs + ncol] = 0.0;
         }
-        if (!(GA.dbg & 4)) {
-        stage(gX, G_NODES * ncol, ncol, s_X, xs);
-        stage(gY, G_NODES * NJ, NJ, s_Y, ys);
-        if (z_lds) stage(gZ, G_NODES * NUr, NUr, s_Z, zs);
+        for (int i = tid; i < ncell_l; i += GT) {
+          const unsigned ce = (unsigned)cells[G_CELL0 + i];
+          const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
+          s_info[i] = (unsigned long long)((ce & 0xFFFFu) * (unsigned)nkp) | ((unsigned long long)(col * 8u) << 32) |
+                      ((unsigned long long)(jc * 8u) << 48);      // (row word | column word: offsets in doubles / bytes)
         }
         if (tid == 0) s_ncell = ncell_l;
         loaded = b;
@@ -150,62 +144,97 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
       if (tid == 0)
         n_useful += (unsigned long long)min(G_NODES, NQ - b * G_NODES) *
                     ((unsigned long long)cells[1] * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
-      // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k]
-      auto pstep = [&](const d4& acc, int k0) {
+      // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k] -- for both tiles of the wave at once: one A
+      // operand (Z of the lane's shift and node) feeds two independent accumulation chains.
+      auto pstep2 = [&](const d4& g0acc, const d4& g1acc, int k0) {
+        auto zrow = [&](int st, double* za) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
+        };
         for (int st = 0; st < NU16; st++) {
-          d4 p = {0, 0, 0, 0};
+          double za[4];
+          zrow(st, za);
+          d4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const double za = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
-            p = __builtin_amdgcn_mfma_f64_16x16x4f64(za, acc[q], p, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g0acc[q], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g1acc[q], p1, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int u = 16 * st + 4 * r + kk;
             const int num = k0 + jj - (u_min + u);
-            const int idx = (M == 1 ? num : (num >> 1)) - sup0;
-            if (u < NU && (M == 1 || (num & 1) == 0) && idx >= 0 && idx < wlen) atomicAdd(&ow[idx], p[r]);
+            const int idx = (M == 1 ? num : (num >> 1)) - sup0;        // (k0 and k0 + 16 have the same parity)
+            const int idx1 = idx + 16 / M;
+            const bool on = u < NU && (M == 1 || (num & 1) == 0);
+            if (on && idx >= 0 && idx < wlen) atomicAdd(&ow[idx], p0[r]);
+            if (on && idx1 >= 0 && idx1 < wlen) atomicAdd(&ow[idx1], p1[r]);
           }
         }
-        n_mfma += 4 * NU16;
+        n_mfma += 8 * NU16;
       };
       // A wave owns pairs of adjacent 16-tick tiles (the second one may lie past the range: its products meet zeros or ticks
-      // outside the window and are dropped): one A operand (X Y of the lane's node and cell) feeds both products, 2 x GPF
-      // response loads are in flight while GPF groups are multiplied; no branch in the loop.
-      for (int kt = wv; kt < n32 && ngrp > 0 && !(A.debug_phases & 0x100000); kt += GW) {
+      // outside the window and are dropped): one A operand (X Y of the lane's node and cell) feeds both products.
+      // Two LDS words per (group, lane) name the cell: its response row for the B operands, its X column and Y row for the A
+      // operand (a padding cell: a listed cell's row, valid memory, and the zero column of X).  A software pipeline over the
+      // groups t of a tile pair, one slot per group: the products of group t; the 2 response loads of
+      // group t + GPF into the registers just consumed; the row word of group t + GPF + 2; X and Y of group t + 2; the column word of
+      // group t + 4 (past the last group the indices wrap: valid, unused).  Every load is issued two slots (LDS) or GPF (L2) before
+      // its use, no branch, and sched_barrier keeps the compiler from sinking them back to their uses.  [Prefetching the next tile
+      // pair's first groups across the P step changed nothing: the loop runs at the rate the L1 delivers the B operands.]
+      const bool run_tiles = wv < n32 && ngrp > 0 && !(A.debug_phases & 0x100000);
+      const unsigned* s_inf32 = (const unsigned*)s_info;
+      const char* xl = (const char*)(s_X + jj * xs);
+      const char* yl = (const char*)(s_Y + jj * ys);
+      auto wrap = [&](int g) {            // (g < 3 ngrp)
+        g = g >= ngrp ? g - ngrp : g;
+        return g >= ngrp ? g - ngrp : g;
+      };
+      auto row_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk)]; };
+      auto col_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk) + 1]; };
+      for (int kt = wv; kt < n32 && run_tiles; kt += GW) {
         const int k0 = kA + 32 * kt;
-        const double* rp = GA.resp_pad + RESP_PAD + k0 + jj;
-        // response row of the lane's cell of group g (a padding cell repeats a listed cell: valid memory, weight 0)
-        auto rowoff = [&](int g) {
-          const unsigned ci = s_cell[4 * g + kk];
-          return (int64_t)(s_rowbase[ci & 63u] + (int)((ci >> 6) & 63u)) * nkp;
-        };
+        const double* rpl = GA.resp_pad + RESP_PAD + k0 + jj;
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        double b0[GPF], b1[GPF];
+        double b0[GPF], b1[GPF], xv[4], yv[4];
+        unsigned lo[4], hi[4];
 #pragma unroll
         for (int u = 0; u < GPF; u++) {
-          const int64_t o = rowoff(u);
-          b0[u] = rp[o];
-          b1[u] = rp[o + 16];
+          const double* q = rpl + row_word(u);
+          b0[u] = q[0];
+          b1[u] = q[16];
         }
+        lo[0] = row_word(GPF);
+        lo[1] = row_word(GPF + 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) hi[u] = col_word(u);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          xv[u] = *(const double*)(xl + (hi[u] & 0xFFFFu));
+          yv[u] = *(const double*)(yl + (hi[u] >> 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int g0 = 0; g0 < ngrp; g0 += GPF) {
-          const int gn = (g0 + GPF < ngrp) ? g0 + GPF : g0;         // (the last round reloads itself: no branch, values unused)
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
-            const unsigned ci = s_cell[4 * (g0 + u) + kk];
-            const double a = (ci >> 15) ? 0.0 : s_X[jj * xs + (ci & 63u)] * s_Y[jj * ys + ((ci >> 6) & 63u)];
+            const double a = xv[u & 3] * yv[u & 3];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
-            const int64_t o = rowoff(gn + u);          // the registers just consumed take the loads of the group GPF ahead
-            b0[u] = rp[o];
-            b1[u] = rp[o + 16];
+            const double* q = rpl + lo[u & 3];
+            b0[u] = q[0];
+            b1[u] = q[16];
+            lo[(u + 2) & 3] = row_word(g0 + u + GPF + 2);
+            xv[(u + 2) & 3] = *(const double*)(xl + (hi[(u + 2) & 3] & 0xFFFFu));
+            yv[(u + 2) & 3] = *(const double*)(yl + (hi[(u + 2) & 3] >> 16));
+            hi[u & 3] = col_word(g0 + u + 4);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
         n_mfma += 2 * ngrp;
         if (!(A.debug_phases & 0x200000)) {
-          pstep(acc0, k0);
-          pstep(acc1, k0 + 16);
+          pstep2(acc0, acc1, k0);
           // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to,
           // sum_n Zi_e[n][u] G_n[edge_k[e]] per shift u.  The column of G sits in four lanes of this wave's accumulators
           // (register r of lane 16 q + col = G[4 r + q][k0 + col]): through LDS to all lanes, one shift per lane.
@@ -217,10 +246,10 @@ __global__ void __launch_bounds__(GT, 4) gcorr_kernel(GArgs GA, int TT, int lds_
               et++;
               const int ke = edge_k[e];
               if (!(emask & (1 << e)) || ke < k0 || ke >= k0 + 32) continue;
-              const bool hi = ke >= k0 + 16;
+              const bool upper = ke >= k0 + 16;
               if (jj == ((ke - k0) & 15)) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) s_gs[wv * G_NODES + 4 * r + kk] = hi ? acc1[r] : acc0[r];
+                for (int r = 0; r < 4; r++) s_gs[wv * G_NODES + 4 * r + kk] = upper ? acc1[r] : acc0[r];
               }
               wsync();
               for (int u = lane; u < NU; u += 64) {
@@ -269,7 +298,7 @@ __global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict_
                                                         int32_t* __restrict__ list, unsigned long long* __restrict__ count) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n || gi[i].status != 1) return;
-  if (g_lds_layout(gi[i].ncol, gi[i].NJ, gi[i].NU, TT).bytes > lds_budget) list[atomicAdd(count, 1ull)] = (int32_t)i;
+  if (g_lds_layout(gi[i].ncol, gi[i].NJ, gi[i].NU, TT, lds_budget).bytes > lds_budget) list[atomicAdd(count, 1ull)] = (int32_t)i;
 }
 
 // ---- record offsets: exclusive scan of the sizes pair_setup_kernel wrote ------------------------------------------------------------
@@ -332,9 +361,9 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
   const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
-  // Two launches of the correlation by LDS need: pairs that fit 19.5 KB run eight to a CU, the rest -- listed here, counted on
+  // Two launches of the correlation by LDS need: pairs that fit 16 KB run ten to a CU, the rest -- listed here, counted on
   // the host together with the pool size -- three to a CU.
-  const int lds_small = 19968 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT).bytes;
+  const int lds_small = 16384 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
   int32_t* d_big = (int32_t*)(d_total + 4);
   int32_t* d_wg = d_big + n;                       // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 16, st));
@@ -360,12 +389,12 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   GA.resp_pad = (const double*)ctx->resp_pad.p;
   if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg))) return rc;
   HIPCHK(hipEventRecord(ctx->ev[5], st));
-  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);
-  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, (const int32_t*)nullptr);
+  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, lds_big, (const int32_t*)nullptr);
+  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, lds_big, (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   if (n_big > 0) {
-    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, d_big);
-    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, d_big);
+    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, lds_big, d_big);
+    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, lds_big, d_big);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(ctx->ev[6], st));

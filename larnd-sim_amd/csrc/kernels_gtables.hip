@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
   for (int b = 0; b < NB; b++) {
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
-    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[2 + e])
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
     int n_cells_b = 0;
     double* gX = brec + cells_d;
     double* gY = gX + 16 * ncol;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
         if (keep) {
           const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
           const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
-          cells[2 + pos] = (int)ce;
+          cells[G_CELL0 + pos] = (int)ce;
           s_cells[pos] = (unsigned short)(col | (jj << 6));
         }
         base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
       if (tid < padded - base && base > 0) {
         // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
         const unsigned c0 = s_cells[0] & 63u, j0 = (s_cells[0] >> 6) & 63u;
-        cells[2 + base + tid] = (int)(0x80000000u | (unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) | (c0 << 16) | (j0 << 24));
+        cells[G_CELL0 + base + tid] = (int)(0x80000000u | (unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) | (c0 << 16) | (j0 << 24));
       }
       if (tid == 0) { cells[0] = padded; cells[1] = base; }
       n_cells_b = base;
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
   for (int b = 0; b < NB; b++) {
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
-    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[2 + e])
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
     double* gX = brec + cells_d;
     double* gY = gX + 16 * ncol;
     double* gZ = gY + 16 * NJ;
@@ -737,13 +737,13 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
         }
         const unsigned long long bal = __ballot(keep);
         const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
-        if (keep) cells[2 + base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)ce;
+        if (keep) cells[G_CELL0 + base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)ce;
         if (base == 0 && bal) first_code = (unsigned)__builtin_amdgcn_readlane((int)ce, __ffsll((long long)bal) - 1);
         base += __popcll(bal);
       }
       const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
       // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
-      if (lane < padded - base && base > 0) cells[2 + base + lane] = (int)(0x80000000u | first_code);
+      if (lane < padded - base && base > 0) cells[G_CELL0 + base + lane] = (int)(0x80000000u | first_code);
       if (lane == 0) { cells[0] = padded; cells[1] = base; }
     }
   }

@@ -23,8 +23,12 @@ ch.quench_drift()
 ch.run(0, len(seg), want_fractions=True)
 # pad: KB off the LDS budget of gcorr's small class (19.5 KB); dbg: option debug_gform (1 no counter atomics, 2 no edge rows,
 # 4 no X / Y / Z staging in gcorr, 8 no stores of the result, 16 no record stores in gtables, 32 no edge rows in gtables)
-for mask, pad, dbg in ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 0, 0), (0x8000000, 0, 0), (0x6000000, 0, 0),
-                       (0xe000000, 0, 0), (0xe000000, 0, 16), (0, 0, 16), (0, 0, 32), (0, 0, 0)):
+WHICH = sys.argv[4] if len(sys.argv) > 4 else "tables"
+RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 0, 0), (0x8000000, 0, 0), (0x6000000, 0, 0),
+                   (0xe000000, 0, 0), (0xe000000, 0, 16), (0, 0, 16), (0, 0, 32), (0, 0, 0)),
+        "corr": ((0, 0, 0), (0x100000, 0, 0), (0x200000, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0x100000, 0, 4), (0x100000, 0, 12),
+                 (0x100000, 0, 14), (0, -12, 0), (0, 6, 0), (0, 0, 0))}
+for mask, pad, dbg in RUNS[WHICH]:
     lib.set_option("debug_phases", 15 | mask)
     lib.set_option("debug_lds_pad_kb", pad)
     lib.set_option("debug_gform", dbg)
