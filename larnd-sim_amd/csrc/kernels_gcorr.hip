@@ -16,6 +16,9 @@
 // Zi table at the one response index it concerns.  No DPP shifts, no 512-tick tile padding, no weight pool: the matrix pipe
 // carries 16 x cells x ticks FMAs per pair where the shifted-window kernels issue (cells x shifts) x 512.
 #include "gform.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
@@ -377,6 +380,22 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   HIPCHK(hipMemcpyAsync(h_tot, d_total, 24, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   const unsigned long long total = h_tot[0], n_big = h_tot[1], n_wg = h_tot[2];
+  if (getenv("LDSIM_DEBUG_GFORM")) {      // class sizes of the launch, and why pairs miss the wave kernel
+    std::vector<GInfo> h((size_t)n);
+    HIPCHK(hipMemcpy(h.data(), gi, (size_t)n * sizeof(GInfo), hipMemcpyDeviceToHost));
+    long n1 = 0, nu = 0, xy = 0, sl = 0, nb2 = 0;
+    for (const GInfo& g : h) {
+      if (g.status != 1) continue;
+      n1++;
+      nb2 += g.NB > 1;
+      if (g.wave_ok) continue;
+      if (g.NU > G_NUCAP) nu++;
+      else if (g.ncol + g.NJ > 54) xy++;
+      else sl++;
+    }
+    fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 128: %ld, X | Y bins > 54: %ld, "
+            "slices > 64: %ld), big LDS class %llu, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl, n_big, total * 8e-9);
+  }
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));
   GA.c = a;

@@ -9,6 +9,7 @@
 // (kernels_gcorr.hip) correlates straight from the tables.
 //
 // Deterministic: every table entry has one owner thread and a fixed order of its terms.
+#include <type_traits>
 #include "gform.h"
 #include "wave_ops.h"
 
@@ -388,13 +389,13 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 
 
 // ---- one wave per pair ---------------------------------------------------------------------------------------------------------
-// gtables_wave_kernel: the same tables for the pairs whose slices fit one chunk (<= 64 slices, <= 64 shifts) and whose X and Y
-// bins together fit 40 columns (GInfo.wave_ok: all but the longest segments).  A wave owns the pair: no workgroup barrier
+// gtables_wave_kernel: the same tables for the pairs whose slices fit one chunk (<= 64 slices, <= 128 shifts) and whose X and Y
+// bins together fit 54 columns (GInfo.wave_ok: all but the longest segments).  A wave owns the pair: no workgroup barrier
 // anywhere, 16 pairs in flight per CU instead of 4, and every phase fills its 64 lanes as (16 table bins) x (4 nodes), each lane
 // carrying nodes q, 4 + q, 8 + q, 12 + q of its bin -- so a bin's member loop is shared by four nodes, the invalid-slice tables
 // of the window edges accumulate in the same pass as Z from the same Gaussians, and no index needs a division.
 // Entry for entry the same expressions and term order as gtables_kernel (the cell test sums the Z totals in another order).
-#define GW_XYS 41         // row stride of the joint X | Y table
+#define GW_XYS 55         // row stride of the joint X | Y table (ncol + NJ <= 54)
 
 template <int M>
 __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
   __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
   __shared__ double s_XY[G_NODES][GW_XYS], s_zs[G_NODES];
   __shared__ unsigned char s_invs[ZC];
-  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[NU_MAX + 1];
+  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[G_NUCAP + 1];
 
   if (lane < PP_COUNT) s_par[lane] = ((const double*)((const char*)P + 32))[lane];
   wsync();
@@ -537,23 +538,58 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
     n_sl = nmax;
     lo_c = lo;
     NUc = hi - lo + 1;
-    if (nmax != iz_hi - iz_lo + 1 || NUc > NU_MAX || NUc != NU || lo != u_min) bad = true;
+    if (nmax != iz_hi - iz_lo + 1 || NUc > G_NUCAP || NUc != NU || lo != u_min) bad = true;
     if (!bad) {
-      int posn = 0, below = 0;
-      const unsigned long long lane_lt = (1ull << lane) - 1ull;
-      for (int bs = lo; bs <= hi; bs++) {                    // the distinct shifts (<= NU_MAX), one ballot each
-        const unsigned long long bal = __ballot(lane < nmax && sh == bs);
-        const int cnt = __popcll(bal);
-        if (lane < nmax && sh > bs) posn += cnt;
-        if (lane < nmax && sh == bs) posn += __popcll(bal & lane_lt);
-        if (bs < lo + lane) below += cnt;
+      const bool in = lane < nmax;
+      const unsigned long long lane_lt = (1ull << lane) - 1ull, lane_le = lane_lt | (1ull << lane);
+      // the slices follow the drift axis, so their shifts rise or fall with the lane: runs of equal shift are contiguous and the
+      // ordered position follows from the run boundaries; any other order (none known) takes one ballot per distinct shift
+      const int prev = __builtin_amdgcn_update_dpp(sh, sh, 0x138, 0xF, 0xF, false);        // wave_shr:1 (lane 0 keeps its own)
+      const bool up = __ballot(in && lane > 0 && sh > prev) != 0, down = __ballot(in && lane > 0 && sh < prev) != 0;
+      int posn = 0;
+      if (!(up && down)) {
+        const unsigned long long RS = __ballot(in && (lane == 0 || sh != prev));                // run starts
+        const int run_first = 63 - __clzll((long long)(RS & lane_le));
+        const unsigned long long above = RS & ~lane_le;
+        const int run_end = above ? __ffsll((long long)above) - 1 : nmax;
+        posn = down ? (nmax - run_end) + (lane - run_first) : lane;
+        // bin starts: a run's first position at its shift, empty bins take the next start (a suffix minimum, 64 bins at a time)
+        s_ustart[lane] = -1;
+        s_ustart[lane + 64] = -1;
+        wsync();
+        if (in && lane == run_first) s_ustart[sh - lo] = (short)posn;
+        wsync();
+        int carry = nmax;
+        for (int part = 0; part < NUc; part += 64) {
+          const int bi = NUc - 1 - part - lane;
+          int v = 1 << 20;
+          if (bi >= 0) {
+            const int e = s_ustart[bi];
+            v = e < 0 ? (1 << 20) : e;
+          }
+          v = min(wave_scan_i32(v, 1 << 20, [](int a, int b) { return a < b ? a : b; }), carry);
+          if (bi >= 0) s_ustart[bi] = (short)v;
+          carry = wave_lane_i32(v, 63);
+        }
+        if (lane == 0) s_ustart[NUc] = (short)nmax;
+      } else {
+        int below = 0, below2 = 0;
+        for (int bs = lo; bs <= hi; bs++) {                    // the distinct shifts, one ballot each
+          const unsigned long long bal = __ballot(in && sh == bs);
+          const int cnt = __popcll(bal);
+          if (in && sh > bs) posn += cnt;
+          if (in && sh == bs) posn += __popcll(bal & lane_lt);
+          if (bs < lo + lane) below += cnt;
+          if (bs < lo + lane + 64) below2 += cnt;
+        }
+        if (lane < NUc) s_ustart[lane] = (short)below;
+        if (lane + 64 < NUc) s_ustart[lane + 64] = (short)below2;
+        if (lane == 0) s_ustart[NUc] = (short)nmax;
       }
-      if (lane < nmax) {
+      if (in) {
         s_dzs[posn] = dzv;
         s_invs[posn] = (unsigned char)inval;
       }
-      if (lane < NUc) s_ustart[lane] = (short)below;
-      if (lane == 0) s_ustart[NUc] = (short)nmax;
 #pragma unroll
       for (int e = 0; e < NEDGE; e++)
         if (__ballot(lane < nmax && (inval & (1 << e)))) anyinv |= 1 << e;
@@ -572,9 +608,13 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
   const double* gx_tab = GA.glx + (int64_t)NQ * (NQ - 1) / 2;
   const double* gw_tab = GA.glw + (int64_t)NQ * (NQ - 1) / 2;
   const bool do_prune = A.prune_log > 0;
-  const double uxr = s_par[PP_UXR], uyr = s_par[PP_UYR], uzr = s_par[PP_UZR], i2T = s_par[PP_I2T], i2L = s_par[PP_I2L];
-  const double kappa = s_par[PP_KAPPA], s_lo = s_par[PP_S_LO], qlen = s_par[PP_QLEN], wscale = s_par[PP_WSCALE];
-  const double thr = s_par[PP_THR];
+  // (wave-uniform values read from LDS land in vector registers: moved to scalar ones, 20 VGPRs less)
+  auto uni = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  const double uxr = uni(s_par[PP_UXR]), uyr = uni(s_par[PP_UYR]), uzr = uni(s_par[PP_UZR]), i2T = uni(s_par[PP_I2T]);
+  const double i2L = uni(s_par[PP_I2L]), kappa = uni(s_par[PP_KAPPA]), s_lo = uni(s_par[PP_S_LO]), qlen = uni(s_par[PP_QLEN]);
+  const double wscale = uni(s_par[PP_WSCALE]), thr = uni(s_par[PP_THR]);
   const unsigned long long cells_d = g_cells_doubles(ncol, NJ);
   const unsigned long long batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
   const int emask = anyinv & ebound;
@@ -601,112 +641,129 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
       wn[m] = on ? w : 0.0;
     }
     wsync();          // the previous batch's tables are no longer read
-    // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
-    for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
-      const int bi = b0 + u16;
-      const bool act = bi < nbins, isx = bi < ncol;
-      const int bb = isx ? bi : bi - ncol;
-      int k = 0, ke = 0;
-      if (act) {
-        k = isx ? s_colstart[bb] : s_jstart[bb];
-        ke = isx ? s_colstart[bb + 1] : s_jstart[bb + 1];
-      }
-      const double* src = isx ? s_dxs : s_dys;
-      const double ur = isx ? uxr : uyr;
-      double cen[4], sum[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int m = 0; m < 4; m++) cen[m] = sn[m] * ur;
-      for (; __ballot(k < ke); k++) {
-        if (k < ke) {
-          const double dd = src[k];
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const double d = dd - cen[m];
-            sum[m] += exp_neg_sel(-d * d * i2T);
-          }
-        }
-      }
-      if (act) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int n = 4 * m + q;
-          const double v = n < nb ? sum[m] : 0.0;
-          s_XY[n][bi] = v;
-          if (!(GA.dbg & 16)) {
-            if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
-          }
-        }
-      }
-    }
-    // ---- Z and, from the same Gaussians, the tables over the slices that are invalid at a window edge -----------------------------------------
+    // The two table phases, compiled for MC = 1 .. 4 node groups (a batch's last nodes fill fewer than four: 59 % of the survey
+    // workload's pairs have a second batch of a few nodes): the MC Gaussians of a member are independent and interleave.
     double zsp[4] = {0, 0, 0, 0};
-    {
-      double cen[4];
-#pragma unroll
-      for (int m = 0; m < 4; m++) cen[m] = sn[m] * uzr;
-      // the (up to) two edges carried with Z, and where their tables go (an edge of the bound without invalid slices has a
-      // table nobody reads)
-      const int e0 = emask ? __ffs(emask) - 1 : 0, m1 = emask & (emask - 1), e1 = m1 ? __ffs(m1) - 1 : -1;
-      const int m2 = m1 & (m1 - 1), e2 = m2 ? __ffs(m2) - 1 : -1;
-      double* gZi0 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e0) - 1)));
-      double* gZi1 = gZ + 16ull * NUr * (unsigned long long)(1 + (e1 >= 0 ? g_popc3(ebound & ((1 << e1) - 1)) : 0));
-      for (int u0 = 0; u0 < NUr; u0 += 16) {
-        const int ub = u0 + u16;
+    auto tables = [&](auto mc_tag) {
+      constexpr int MC = decltype(mc_tag)::value;
+      // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
+      for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
+        const int bi = b0 + u16;
+        const bool act = bi < nbins, isx = bi < ncol;
+        const int bb = isx ? bi : bi - ncol;
         int k = 0, ke = 0;
-        if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
-        double z[4] = {0, 0, 0, 0}, zi[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+        if (act) {
+          k = isx ? s_colstart[bb] : s_jstart[bb];
+          ke = isx ? s_colstart[bb + 1] : s_jstart[bb + 1];
+        }
+        const double* src = isx ? s_dxs : s_dys;
+        const double ur = isx ? uxr : uyr;
+        double cen[4], sum[4] = {0, 0, 0, 0};
+  #pragma unroll
+        for (int m = 0; m < 4; m++) cen[m] = sn[m] * ur;
+        for (; __ballot(k < ke); k++) {
           if (k < ke) {
-            const double dd = s_dzs[k];
-            const int inv = s_invs[k];
-            const bool i0 = (inv >> e0) & 1, i1 = e1 >= 0 && ((inv >> e1) & 1);
-#pragma unroll
+            const double dd = src[k];
+  #pragma unroll
             for (int m = 0; m < 4; m++) {
-              const double d = dd - cen[m];
-              const double g = exp_neg_sel(-d * d * i2L);
-              z[m] += g;
-              zi[0][m] += i0 ? g : 0.0;
-              zi[1][m] += i1 ? g : 0.0;
+              if (m < MC) {
+                const double d = dd - cen[m];
+                sum[m] += exp_neg_sel(-d * d * i2T);
+              }
             }
           }
         }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int n = 4 * m + q;
-          const double v = 0.0 + wn[m] * z[m];
-          zsp[m] += v;
-          if (!(GA.dbg & 16)) gZ[n * NUr + ub] = v;
-        }
-        if (!(GA.dbg & 48)) {
-#pragma unroll
+        if (act) {
+  #pragma unroll
           for (int m = 0; m < 4; m++) {
-            if (emask) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
-            if (e1 >= 0) gZi1[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[1][m];
+            const int n = 4 * m + q;
+            const double v = n < nb ? sum[m] : 0.0;
+            s_XY[n][bi] = v;
+            if (!(GA.dbg & 16)) {
+              if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
+            }
           }
         }
       }
-      // a third edge (a response staged down to index 0 and up to the window's end): its table in a pass of its own
-      if (e2 >= 0) {
-        double* gZi2 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e2) - 1)));
+      // ---- Z and, from the same Gaussians, the tables over the slices that are invalid at a window edge -----------------------------------------
+      {
+        double cen[4];
+  #pragma unroll
+        for (int m = 0; m < 4; m++) cen[m] = sn[m] * uzr;
+        // the (up to) two edges carried with Z, and where their tables go (an edge of the bound without invalid slices has a
+        // table nobody reads)
+        const int e0 = emask ? __ffs(emask) - 1 : 0, m1 = emask & (emask - 1), e1 = m1 ? __ffs(m1) - 1 : -1;
+        const int m2 = m1 & (m1 - 1), e2 = m2 ? __ffs(m2) - 1 : -1;
+        double* gZi0 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e0) - 1)));
+        double* gZi1 = gZ + 16ull * NUr * (unsigned long long)(1 + (e1 >= 0 ? g_popc3(ebound & ((1 << e1) - 1)) : 0));
         for (int u0 = 0; u0 < NUr; u0 += 16) {
           const int ub = u0 + u16;
           int k = 0, ke = 0;
           if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
-          double zi2[4] = {0, 0, 0, 0};
-          for (; __ballot(k < ke); k++) {
-            if (k < ke && ((s_invs[k] >> e2) & 1)) {
+          double z[4] = {0, 0, 0, 0}, zi[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+          for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+            if (k < ke) {
               const double dd = s_dzs[k];
-#pragma unroll
+              const int inv = s_invs[k];
+              const bool i0 = (inv >> e0) & 1, i1 = e1 >= 0 && ((inv >> e1) & 1);
+  #pragma unroll
               for (int m = 0; m < 4; m++) {
-                const double d = dd - cen[m];
-                zi2[m] += exp_neg_sel(-d * d * i2L);
+                if (m < MC) {
+                  const double d = dd - cen[m];
+                  const double g = exp_neg_sel(-d * d * i2L);
+                  z[m] += g;
+                  zi[0][m] += i0 ? g : 0.0;
+                  zi[1][m] += i1 ? g : 0.0;
+                }
               }
             }
           }
-#pragma unroll
-          for (int m = 0; m < 4; m++) gZi2[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi2[m];
+  #pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int n = 4 * m + q;
+            const double v = 0.0 + wn[m] * z[m];
+            zsp[m] += v;
+            if (!(GA.dbg & 16)) gZ[n * NUr + ub] = v;
+          }
+          if (!(GA.dbg & 48)) {
+  #pragma unroll
+            for (int m = 0; m < 4; m++) {
+              if (emask) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
+              if (e1 >= 0) gZi1[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[1][m];
+            }
+          }
+        }
+        // a third edge (a response staged down to index 0 and up to the window's end): its table in a pass of its own
+        if (e2 >= 0) {
+          double* gZi2 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e2) - 1)));
+          for (int u0 = 0; u0 < NUr; u0 += 16) {
+            const int ub = u0 + u16;
+            int k = 0, ke = 0;
+            if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
+            double zi2[4] = {0, 0, 0, 0};
+            for (; __ballot(k < ke); k++) {
+              if (k < ke && ((s_invs[k] >> e2) & 1)) {
+                const double dd = s_dzs[k];
+  #pragma unroll
+                for (int m = 0; m < 4; m++) {
+                  if (m < MC) {
+                    const double d = dd - cen[m];
+                    zi2[m] += exp_neg_sel(-d * d * i2L);
+                  }
+                }
+              }
+            }
+  #pragma unroll
+            for (int m = 0; m < 4; m++) gZi2[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi2[m];
+          }
         }
       }
+    };
+    switch ((nb + 3) >> 2) {
+      case 1: tables(std::integral_constant<int, 1>{}); break;
+      case 2: tables(std::integral_constant<int, 2>{}); break;
+      case 3: tables(std::integral_constant<int, 3>{}); break;
+      default: tables(std::integral_constant<int, 4>{}); break;
     }
     // per-node totals over the shifts (cell test): row sums over the 16 lanes of a node group
 #pragma unroll
@@ -731,8 +788,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
         if (cc < ncand) {
           col = (int)(((unsigned)cc * nj_inv) >> 20); jj = cc - col * NJ;
           double w = 0;
-#pragma unroll 4
-          for (int n = 0; n < G_NODES; n++) w = fma(s_XY[n][col] * s_XY[n][ncol + jj], s_zs[n], w);
+          for (int n = 0; n < nb; n++) w = fma(s_XY[n][col] * s_XY[n][ncol + jj], s_zs[n], w);      // (rows past nb are zero)
           keep = do_prune ? w > thr : w != 0.0;
         }
         const unsigned long long bal = __ballot(keep);
