@@ -21,7 +21,8 @@ int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, cons
                      int32_t*, int64_t*, int64_t);
 int sort_batch_first(ldsim_ctx*, int64_t, int64_t, int32_t, int32_t*);
 int sort_tmax_batch(ldsim_ctx*, int64_t, int64_t, int32_t, double*, int32_t*, unsigned long long*);
-int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out);
+int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out,
+                 const int32_t** flag_list, const unsigned long long** flag_count);
 int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const double*,
                       const double*, int, int64_t, int32_t*);
 
@@ -76,7 +77,7 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
     // node-separable form (gform.h): tables, then the correlation on the matrix pipe; no weight pool, no repeat launches
     int32_t* flags = nullptr;
     a.win = win;
-    int rc = gform_launch(ctx, a, counters, &flags);
+    int rc = gform_launch(ctx, a, counters, &flags, &a.flag_list, &a.flag_count);
     a.win = nullptr;                       // (the monolithic kernel writes its rows in full)
     if (rc < 0) return rc;
     if (rc == 0) {
@@ -86,6 +87,8 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
       a.flag_stride = 1;
       return current_launch(ctx, a);
     }
+    a.flag_list = nullptr;
+    a.flag_count = nullptr;
   }
   if (!(ctx->split_kernels && n_valid > 0 && split_sizes(ctx, a, &ib, &hb, &cb) > 0)) return current_launch(ctx, a);
   CK(ldsim_ensure(ctx, SB_ITEMS, (size_t)n_valid * ib));

@@ -16,10 +16,9 @@
 #include "current_common.h"
 
 template <int M>
-__global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(CurArgs A) {
+__device__ __forceinline__ void current_pair(const CurArgs& A, const int64_t pair) {
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t pair = blockIdx.x;
   if (pair >= A.n_pairs) return;
   if (A.only_flagged && A.only_flagged[pair * A.flag_stride + 7] == 0) return;
 
@@ -522,6 +521,21 @@ __global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(
   if (lane == 0 && n_surv) stat_add(A.counters, 1, n_surv);
 }
 
+// one workgroup per pair, or -- the recompute pass of the split paths, where flagged pairs are few or none -- a fixed grid over
+// the list of flagged pairs
+template <int M>
+__global__ void __launch_bounds__(CUR_THREADS, (M == 1 ? 2 : 1)) current_kernel(CurArgs A) {
+  if (!A.flag_list) {
+    current_pair<M>(A, blockIdx.x);
+    return;
+  }
+  const int64_t cnt = (int64_t)*A.flag_count;
+  for (int64_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+    current_pair<M>(A, A.flag_list[idx]);
+    __syncthreads();
+  }
+}
+
 extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {
   if (args.n_pairs == 0) return 0;
   const LdsimConsts& h = ctx->h_consts;
@@ -539,7 +553,7 @@ extern "C++" int current_launch(ldsim_ctx* ctx, const CurArgs& args) {
     ldsim_set_error("too many pairs for one launch");
     return LDSIM_EINVAL;
   }
-  dim3 grid((unsigned)args.n_pairs), block(CUR_THREADS);
+  dim3 grid((unsigned)(args.flag_list ? (args.n_pairs < 2048 ? args.n_pairs : 2048) : args.n_pairs)), block(CUR_THREADS);
   if (M == 1)
     hipLaunchKernelGGL(current_kernel<1>, grid, block, 0, ctx->stream, args);
   else

@@ -76,9 +76,12 @@ struct HitRec {
 // draws one normal before the loop (reset noise, fee.py:557), two at every pass of the loop (uncorrelated + discriminator
 // noise, :583-584, also on busy ticks), two after an integration (:616-617) and one at every reset (:621,649); *n_draws
 // returns how many were consumed.  t_stop = time_ticks[-1] of linspace(0, t_stop, NT + 1) (cli/simulate_pixels.py:1072).
+// [t_first, t_end): the ticks where S can be non-zero.  Without noise and with a positive threshold the scan's state does not
+// change on ticks whose charge is zero while the ADC is idle and the sum below threshold, so it starts at t_first and stops
+// once past t_end + ntap with the ADC idle (with noise every tick draws its normals and may trigger: all ticks are walked).
 __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_stop, double thr, double time_padding,
                         int lane, HitRec* hits /* LDS, [A] */, const double* wtap, int ntap, const float* __restrict__ z,
-                        int* n_draws) {
+                        int* n_draws, int t_first = 0, int t_end = 1 << 30) {
   const double dt = c->time_sampling;
   const bool has_rt = c->buffer_risetime > 0;
   const int A = c->max_adc_values;
@@ -91,6 +94,9 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
   int ic = 0, iadc = 0, adc_busy = 0, last_reset = 0, cur = 0;
   double q_sum = 0, true_q = 0;
   if (z) q_sum = (double)z[cur++] * s_reset;
+  const bool skip_idle = !z && thr > 0;
+  if (skip_idle && t_first > 0) ic = t_first < NT ? t_first : NT;
+  const int t_quiet = t_end + ntap;            // from here on q(ic) = 0
   while ((ic < NT || adc_busy > 0) && iadc < A) {
     // one chunk of 64 consecutive ticks
     int my_ic = ic + lane;
@@ -117,6 +123,7 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
       true_q += lane_bcast(incl, 63);
       ic += 64;
       adc_busy = adc_busy > 64 ? adc_busy - 64 : 0;
+      if (skip_idle && adc_busy == 0 && ic >= t_quiet) break;      // (lane 63 was idle and below threshold: nothing can follow)
       continue;
     }
     int f = __ffsll((long long)tm) - 1;
@@ -185,7 +192,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   __shared__ int s_start[M_MAX], s_w0[M_MAX], s_w1[M_MAX];
   __shared__ int64_t s_row[M_MAX];
   __shared__ double wtap[64], G[64];
-  __shared__ int s_nh;
+  __shared__ int s_nh, s_trange[2];
 
   const int64_t p0 = F.uoff[u], p1 = F.uoff[u + 1];
   // slots: pairs whose ring code is valid (key low nibble != 15), at most M (detsim.py:582-607)
@@ -231,6 +238,15 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   // ---- summed waveform: each thread owns ticks tid, tid+256, ... and adds the slots' rows in slot order, each over the ticks
   // its window puts on the pixel's time axis (detsim.py:516-520) ------------------------------------------------------------
   for (int t = tid; t < NT; t += FEE_THREADS) S[t] = 0;
+  if (tid == 0) {          // the ticks the slots' windows cover
+    int t_lo = NT, t_hi = 0;
+    for (int k = 0; k < n_slots; k++) {
+      const int lo = max(s_start[k] + s_w0[k], 0), hi = min(s_start[k] + s_w1[k], NT);
+      if (hi > lo) { t_lo = min(t_lo, lo); t_hi = max(t_hi, hi); }
+    }
+    s_trange[0] = t_lo;
+    s_trange[1] = t_hi;
+  }
   for (int k = 0; k < n_slots && !(F.debug & 0x10000); k++) {
     const int st = s_start[k];
     const int lo = max(st + s_w0[k], 0), hi = min(st + s_w1[k], NT);
@@ -243,7 +259,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
     const double thr = F.thr_table ? F.thr_table[F.upix[u]] : F.threshold;
     int nd = 0;
     int nh = (F.debug & 0x20000) ? 0 : adc_scan(c, S, NT, 1 * c->time_interval[1], thr, F.time_padding, lane, hits, wtap, ntap,
-                      F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd);
+                      F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd, s_trange[0], s_trange[1]);
     if (lane == 0) {
       s_nh = nh;
       if (F.n_draws) F.n_draws[u] = nd;

@@ -336,7 +336,15 @@ extern "C++" int gform_M(const ldsim_ctx* ctx, const CurArgs& args) {
 
 // tables + correlation of all pairs of `a`; *flags = device array [n_pairs] of the pairs left to the monolithic kernel.
 // Returns 0 = done, 1 = configuration not covered, < 0 = error.  One host sync (the size of the record pool).
-extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out) {
+// the pairs flagged for the monolithic kernel, as a list (none in most launches: a workgroup per pair to look would cost 0.5 ms)
+__global__ void __launch_bounds__(256) gflag_list_kernel(const int32_t* __restrict__ flags, int64_t n, int32_t* __restrict__ list,
+                                                        unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && flags[i]) list[atomicAdd(count, 1ull)] = (int32_t)i;
+}
+
+extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long long* counters, int32_t** flags_out,
+                              const int32_t** flag_list, const unsigned long long** flag_count) {
   const int M = gform_M(ctx, a);
   if (!M) return 1;
   const int64_t n = a.n_pairs;
@@ -345,7 +353,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if ((rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(n)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_HDR, (size_t)n * sizeof(GInfo)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_ITEMS, (size_t)(n + 16) * 4))) return rc;                    // flags
-  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 4) * 8 + (size_t)(2 * n + 2) * 4))) return rc;      // sizes | offsets | total, n_big, n_wg | big list | wg list
+  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 4) * 8 + (size_t)(3 * n + 2) * 4))) return rc;      // sizes | offsets | total, n_big, n_wg, n_flagged | big list | wg list | flagged list
   SplitArgs S{};
   S.c = a;
   GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
@@ -369,7 +377,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   const int lds_small = 16384 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
   int32_t* d_big = (int32_t*)(d_total + 4);
   int32_t* d_wg = d_big + n;                       // the pairs the tables stage gives to its workgroup kernel
-  HIPCHK(hipMemsetAsync(d_total + 1, 0, 16, st));
+  HIPCHK(hipMemsetAsync(d_total + 1, 0, 24, st));
   hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, lds_small, d_big, d_total + 1);
   HIPCHK(hipGetLastError());
   GA.gi = gi;
@@ -420,5 +428,9 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // the pool's size in the statistics slot of the split paths (doubles)
   HIPCHK(hipMemcpyAsync(&counters[7], d_total, 8, hipMemcpyDeviceToDevice, st));
   *flags_out = GA.flags;
+  hipLaunchKernelGGL(gflag_list_kernel, dim3(g0), dim3(256), 0, st, GA.flags, n, d_wg + n, d_total + 3);
+  HIPCHK(hipGetLastError());
+  *flag_list = d_wg + n;
+  *flag_count = d_total + 3;
   return 0;
 }

@@ -49,6 +49,8 @@ struct CurArgs {
                                  // row is written in full (zeros outside the window)
   const int32_t* only_flagged;   // if set: run only pairs whose only_flagged[pair*flag_stride + 7] != 0
   int32_t flag_stride;
+  const int32_t* flag_list;      // if set: the flagged pairs as a list of *flag_count entries; a fixed grid walks it (no workgroup per pair
+  const unsigned long long* flag_count;   //   that only finds its flag unset)
 };
 
 struct FeeArgs {

@@ -26,6 +26,7 @@ ch.run(0, len(seg), want_fractions=True)
 WHICH = sys.argv[4] if len(sys.argv) > 4 else "tables"
 RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 0, 0), (0x8000000, 0, 0), (0x6000000, 0, 0),
                    (0xe000000, 0, 0), (0xe000000, 0, 16), (0, 0, 16), (0, 0, 32), (0, 0, 0)),
+        "adc": ((0, 0, 0), (0x10000, 0, 0), (0x20000, 0, 0), (0x40000, 0, 0), (0x60000, 0, 0), (0x70000, 0, 0), (0, 0, 0)),
         "corr": ((0, 0, 0), (0x100000, 0, 0), (0x200000, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0x100000, 0, 4), (0x100000, 0, 12),
                  (0x100000, 0, 14), (0, -12, 0), (0, 6, 0), (0, 0, 0))}
 for mask, pad, dbg in RUNS[WHICH]:
@@ -34,6 +35,6 @@ for mask, pad, dbg in RUNS[WHICH]:
     lib.set_option("debug_gform", dbg)
     st = ch.run(0, len(seg), want_fractions=True)
     ms = ch.kernel_ms()
-    print(f"{cfg} {resp} debug_phases {mask:#10x} lds pad {pad:2d} KB dbg {dbg:2d}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
+    print(f"{cfg} {resp} debug_phases {mask:#10x} lds pad {pad:2d} KB dbg {dbg:2d}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  fallback {ms['fallback_ms']:.2f}  adc {ms['adc_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
 lib.set_option("debug_phases", 15)
 lib.set_option("debug_gform", 0)
