@@ -19,14 +19,18 @@ template <bool RESPONSE>
 __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     const float* __restrict__ inc, const int64_t* __restrict__ tid, const double* __restrict__ tph, int D, int T, int Mt,
     const double* __restrict__ weights /* [C+1] */, int C, const double* __restrict__ gain /* [D] or NULL */,
-    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid, double* __restrict__ out_tph,
-    const double* __restrict__ truth_max /* [D][T]: light_truth_max_kernel, or NULL when Mt == 0 */) {
+    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid /* [D][Mt][T]: slot-major working copy */,
+    double* __restrict__ out_tph /* [D][Mt][T] */,
+    const double* __restrict__ truth_max /* [D][T]: light_truth_max_kernel, or NULL when Mt == 0 */,
+    const int64_t* __restrict__ tid_sm /* RESPONSE: the input ids slot-major, [D][Mt][T] (read at the OUTPUT tick) */) {
   __shared__ float s_x[JCHUNK];
   __shared__ double s_w[JCHUNK + LR_THREADS];
   // largest photon count (RESPONSE: magnitude) among the filled truth slots of input tick j, -1 when it has none: a pair
   // (i, j) whose weight times this stays below the threshold cannot pass the per-slot test (rounding is monotone), so its
   // walk over the <= Mt slots -- Mt global reads per pair -- is skipped as a whole
   __shared__ double s_tmax[JCHUNK];
+  __shared__ int64_t s_sid[LR_THREADS / 64][64];       // a wave's copy of the truth slots of the input tick it is walking
+  __shared__ double s_sph[LR_THREADS / 64][64];
   const int d = blockIdx.y;
   const int i0 = blockIdx.x * LR_THREADS;
   const int i = i0 + threadIdx.x;
@@ -37,6 +41,11 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   float acc = live ? out[(int64_t)d * T + i] : 0.f;
   const double g = RESPONSE ? gain[d] : 1.0;
   const int my_j0 = max(i - C, 0);
+  // the output's truth rows live slot-major while the kernel works ([detector][slot][tick]: the wave's 64 ticks of one slot are
+  // one 512-byte run; in the reference's [detector][tick][slot] every lane's row is 8 Mt bytes from its neighbour's and each
+  // access of a term its own cache line -- the stage ran at the rate the L2 serves those lines)
+  const int64_t orow = (int64_t)d * Mt * T + i;
+  auto O = [&](int b) { return orow + (int64_t)b * T; };
   // RESPONSE: the reference's slot search compares ids of the INPUT row at the OUTPUT tick (light_sim.py:331-335), which
   // does not change while this thread works: with f = index of that row's first -1 (Mt if none) and distinct ids in front
   // of it, "first b with tid[dst+b] == tid[dst+a] or -1" is a itself for a < f and f otherwise -- no search.  Rows with a
@@ -58,7 +67,7 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     prefix_ok = true;
     bool seen_empty = false;
     for (int b = 0; b < Mt; b++) {
-      const int64_t id = out_tid[dst + b];
+      const int64_t id = out_tid[O(b)];
       if (id == -1) { seen_empty = true; continue; }
       if (seen_empty) { prefix_ok = false; break; }
       filled = b + 1;
@@ -72,12 +81,12 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   if (RESPONSE && Mt > 0 && live) {
     const int64_t dst = ((int64_t)d * T + i) * Mt;
     for (int b = 0; b < Mt; b++)
-      if (tid[dst + b] == -1) { row_f = b; break; }
+      if (tid_sm[O(b)] == -1) { row_f = b; break; }
     row_unique = true;
     for (int b = 1; b < row_f && row_unique; b++) {
-      const int64_t idb = tid[dst + b];
+      const int64_t idb = tid_sm[O(b)];
       for (int e = 0; e < b; e++)
-        if (tid[dst + e] == idb) { row_unique = false; break; }
+        if (tid_sm[O(e)] == idb) { row_unique = false; break; }
     }
   }
 
@@ -92,53 +101,69 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     }
     for (int k = threadIdx.x; k <= n_hi - n_lo; k += LR_THREADS) s_w[k] = weights[n_lo + k];
     __syncthreads();
-    if (!live) continue;
-    // one j loop for the whole wave (a thread's own range [i - C, i] is a predicate): the input tick's sample, bound and
-    // truth slots then sit at wave-uniform addresses, i.e. broadcast LDS reads and scalar loads instead of per-lane loads
-    // (measured: it pays for the SiPM stage, 66 -> 46 ms at 50 slots, and costs the scintillation stage 10 %, whose zero
-    // samples let a thread skip most of its own range anyway -- that one keeps the per-thread range)
-    const int ja = RESPONSE ? jc : max(jc, my_j0), jb = RESPONSE ? jc + nj - 1 : min(jc + nj - 1, i);
-    for (int j = ja; j <= jb; j++) {
-      if (RESPONSE && (j < my_j0 || j > i)) continue;
+    // One j loop for the whole wave (a thread's own range [i - C, i] is a predicate): the input tick's sample and bound are
+    // broadcast LDS reads, a zero sample or a tick without truth skips the wave as a whole, and when some lane's product can
+    // pass the threshold the wave stages the tick's <= 64 truth slots in LDS with one coalesced read -- the walk over them
+    // (the bulk of the truth leg: one dependent L2 round trip per slot and pair before) then runs on LDS broadcasts.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = jc; j <= jc + nj - 1; j++) {
       const float xv = s_x[j - jc];
       if (!RESPONSE && xv == 0.f) continue;                                     // light_sim.py:166-167
-      const double w = s_w[(i - j) - n_lo];
-      if (RESPONSE) acc = (float)((double)acc + g * w * (double)xv);            // :320  LIGHT_GAIN[idet] * tick_weight * x
-      else acc = (float)((double)acc + w * (double)xv);                         // :169
-      if (Mt > 0 && s_tmax[j - jc] >= 0.0 &&
-          !(RESPONSE ? (fabs(w) * s_tmax[j - jc] < truth_threshold) : (w >= 0.0 && w * s_tmax[j - jc] < truth_threshold))) {
-        const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
+      const bool mine = live && j >= my_j0 && j <= i;
+      const double w = mine ? s_w[(i - j) - n_lo] : 0.0;
+      if (mine) {
+        if (RESPONSE) acc = (float)((double)acc + g * w * (double)xv);          // :320  LIGHT_GAIN[idet] * tick_weight * x
+        else acc = (float)((double)acc + w * (double)xv);                       // :169
+      }
+      if (Mt <= 0) continue;
+      const double bound = s_tmax[j - jc];
+      if (bound < 0.0) continue;
+      const bool walk = mine && !(RESPONSE ? (fabs(w) * bound < truth_threshold) : (w >= 0.0 && w * bound < truth_threshold));
+      if (!__ballot(walk)) continue;
+      const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
+      const bool staged = Mt <= 64;
+      if (staged) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < Mt) {
+          s_sid[wv][lane] = tid[src + lane];
+          s_sph[wv][lane] = tph[src + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (walk) {
         for (int a = 0; a < Mt; a++) {
-          if (tid[src + a] == -1) break;
-          const double ph = tph[src + a];
+          const int64_t ida_src = staged ? s_sid[wv][a] : tid[src + a];
+          if (ida_src == -1) break;
+          const double ph = staged ? s_sph[wv][a] : tph[src + a];
           if (RESPONSE ? (fabs(w * ph) < truth_threshold) : (w * ph < truth_threshold)) continue;
           if (RESPONSE && row_unique) {
             const int b = a < row_f ? a : row_f;
             if (b < Mt) {
-              out_tid[dst + b] = tid[dst + a];
-              out_tph[dst + b] += w * ph;
+              out_tid[O(b)] = tid_sm[O(a)];
+              out_tph[O(b)] += w * ph;
             }
             continue;
           }
           if (!RESPONSE && prefix_ok) {
-            const int64_t id = tid[src + a];
+            const int64_t id = ida_src;
             unsigned long long ws;
             const unsigned long long bit = sig_bit(id, ws);
             const unsigned long long word = ws == 0 ? sig0 : (ws == 1 ? sig1 : (ws == 2 ? sig2 : sig3));
             if (id != -1 && !(word & bit)) {             // certainly not stored yet
               if (filled < Mt) {
-                out_tid[dst + filled] = id;
-                out_tph[dst + filled] += w * ph;
+                out_tid[O(filled)] = id;
+                out_tph[O(filled)] += w * ph;
                 filled++;
                 if (ws == 0) sig0 |= bit; else if (ws == 1) sig1 |= bit; else if (ws == 2) sig2 |= bit; else sig3 |= bit;
               }
               continue;
             }
             for (int b = 0; b < Mt; b++) {              // maybe stored: the literal search (an insert extends the prefix)
-              const int64_t cur = out_tid[dst + b];
+              const int64_t cur = out_tid[O(b)];
               if (cur == id || cur == -1) {
-                out_tid[dst + b] = id;
-                out_tph[dst + b] += w * ph;
+                out_tid[O(b)] = id;
+                out_tph[O(b)] += w * ph;
                 if (cur == -1 && id != -1) {
                   filled = b + 1;
                   if (ws == 0) sig0 |= bit; else if (ws == 1) sig1 |= bit; else if (ws == 2) sig2 |= bit; else sig3 |= bit;
@@ -151,17 +176,17 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
           for (int b = 0; b < Mt; b++) {
             if (RESPONSE) {
               // :331-335 literally: the slot test reads the INPUT ids at [idet, itick], not the output's
-              const int64_t idb = tid[dst + b], ida = tid[dst + a];
+              const int64_t idb = tid_sm[O(b)], ida = tid_sm[O(a)];
               if (idb == ida || idb == -1) {
-                out_tid[dst + b] = ida;
-                out_tph[dst + b] += w * ph;
+                out_tid[O(b)] = ida;
+                out_tph[O(b)] += w * ph;
                 break;
               }
             } else {
-              const int64_t id = tid[src + a];
-              if (out_tid[dst + b] == id || out_tid[dst + b] == -1) {           // :180-183
-                out_tid[dst + b] = id;
-                out_tph[dst + b] += w * ph;
+              const int64_t id = ida_src;
+              if (out_tid[O(b)] == id || out_tid[O(b)] == -1) {           // :180-183
+                out_tid[O(b)] = id;
+                out_tph[O(b)] += w * ph;
                 break;
               }
             }
@@ -191,6 +216,40 @@ __global__ void light_truth_max_kernel(const int64_t* __restrict__ tid, const do
   truth_max[e] = any ? (response ? m : fmax(m, 0.0)) : -1.0;
 }
 
+// [detector][tick][slot] <-> [detector][slot][tick] of an 8-byte array, TR_TICKS ticks of one detector per workgroup through LDS
+// (both sides in runs of at least 512 bytes)
+#define TR_TICKS 64
+template <bool TO_SLOT_MAJOR>
+__global__ void __launch_bounds__(256) light_truth_transpose_kernel(const unsigned long long* __restrict__ src,
+                                                                    unsigned long long* __restrict__ dst, int T, int Mt) {
+  extern __shared__ unsigned long long s_t[];        // [TR_TICKS][Mt + 1]
+  const int d = blockIdx.y, t0 = blockIdx.x * TR_TICKS, nt = min(TR_TICKS, T - t0);
+  const int64_t row_major = ((int64_t)d * T + t0) * Mt;          // nt * Mt contiguous words
+  const int64_t slot_major = (int64_t)d * Mt * T + t0;           // slot b: nt words at + b * T
+  const int n = nt * Mt;
+  if (TO_SLOT_MAJOR) {
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int t = e / Mt, b = e - t * Mt;
+      s_t[t * (Mt + 1) + b] = src[row_major + e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Mt * TR_TICKS; e += 256) {
+      const int b = e / TR_TICKS, t = e % TR_TICKS;
+      if (t < nt) dst[slot_major + (int64_t)b * T + t] = s_t[t * (Mt + 1) + b];
+    }
+  } else {
+    for (int e = threadIdx.x; e < Mt * TR_TICKS; e += 256) {
+      const int b = e / TR_TICKS, t = e % TR_TICKS;
+      if (t < nt) s_t[t * (Mt + 1) + b] = src[slot_major + (int64_t)b * T + t];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int t = e / Mt, b = e - t * Mt;
+      dst[row_major + e] = s_t[t * (Mt + 1) + b];
+    }
+  }
+}
+
 extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid,
                                        const double* tph, int D, int T, int Mt, const double* weights, int C,
                                        const double* gain, float* out, int64_t* out_tid, double* out_tph) {
@@ -207,12 +266,44 @@ extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const floa
                        response ? 1 : 0, tmax);
     HIPCHK(hipGetLastError());
   }
+  // the output's truth rows: to slot-major, through the kernel, and back (2 x 2 passes over [D][T][Mt]: a few ms at 2.5 GB each)
+  int64_t* w_tid = nullptr;
+  int64_t* in_sm = nullptr;
+  double* w_tph = nullptr;
+  if (Mt > 0) {
+    const size_t bt = (size_t)D * T * Mt;
+    int rc = ldsim_ensure_buf(ctx, &ctx->light_wtid, bt * 8 + 16);
+    if (rc) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &ctx->light_wtph, bt * 8 + 16))) return rc;
+    w_tid = (int64_t*)ctx->light_wtid.p;
+    w_tph = (double*)ctx->light_wtph.p;
+    dim3 tg((unsigned)((T + TR_TICKS - 1) / TR_TICKS), (unsigned)D);
+    hipLaunchKernelGGL(light_truth_transpose_kernel<true>, tg, dim3(256), (size_t)TR_TICKS * (Mt + 1) * 8, ctx->stream,
+                       (const unsigned long long*)out_tid, (unsigned long long*)w_tid, T, Mt);
+    hipLaunchKernelGGL(light_truth_transpose_kernel<true>, tg, dim3(256), (size_t)TR_TICKS * (Mt + 1) * 8, ctx->stream,
+                       (const unsigned long long*)out_tph, (unsigned long long*)w_tph, T, Mt);
+    if (response) {        // the SiPM stage compares ids of the INPUT row at the output tick (light_sim.py:331-335): slot-major too
+      if ((rc = ldsim_ensure_buf(ctx, &ctx->light_wtid2, bt * 8 + 16))) return rc;
+      in_sm = (int64_t*)ctx->light_wtid2.p;
+      hipLaunchKernelGGL(light_truth_transpose_kernel<true>, tg, dim3(256), (size_t)TR_TICKS * (Mt + 1) * 8, ctx->stream,
+                         (const unsigned long long*)tid, (unsigned long long*)in_sm, T, Mt);
+    }
+    HIPCHK(hipGetLastError());
+  }
   if (response)
     hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain, thr,
-                       out, out_tid, out_tph, tmax);
+                       out, w_tid, w_tph, tmax, in_sm);
   else
     hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain,
-                       thr, out, out_tid, out_tph, tmax);
+                       thr, out, w_tid, w_tph, tmax, (const int64_t*)nullptr);
   HIPCHK(hipGetLastError());
+  if (Mt > 0) {
+    dim3 tg((unsigned)((T + TR_TICKS - 1) / TR_TICKS), (unsigned)D);
+    hipLaunchKernelGGL(light_truth_transpose_kernel<false>, tg, dim3(256), (size_t)TR_TICKS * (Mt + 1) * 8, ctx->stream,
+                       (const unsigned long long*)w_tid, (unsigned long long*)out_tid, T, Mt);
+    hipLaunchKernelGGL(light_truth_transpose_kernel<false>, tg, dim3(256), (size_t)TR_TICKS * (Mt + 1) * 8, ctx->stream,
+                       (const unsigned long long*)w_tph, (unsigned long long*)out_tph, T, Mt);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }

@@ -105,6 +105,7 @@ struct ldsim_ctx {
   double quad_n0 = 4.8, quad_slope = 1.6;    // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-10 of the peak weight
   // overlapped download of the chain's results (ldsim_chain_download_async): a second stream copies launch k's per-pixel
   // arrays to the host while launch k + 1 computes into the other set of output buffers
+  DevBuf light_wtid, light_wtph, light_wtid2;            // slot-major working copies of a response stage's output truth rows
   DevBuf light_tmax;                         // per (detector, tick) bound on the truth slots' photons (light_truth_max_kernel)
   hipStream_t copy_stream = nullptr;
   DevBuf out_alt[7];                         // the other set of SB_UPIX, SB_UBATCH, SB_ADC, SB_TICKS, SB_DIGIT, SB_TPM, SB_FRAC
