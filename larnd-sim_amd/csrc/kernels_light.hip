@@ -388,6 +388,87 @@ __global__ void light_replay_kernel(const unsigned long long* __restrict__ keys,
   out[o] = acc;
 }
 
+
+// The same replay with a wave per block of RW_BLOCK sorted records (max_truth <= 64): the wave owns the (detector, tick) cells
+// whose first record lies in its block and walks each to its end.  The records are fetched 64 at a time, one per lane (key,
+// photons and track id: three dependent loads, but 64 in flight), and replayed in order from registers; lane k keeps truth
+// slot k of the cell, so "the first slot that is empty or holds this id" (light_sim.py:120-126) is one ballot and the row is
+// read and written once, coalesced.  One thread per cell walked its run alone with a global-memory slot search per record:
+// a busy tick of a busy detector (thousands of records) set the kernel's time.
+#define RW_BLOCK 256
+__global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned long long* __restrict__ keys,
+                                                               const int32_t* __restrict__ vals, const int32_t* __restrict__ rec_seg,
+                                                               const double* __restrict__ rec_ph, int64_t n_rec,
+                                                               const int64_t* __restrict__ track_id, int64_t n_ticks,
+                                                               double truth_threshold, float* __restrict__ out,
+                                                               int64_t* __restrict__ true_id, double* __restrict__ true_ph,
+                                                               int max_truth) {
+  const int lane = threadIdx.x;
+  const int SH = LK_RANK_BITS + LK_IP_BITS;
+  const int64_t b0 = (int64_t)blockIdx.x * RW_BLOCK, b1 = min(b0 + RW_BLOCK, n_rec);
+  auto rl64 = [](unsigned long long v, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, l);
+  };
+  bool open = false;                 // a cell of this wave is being replayed
+  unsigned cur_cell = 0;
+  int64_t o = 0;
+  float acc = 0.f;
+  int64_t slot_id = -1;              // lane k: truth slot k of the open cell
+  double slot_ph = 0.0;
+  auto close_cell = [&]() {
+    if (lane == 0) out[o] = acc;
+    if (lane < max_truth) {
+      true_id[o * max_truth + lane] = slot_id;
+      true_ph[o * max_truth + lane] = slot_ph;
+    }
+  };
+  unsigned prev_cell = b0 > 0 ? (unsigned)(keys[b0 - 1] >> SH) : 0xFFFFFFFFu;       // (cells use 28 bits)
+  for (int64_t c0 = b0; c0 < n_rec; c0 += 64) {
+    if (c0 >= b1 && !open) break;                 // past the block and nothing left to finish
+    const int64_t j = c0 + lane;
+    unsigned cell = 0xFFFFFFFFu;
+    double ph = 0.0;
+    int64_t id = -1;
+    if (j < n_rec) {
+      cell = (unsigned)(keys[j] >> SH);
+      const int32_t w = vals[j];
+      ph = rec_ph[w];
+      id = track_id[rec_seg[w]];
+    }
+    const int nv = (int)min((int64_t)64, n_rec - c0);
+    bool done = false;
+    for (int t = 0; t < nv && !done; t++) {
+      const unsigned ct = (unsigned)__builtin_amdgcn_readlane((int)cell, t);
+      const bool head = ct != prev_cell;
+      prev_cell = ct;
+      if (head) {
+        if (open) { close_cell(); open = false; }
+        if (c0 + t >= b1) { done = true; break; }          // the next block's cell
+        open = true;
+        cur_cell = ct;
+        o = (int64_t)(ct >> LK_TICK_BITS) * n_ticks + (int64_t)(ct & ((1u << LK_TICK_BITS) - 1));
+        acc = out[o];
+        slot_id = lane < max_truth ? true_id[o * max_truth + lane] : -2;
+        slot_ph = lane < max_truth ? true_ph[o * max_truth + lane] : 0.0;
+      }
+      if (!open) continue;                                   // the tail of a cell that began in an earlier block
+      const double pt = __longlong_as_double((long long)rl64((unsigned long long)__double_as_longlong(ph), t));
+      acc = (float)((double)acc + pt);
+      if (pt > truth_threshold) {
+        const int64_t it = (int64_t)rl64((unsigned long long)id, t);
+        const unsigned long long m = __ballot(lane < max_truth && (slot_id == -1 || slot_id == it));
+        if (m && lane == __ffsll((long long)m) - 1) {
+          slot_id = it;
+          slot_ph += pt;
+        }
+      }
+    }
+    if (done) break;
+  }
+  if (open) close_cell();
+}
+
 extern "C++" {
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
@@ -499,8 +580,12 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   hipLaunchKernelGGL(light_fill_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_offs, d_rank, k0, v0, rseg, rph);
   HIPCHK(hipGetLastError());
   if ((rc = sort_pairs(ctx, k0, k1, v0, v1, n_rec))) return rc;
-  hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, rseg, rph, n_rec, track_id,
-                     n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
+  if (max_truth <= 64)
+    hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_rec, RW_BLOCK)), dim3(64), 0, st, k1, v1, rseg, rph, n_rec, track_id,
+                       n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
+  else
+    hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, rseg, rph, n_rec, track_id,
+                       n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
   HIPCHK(hipGetLastError());
   return 0;
 }
