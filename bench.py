@@ -371,7 +371,7 @@ def main():
         gform = a.weights_mode == 2
         # csrc/kernels_gcorr.hip (node-separable form) or csrc/kernels_macshift.hip
         mac_name = f"gcorr_kernel<{M}>" if gform else ("mac_shift_kernel" if M == 1 else "mac_shift2_kernel")
-        w_name = f"gtables_kernel<{M}>" if gform else (f"qweights_kernel<{M}>" if a.weights_mode == 1 else f"weights_kernel<{M}>")
+        w_name = f"gtables_wave_kernel<{M}>" if gform else (f"qweights_kernel<{M}>" if a.weights_mode == 1 else f"weights_kernel<{M}>")
         # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]

@@ -278,8 +278,8 @@ class ChargeChain:
         resp = np.zeros((nd, nt), dtype=np.float32)
         sc = np.zeros((nd, nt), dtype=np.float32) if stages else None
         di = np.zeros((nd, nt), dtype=np.float32) if stages else None
-        tid = np.full((nd, nt, mt), -1, dtype=np.int64)
-        tph = np.zeros((nd, nt, mt))
+        tid = np.full((nd, nt, mt if truth else 0), -1, dtype=np.int64)
+        tph = np.zeros((nd, nt, mt if truth else 0))
         lib.check(lib.load().ldsim_dev_light_response_download(
             self.ctx, lib.ptr(sc), lib.ptr(di), lib.ptr(resp), lib.ptr(tid) if (mt and truth) else None,
             lib.ptr(tph) if (mt and truth) else None))
@@ -294,10 +294,11 @@ class ChargeChain:
         """(light_sample_inc f4 [n_det][n_ticks], true_track_id i8 [..][max_truth], true_photons f8 [..][max_truth])."""
         nd, nt, mt = self._light_shape
         out = np.zeros((nd, nt), dtype=np.float32)
-        tid = np.full((nd, nt, mt), -1, dtype=np.int64)
-        tph = np.zeros((nd, nt, mt))
-        lib.check(lib.load().ldsim_dev_light_download(self.ctx, lib.ptr(out), lib.ptr(tid) if (mt and truth) else None,
-                                                      lib.ptr(tph) if (mt and truth) else None))
+        want = bool(mt and truth)          # (the truth arrays are GBs at 50 slots: only made when asked for)
+        tid = np.full((nd, nt, mt if want else 0), -1, dtype=np.int64)
+        tph = np.zeros((nd, nt, mt if want else 0))
+        lib.check(lib.load().ldsim_dev_light_download(self.ctx, lib.ptr(out), lib.ptr(tid) if want else None,
+                                                      lib.ptr(tph) if want else None))
         return out, tid, tph
 
     def light_kernel_ms(self):
