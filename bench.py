@@ -28,7 +28,9 @@ for p in (os.path.join(REPO, "larnd-sim_amd"), REPO):
 import numpy as np  # noqa: E402
 
 SEGS_PER_GPU = 100_000
-CHUNK_SEGMENTS = 50_000
+# segments per chain launch (whole batches).  Measured on module0 (gpurun_out sweep): 25 k 3.36, 50 k 3.51,
+# 100 k 3.58, 200 k 3.67 x 10^6 segments/s -- fixed costs per launch (5 host round trips, sorts, tails of the big kernels)
+CHUNK_SEGMENTS = int(os.environ.get("LDSIM_CHUNK_SEGMENTS", "100000"))
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "r03_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
