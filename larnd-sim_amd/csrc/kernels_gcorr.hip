@@ -28,8 +28,8 @@ static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padd
 #define GW 2             //   (the kernel waits on a chain of dependent latencies: DESIGN.md section 4, profiles/r03_occupancy*.log)
 
 // LDS of a pair, carved from the dynamic block by its real dimensions (a typical pair needs 12 KB; sized for the caps it would
-// be 54 KB and two pairs per CU).  Two size classes: pairs that fit `small` (16 KB; measured: 10 pairs per CU at 96 VGPRs
-// beat 8 at 128 and 12 at 80 with spills, profiles/r03_gcorr_occupancy.log) run 10 per CU, the others in a second launch.
+// be 54 KB and two pairs per CU).  Size classes: pairs that fit 16 KB (measured: 10 pairs per CU at 96 VGPRs beat 8 at 128
+// and 12 at 80 with spills, profiles/r03_gcorr_occupancy.log) run 10 per CU, the others in launches of their own (g_lds_class).
 struct GLds {
   int xs, ys, zs, cellcap, bytes;
   bool z_lds;
@@ -50,8 +50,16 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   return L;
 }
 
+// the launch a pair belongs to: the smallest LDS budget its tables fit (0: the launch over all pairs, 16 KB, ten pairs per CU;
+// 1: 32 KB, five per CU; 2: the largest pair the caps allow, two to three per CU -- launches over lists)
+__host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, int TT, int b0, int b1) {
+  if (g_lds_layout(ncol, NJ, NU, TT, b0).bytes <= b0) return 0;
+  return g_lds_layout(ncol, NJ, NU, TT, b1).bytes <= b1 ? 1 : 2;
+}
+
 template <int M>
-__global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int lds_budget, int lds_big, const int32_t* __restrict__ big_list) {
+__global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
+                                                      int cls) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -75,9 +83,8 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int lds_
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
-  const bool small = g_lds_layout(ncol, NJ, NU, TT, lds_budget).bytes <= lds_budget;
-  if (small != (big_list == nullptr)) return;      // the other launch's pair
-  const GLds L = g_lds_layout(ncol, NJ, NU, TT, small ? lds_budget : lds_big);
+  if (g_lds_class(ncol, NJ, NU, TT, b0, b1) != cls) return;      // another launch's pair
+  const GLds L = g_lds_layout(ncol, NJ, NU, TT, cls == 0 ? b0 : (cls == 1 ? b1 : b2));
   const double* __restrict__ rec = GA.rec + gip->off;
   const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
   const int NUr = g_nur(NU), NU16 = NUr >> 4;
@@ -296,12 +303,23 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int lds_
   if (tid == 0 && n_useful) stat_add(A.counters, 8, n_useful);
 }
 
-// pairs whose LDS need exceeds the small budget, for the second launch
-__global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict__ gi, int64_t n, int TT, int lds_budget,
-                                                        int32_t* __restrict__ list, unsigned long long* __restrict__ count) {
+// the pairs of the launches after the first (g_lds_class 1, 2), one atomic per wave and list
+__global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict__ gi, int64_t n, int TT, int b0, int b1,
+                                                        int32_t* __restrict__ lists /* [2][n] */,
+                                                        unsigned long long* __restrict__ counts /* [2] */) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || gi[i].status != 1) return;
-  if (g_lds_layout(gi[i].ncol, gi[i].NJ, gi[i].NU, TT, lds_budget).bytes > lds_budget) list[atomicAdd(count, 1ull)] = (int32_t)i;
+  const int lane = threadIdx.x & 63;
+  int cls = 0;
+  if (i < n && gi[i].status == 1) cls = g_lds_class(gi[i].ncol, gi[i].NJ, gi[i].NU, TT, b0, b1);
+  for (int c = 1; c <= 2; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&counts[c - 1], (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (cls == c) lists[(int64_t)(c - 1) * n + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+  }
 }
 
 // ---- record offsets: exclusive scan of the sizes pair_setup_kernel wrote ------------------------------------------------------------
@@ -319,8 +337,10 @@ __global__ void __launch_bounds__(256) goff_scatter_kernel(GInfo* __restrict__ g
 }
 
 int sort_exclusive_scan_u64(ldsim_ctx*, const unsigned long long*, unsigned long long*, int64_t);
-extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* list, int64_t n_list);
-extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* list, unsigned long long* count);
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* wg_list, int64_t n_wg, const int32_t* w2_list,
+                                int64_t n_w2);
+extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* wg_list, unsigned long long* wg_count, int32_t* w2_list,
+                                     unsigned long long* w2_count);
 extern "C++" int resp_pad_ensure(ldsim_ctx* ctx, const CurArgs& A, int* k_lo, int* k_hi, int* nkp);
 
 // M of the form for these constants, 0 = configuration not covered (caller uses the monolithic kernel)
@@ -353,7 +373,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if ((rc = ldsim_ensure(ctx, SB_PPAR, qpair_params_bytes(n)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_HDR, (size_t)n * sizeof(GInfo)))) return rc;
   if ((rc = ldsim_ensure(ctx, SB_ITEMS, (size_t)(n + 16) * 4))) return rc;                    // flags
-  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 4) * 8 + (size_t)(3 * n + 2) * 4))) return rc;      // sizes | offsets | total, n_big, n_wg, n_flagged | big list | wg list | flagged list
+  if ((rc = ldsim_ensure(ctx, SB_CORR, (size_t)(2 * n + 8) * 8 + (size_t)(5 * n + 2) * 4))) return rc;      // sizes | offsets | total, 2 class counts, n_wg, n_flagged, n_w2 | 2 class lists | wg list | flagged list | wide-wave list
   SplitArgs S{};
   S.c = a;
   GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
@@ -372,22 +392,24 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
   const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
-  // Two launches of the correlation by LDS need: pairs that fit 16 KB run ten to a CU, the rest -- listed here, counted on
-  // the host together with the pool size -- three to a CU.
-  const int lds_small = 16384 - ctx->debug_lds_pad_kb * 1024, lds_big = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
-  int32_t* d_big = (int32_t*)(d_total + 4);
-  int32_t* d_wg = d_big + n;                       // the pairs the tables stage gives to its workgroup kernel
-  HIPCHK(hipMemsetAsync(d_total + 1, 0, 24, st));
-  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, lds_small, d_big, d_total + 1);
+  // Launches of the correlation by LDS need (g_lds_class): pairs that fit 16 KB run ten to a CU in the launch over all pairs, the
+  // rest -- listed here, counted on the host together with the pool size -- five to a CU at 32 KB or two to three at the caps' size.
+  const int b0 = 16384 - ctx->debug_lds_pad_kb * 1024, b1 = 32768, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
+  int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
+  int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
+  HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
+  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, b0, b1, d_big, d_total + 1);
   HIPCHK(hipGetLastError());
   GA.gi = gi;
   GA.dbg = (ctx->debug_gform & ~64) | (ctx->gform_wave_tables ? 0 : 64);
   GA.c.n_pairs = n;
-  if ((rc = gtables_list_launch(ctx, GA, d_wg, d_total + 2))) return rc;
-  unsigned long long h_tot[3] = {0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h_tot, d_total, 24, hipMemcpyDeviceToHost, st));
+  int32_t* d_w2 = d_wg + 2 * n;                    // (d_wg + n: the flagged list)
+  if ((rc = gtables_list_launch(ctx, GA, d_wg, d_total + 3, d_w2, d_total + 5))) return rc;
+  unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h_tot, d_total, 48, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  const unsigned long long total = h_tot[0], n_big = h_tot[1], n_wg = h_tot[2];
+  const unsigned long long total = h_tot[0], n_wg = h_tot[3], n_w2 = h_tot[5];
+  const unsigned long long n_cls[3] = {(unsigned long long)n, h_tot[1], h_tot[2]};
   if (getenv("LDSIM_DEBUG_GFORM")) {      // class sizes of the launch, and why pairs miss the wave kernel
     std::vector<GInfo> h((size_t)n);
     HIPCHK(hipMemcpy(h.data(), gi, (size_t)n * sizeof(GInfo), hipMemcpyDeviceToHost));
@@ -398,11 +420,12 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
       nb2 += g.NB > 1;
       if (g.wave_ok) continue;
       if (g.NU > G_NUCAP) nu++;
-      else if (g.ncol + g.NJ > 54) xy++;
+      else if (g.ncol + g.NJ > 80) xy++;
       else sl++;
     }
-    fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 128: %ld, X | Y bins > 54: %ld, "
-            "slices > 64: %ld), big LDS class %llu, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl, n_big, total * 8e-9);
+    fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 128: %ld, X | Y bins > 80: %ld, "
+            "slices > 64: %ld), wide wave tables kernel %llu, correlation launches at 32 KB / %d KB of LDS: %llu / %llu pairs, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl,
+            n_w2, b2 >> 10, n_cls[1], n_cls[2], total * 8e-9);
   }
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));
@@ -414,23 +437,23 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   GA.glx = ctx->d_glx;
   GA.glw = ctx->d_glw;
   GA.resp_pad = (const double*)ctx->resp_pad.p;
-  if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg))) return rc;
+  if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg, d_w2, (int64_t)n_w2))) return rc;
   HIPCHK(hipEventRecord(ctx->ev[5], st));
-  if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, lds_big, (const int32_t*)nullptr);
-  else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n), dim3(GT), (size_t)lds_small, st, GA, TT, lds_small, lds_big, (const int32_t*)nullptr);
-  HIPCHK(hipGetLastError());
-  if (n_big > 0) {
-    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, lds_big, d_big);
-    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_big), dim3(GT), (size_t)lds_big, st, GA, TT, lds_small, lds_big, d_big);
+  for (int cls = 0; cls < 3; cls++) {
+    if (n_cls[cls] == 0) continue;
+    const int32_t* list = cls == 0 ? nullptr : d_big + (int64_t)(cls - 1) * n;
+    const size_t dyn = (size_t)(cls == 0 ? b0 : (cls == 1 ? b1 : b2));
+    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_cls[cls]), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls);
+    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_cls[cls]), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   // the pool's size in the statistics slot of the split paths (doubles)
   HIPCHK(hipMemcpyAsync(&counters[7], d_total, 8, hipMemcpyDeviceToDevice, st));
   *flags_out = GA.flags;
-  hipLaunchKernelGGL(gflag_list_kernel, dim3(g0), dim3(256), 0, st, GA.flags, n, d_wg + n, d_total + 3);
+  hipLaunchKernelGGL(gflag_list_kernel, dim3(g0), dim3(256), 0, st, GA.flags, n, d_wg + n, d_total + 4);
   HIPCHK(hipGetLastError());
   *flag_list = d_wg + n;
-  *flag_count = d_total + 3;
+  *flag_count = d_total + 4;
   return 0;
 }

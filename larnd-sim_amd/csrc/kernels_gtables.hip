@@ -395,25 +395,27 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 // carrying nodes q, 4 + q, 8 + q, 12 + q of its bin -- so a bin's member loop is shared by four nodes, the invalid-slice tables
 // of the window edges accumulate in the same pass as Z from the same Gaussians, and no index needs a division.
 // Entry for entry the same expressions and term order as gtables_kernel (the cell test sums the Z totals in another order).
-#define GW_XYS 55         // row stride of the joint X | Y table (ncol + NJ <= 54)
+// XYS = row stride of the joint X | Y table: 55 (ncol + NJ <= 54, 9.7 KB of LDS, 16 pairs per CU) for the launch over all pairs,
+// 81 (<= 80, 13 KB, 12 per CU, no register spill at 3 waves per SIMD) over the list of the pairs that need it (wide diffusion:
+// a sixth of the ndlar pairs)
 
-template <int M>
-__global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
+template <int M, int XYS>
+__global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
-  const int64_t pair = blockIdx.x;
+  const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
   GInfo* __restrict__ gip = GA.gi + pair;
   const int status = (A.debug_phases & 0x100) ? 0 : gip->status;
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
-    if (lane == 0) {
+    if (lane == 0 && !list) {
       GA.flags[pair] = status == 2;
       if (status == 2) stat_add(A.counters, 6, 1ull);
     }
     return;
   }
-  if (!gip->wave_ok || (GA.dbg & 64)) return;      // gtables_kernel's pair
+  if (gip->wave_ok != (XYS <= 55 ? 1 : 2) || (GA.dbg & 64)) return;      // the other instantiation's or gtables_kernel's pair
   const int ncol_g = gip->ncol, NJ_g = gip->NJ, u_min = gip->u_min, NU = gip->NU, ebound = gip->edge_bound, NB = gip->NB;
   double* __restrict__ rec = GA.rec + gip->off;
   const PairParams* __restrict__ P = GA.pp + pair;
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
 
   __shared__ double s_par[32];
   __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
-  __shared__ double s_XY[G_NODES][GW_XYS], s_zs[G_NODES];
+  __shared__ double s_XY[G_NODES][XYS], s_zs[G_NODES];
   __shared__ unsigned char s_invs[ZC];
   __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[G_NUCAP + 1];
 
@@ -505,7 +507,7 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
     if (j >= 0) s_dys[posn] = ddy;
     if (jmax >= jmin && lane <= NJ && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
   }
-  if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin || ncol + NJ > GW_XYS - 1) bad = true;
+  if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin || ncol + NJ > XYS - 1) bad = true;
 
   // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
   int n_sl, lo_c, NUc, anyinv = 0;
@@ -810,31 +812,52 @@ __global__ void __launch_bounds__(64, 4) gtables_wave_kernel(GArgs GA) {
   }
 }
 
-// the pairs gtables_wave_kernel leaves to gtables_kernel
-__global__ void __launch_bounds__(256) gtables_list_kernel(const GInfo* __restrict__ gi, int64_t n, int all, int32_t* __restrict__ list,
-                                                          unsigned long long* __restrict__ count) {
+// the pairs gtables_wave_kernel's first launch leaves to its wide instantiation (wave_ok 2) and to gtables_kernel (0); one atomic
+// per wave and list
+__global__ void __launch_bounds__(256) gtables_list_kernel(const GInfo* __restrict__ gi, int64_t n, int all, int32_t* __restrict__ wg_list,
+                                                          unsigned long long* __restrict__ wg_count, int32_t* __restrict__ w2_list,
+                                                          unsigned long long* __restrict__ w2_count) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || gi[i].status != 1) return;
-  if (all || !gi[i].wave_ok) list[atomicAdd(count, 1ull)] = (int32_t)i;
+  const int lane = threadIdx.x & 63;
+  int cls = 0;                 // 1: workgroup kernel, 2: wide wave kernel
+  if (i < n && gi[i].status == 1) cls = (all || gi[i].wave_ok == 0) ? 1 : (gi[i].wave_ok == 2 ? 2 : 0);
+  for (int c = 1; c <= 2; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(c == 1 ? wg_count : w2_count, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (cls == c) (c == 1 ? wg_list : w2_list)[(int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+  }
 }
 
-extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* list, unsigned long long* count) {
+extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* wg_list, unsigned long long* wg_count, int32_t* w2_list,
+                                     unsigned long long* w2_count) {
   const int64_t n = GA.c.n_pairs;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(gtables_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, GA.gi, n, (GA.dbg & 64) ? 1 : 0, list, count);
+  hipLaunchKernelGGL(gtables_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, GA.gi, n, (GA.dbg & 64) ? 1 : 0,
+                     wg_list, wg_count, w2_list, w2_count);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// wave kernel over all pairs, then the workgroup kernel over the `n_list` listed ones
-extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* list, int64_t n_list) {
+// wave kernel over all pairs, its wide instantiation over the `n_w2` pairs of `w2_list`, then the workgroup kernel over the `n_wg`
+// listed ones
+extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* wg_list, int64_t n_wg, const int32_t* w2_list,
+                                int64_t n_w2) {
   if (GA.c.n_pairs == 0) return 0;
-  if (M == 1) hipLaunchKernelGGL(gtables_wave_kernel<1>, dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA);
-  else hipLaunchKernelGGL(gtables_wave_kernel<2>, dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA);
+  if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 55>), dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA, (const int32_t*)nullptr);
+  else hipLaunchKernelGGL((gtables_wave_kernel<2, 55>), dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA, (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
-  if (n_list > 0) {
-    if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)n_list), dim3(CUR_THREADS), 0, ctx->stream, GA, list);
-    else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)n_list), dim3(CUR_THREADS), 0, ctx->stream, GA, list);
+  if (n_w2 > 0) {
+    if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 81>), dim3((unsigned)n_w2), dim3(64), 0, ctx->stream, GA, w2_list);
+    else hipLaunchKernelGGL((gtables_wave_kernel<2, 81>), dim3((unsigned)n_w2), dim3(64), 0, ctx->stream, GA, w2_list);
+    HIPCHK(hipGetLastError());
+  }
+  if (n_wg > 0) {
+    if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ctx->stream, GA, wg_list);
+    else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ctx->stream, GA, wg_list);
     HIPCHK(hipGetLastError());
   }
   return 0;
