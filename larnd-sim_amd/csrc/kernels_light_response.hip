@@ -11,6 +11,7 @@
 // x[j] (broadcast) and consecutive weights (conflict-free).  Truth slots (optional) follow the reference literally; a
 // per-tick bound on the slots' photons (light_truth_max_kernel) lets a pair (i, j) skip its slot walk when none can pass.
 #include "ldsim_dev.h"
+#include "wave_ops.h"
 
 #define LR_THREADS 256
 #define JCHUNK 1024
@@ -99,40 +100,85 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
       s_x[k] = x[jc + k];
       if (Mt > 0) s_tmax[k] = truth_max[(int64_t)d * T + jc + k];
     }
-    for (int k = threadIdx.x; k <= n_hi - n_lo; k += LR_THREADS) s_w[k] = weights[n_lo + k];
+    // (SiPM stage without truth slots: the weights staged as LIGHT_GAIN[row] * w, the product the reference forms first, :320)
+    const bool premul = RESPONSE && Mt <= 0;
+    for (int k = threadIdx.x; k <= n_hi - n_lo; k += LR_THREADS) s_w[k] = premul ? g * weights[n_lo + k] : weights[n_lo + k];
     __syncthreads();
     // One j loop for the whole wave (a thread's own range [i - C, i] is a predicate): the input tick's sample and bound are
     // broadcast LDS reads, a zero sample or a tick without truth skips the wave as a whole, and when some lane's product can
     // pass the threshold the wave stages the tick's <= 64 truth slots in LDS with one coalesced read -- the walk over them
     // (the bulk of the truth leg: one dependent L2 round trip per slot and pair before) then runs on LDS broadcasts.
+    // The chunk is walked 64 input ticks at a time: lane l fetches sample and bound of tick jb + l once, the loop over the 64 ticks
+    // takes them from there with v_readlane (three LDS reads per term were what the plain convolution ran at: the LDS, shared by
+    // the CU's four SIMDs, was its limit), and which ticks are zero / without truth is two ballots.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = jc; j <= jc + nj - 1; j++) {
-      const float xv = s_x[j - jc];
-      if (!RESPONSE && xv == 0.f) continue;                                     // light_sim.py:166-167
+    for (int jb = jc; jb <= jc + nj - 1; jb += 64) {
+      const int nb64 = min(64, jc + nj - jb);
+      const float x_l = lane < nb64 ? s_x[jb - jc + lane] : 0.f;
+      const double t_l = (Mt > 0 && lane < nb64) ? s_tmax[jb - jc + lane] : -1.0;
+      const unsigned long long m_nz = RESPONSE ? ~0ull : __ballot(x_l != 0.f);
+      const unsigned long long m_truth = __ballot(t_l >= 0.0);
+      unsigned long long todo = (nb64 == 64 ? ~0ull : ((1ull << nb64) - 1ull)) & m_nz;
+      // a block inside every lane's own range [i - C, i] (most blocks) and without truth: the bare convolution, no predicate
+      const int w_i0 = i0 + (wv << 6);
+      const bool inside = w_i0 + 63 < T && jb >= max(w_i0 + 63 - C, 0) && jb + nb64 - 1 <= w_i0;
+      if (inside && !m_truth) {
+        const double* wl = s_w + (i - jb) - n_lo;
+        for (; todo; todo &= todo - 1) {
+          const int t = __ffsll((long long)todo) - 1;
+          const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_l), t));
+          const double w = wl[-t];
+          if (RESPONSE && !premul) acc = (float)((double)acc + g * w * (double)xv);
+          else acc = (float)((double)acc + w * (double)xv);
+        }
+        continue;
+      }
+    for (; todo; todo &= todo - 1) {
+      const int t = __ffsll((long long)todo) - 1;
+      const int j = jb + t;
+      const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_l), t));
       const bool mine = live && j >= my_j0 && j <= i;
       const double w = mine ? s_w[(i - j) - n_lo] : 0.0;
       if (mine) {
-        if (RESPONSE) acc = (float)((double)acc + g * w * (double)xv);          // :320  LIGHT_GAIN[idet] * tick_weight * x
-        else acc = (float)((double)acc + w * (double)xv);                       // :169
+        if (RESPONSE && !premul) acc = (float)((double)acc + g * w * (double)xv);          // :320  LIGHT_GAIN[idet] * tick_weight * x
+        else acc = (float)((double)acc + w * (double)xv);                       // :169 (and :320 with the gain already in w)
       }
-      if (Mt <= 0) continue;
-      const double bound = s_tmax[j - jc];
-      if (bound < 0.0) continue;
+      if (!((m_truth >> t) & 1ull)) continue;
+      const double bound = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t_l), t), __builtin_amdgcn_readlane(__double2loint(t_l), t));
       const bool walk = mine && !(RESPONSE ? (fabs(w) * bound < truth_threshold) : (w >= 0.0 && w * bound < truth_threshold));
       if (!__ballot(walk)) continue;
       const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
       const bool staged = Mt <= 64;
+      // the slots some lane's product can pass on: lane a holds slot a while it stages it, so with the largest weight among the
+      // walking lanes this is one ballot -- the walk visits those slots only, in ascending order, instead of all filled ones
+      unsigned long long cand = ~0ull;
       if (staged) {
         __builtin_amdgcn_wave_barrier();
+        int64_t my_id = -1;
+        double my_ph = 0.0;
         if (lane < Mt) {
-          s_sid[wv][lane] = tid[src + lane];
-          s_sph[wv][lane] = tph[src + lane];
+          my_id = tid[src + lane];
+          my_ph = tph[src + lane];
+          s_sid[wv][lane] = my_id;
+          s_sph[wv][lane] = my_ph;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const unsigned long long empty = __ballot(lane < Mt && my_id == -1);
+        const int nfill = empty ? __ffsll((long long)empty) - 1 : Mt;          // (the walk stops at the first empty slot)
+        const double wmax = wave_max_f64(walk ? fabs(w) : 0.0);
+        if (RESPONSE) cand = __ballot(lane < nfill && !(wmax * fabs(my_ph) < truth_threshold));
+        else if (__ballot(walk && w < 0.0)) cand = nfill >= 64 ? ~0ull : ((1ull << nfill) - 1ull);
+        else cand = __ballot(lane < nfill && !(my_ph >= 0.0 ? wmax * my_ph < truth_threshold : truth_threshold > 0.0));
       }
       if (walk) {
-        for (int a = 0; a < Mt; a++) {
+        for (int a0 = 0; a0 < Mt; a0++) {
+          int a = a0;
+          if (staged) {
+            if (!cand) break;
+            a = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+          }
           const int64_t ida_src = staged ? s_sid[wv][a] : tid[src + a];
           if (ida_src == -1) break;
           const double ph = staged ? s_sph[wv][a] : tph[src + a];
@@ -193,6 +239,7 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
           }
         }
       }
+    }
     }
   }
   if (live) out[(int64_t)d * T + i] = acc;
