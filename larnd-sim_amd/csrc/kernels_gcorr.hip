@@ -66,12 +66,15 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
-  if (GA.flags[pair]) {                             // the monolithic kernel writes this pair, in full
+  // (the flag and the whole GInfo record are requested before the first branch: one round trip to memory instead of two)
+  const int flagged = GA.flags[pair];
+  const GInfo gi = GA.gi[pair];
+  float* out = A.out + pair * (int64_t)A.T;
+  if (flagged) {                                    // the monolithic kernel writes this pair, in full
     if (A.win && !big_list && tid == 0) { A.win[2 * pair] = 0; A.win[2 * pair + 1] = A.T; }
     return;
   }
-  float* out = A.out + pair * (int64_t)A.T;
-  const GInfo* __restrict__ gip = GA.gi + pair;
+  const GInfo* gip = &gi;
   if (gip->status != 1) {                           // (nothing to emit: status 2 pairs are flagged)
     if (!big_list) {
       if (A.win) {

@@ -407,7 +407,14 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
   GInfo* __restrict__ gip = GA.gi + pair;
-  const int status = (A.debug_phases & 0x100) ? 0 : gip->status;
+  // (everything the pair's two records hold is requested before the first branch: one round trip to memory instead of three)
+  const GInfo gi0 = *gip;
+  const PairParams* __restrict__ P = GA.pp + pair;
+  int p_i[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) p_i[k] = ((const int*)P)[k];
+  const double par_l = lane < PP_COUNT ? ((const double*)((const char*)P + 32))[lane] : 0.0;
+  const int status = (A.debug_phases & 0x100) ? 0 : gi0.status;
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
     if (lane == 0 && !list) {
       GA.flags[pair] = status == 2;
@@ -415,11 +422,11 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     }
     return;
   }
-  if (gip->wave_ok != (XYS <= 55 ? 1 : 2) || (GA.dbg & 64)) return;      // the other instantiation's or gtables_kernel's pair
-  const int ncol_g = gip->ncol, NJ_g = gip->NJ, u_min = gip->u_min, NU = gip->NU, ebound = gip->edge_bound, NB = gip->NB;
-  double* __restrict__ rec = GA.rec + gip->off;
-  const PairParams* __restrict__ P = GA.pp + pair;
-  const int NQ = P->NQ, iz_lo = P->iz_lo, iz_hi = P->iz_hi, it0 = P->it0, T = P->T, it_w0 = P->it_w0, it_w1 = P->it_w1;
+  if (gi0.wave_ok != (XYS <= 55 ? 1 : 2) || (GA.dbg & 64)) return;      // the other instantiation's or gtables_kernel's pair
+  const int ncol_g = gi0.ncol, NJ_g = gi0.NJ, u_min = gi0.u_min, NU = gi0.NU, ebound = gi0.edge_bound, NB = gi0.NB;
+  double* __restrict__ rec = GA.rec + gi0.off;
+  // PairParams: status, NQ, iz_lo, iz_hi, it0, T, it_w0, it_w1
+  const int NQ = p_i[1], iz_lo = p_i[2], iz_hi = p_i[3], it0 = p_i[4], T = p_i[5], it_w0 = p_i[6], it_w1 = p_i[7];
   const int NUr = g_nur(NU);
 
   __shared__ double s_par[32];
@@ -428,7 +435,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   __shared__ unsigned char s_invs[ZC];
   __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[G_NUCAP + 1];
 
-  if (lane < PP_COUNT) s_par[lane] = ((const double*)((const char*)P + 32))[lane];
+  if (lane < PP_COUNT) s_par[lane] = par_l;
   wsync();
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
@@ -507,7 +514,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     if (j >= 0) s_dys[posn] = ddy;
     if (jmax >= jmin && lane <= NJ && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
   }
-  if (ncol != ncol_g || NJ != NJ_g || jmin != gip->jmin || ncol + NJ > XYS - 1) bad = true;
+  if (ncol != ncol_g || NJ != NJ_g || jmin != gi0.jmin || ncol + NJ > XYS - 1) bad = true;
 
   // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
   int n_sl, lo_c, NUc, anyinv = 0;
