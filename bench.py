@@ -236,8 +236,8 @@ def main():
                 ch.sum_light(int(b), int(e), op_all)
                 if record:
                     acc["sum_ms"] += ch.light_kernel_ms()["sum_ms"]; acc["sum_n"] += 1
-                if download:
-                    ch.download_light(truth=False)
+                # (the photon sums stay in HBM in the PCIe-inclusive passes too: their consumers -- scintillation, SiPM response,
+                # triggers -- run on the device, in the reference as here; what reaches the host is the digitised trigger windows)
         for i, (b, e) in enumerate(ranges):
             st = ch.run(b, e, want_fractions=bool(a.fractions))
             if record:
@@ -302,10 +302,10 @@ def main():
                                     "h2d_ms": 1e3 * t_up,
                                     "note": "one pass incl. H2D of the 152-byte records and D2H of unique_pix / adc_list / "
                                             "adc_ticks / adc_digit / track_pixel_map / current_fractions"
-                                            + (" / light_sample_inc" if light_on else "")
                                             + " per chunk (records from pageable memory, results into page-locked buffers)"}
         # (a') the same with every chunk's D2H on the copy stream beside the next chunk's kernels (ldsim_chain_download_async)
-        step(False, download="overlapped")   # sizes the second set of output / host buffers
+        for _ in range(2 if len(ranges) == 1 else 1):      # size both alternating sets of output / host buffers
+            step(False, download="overlapped")
         ch.synchronize()
         t1 = time.perf_counter()
         ch.upload(seg, bid)
@@ -373,7 +373,7 @@ def main():
         gform = a.weights_mode == 2
         # csrc/kernels_gcorr.hip (node-separable form) or csrc/kernels_macshift.hip
         mac_name = f"gcorr_kernel<{M}>" if gform else ("mac_shift_kernel" if M == 1 else "mac_shift2_kernel")
-        w_name = f"gtables_wave_kernel<{M}>" if gform else (f"qweights_kernel<{M}>" if a.weights_mode == 1 else f"weights_kernel<{M}>")
+        w_name = f"gtables_wave_kernel<{M}, 55>" if gform else (f"qweights_kernel<{M}>" if a.weights_mode == 1 else f"weights_kernel<{M}>")
         # dominant kernel of the path: the longer of the split path's two kernels, or the monolithic current_kernel
         if not split:
             dom_name, dom_ms = f"current_kernel<{M}>", acc["cur_ms"]
