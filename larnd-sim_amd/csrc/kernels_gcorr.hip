@@ -28,8 +28,9 @@ static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padd
 #define GW 2             //   (the kernel waits on a chain of dependent latencies: DESIGN.md section 4, profiles/r03_occupancy*.log)
 
 // LDS of a pair, carved from the dynamic block by its real dimensions (a typical pair needs 12 KB; sized for the caps it would
-// be 54 KB and two pairs per CU).  Size classes: pairs that fit 16 KB (measured: 10 pairs per CU at 96 VGPRs beat 8 at 128
-// and 12 at 80 with spills, profiles/r03_gcorr_occupancy.log) run 10 per CU, the others in launches of their own (g_lds_class).
+// be 54 KB and two pairs per CU).  Size classes: pairs that fit the first budget run 10 - 12 per CU (measured,
+// profiles/r03_gcorr_occupancy.log: 10 per CU at 96 VGPRs beat 8 at 128; 12 at 80 VGPRs pays once the slot loop's rings are two
+// registers deep instead of four: 7.15 -> 6.65 ms), the others in launches of their own (g_lds_class).
 struct GLds {
   int xs, ys, zs, cellcap, bytes;
   bool z_lds;
@@ -58,7 +59,7 @@ __host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, in
 }
 
 template <int M>
-__global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
+__global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
                                                       int cls) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
@@ -192,8 +193,8 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, 
       // Two LDS words per (group, lane) name the cell: its response row for the B operands, its X column and Y row for the A
       // operand (a padding cell: a listed cell's row, valid memory, and the zero column of X).  A software pipeline over the
       // groups t of a tile pair, one slot per group: the products of group t; the 2 response loads of
-      // group t + GPF into the registers just consumed; the row word of group t + GPF + 2; X and Y of group t + 2; the column word of
-      // group t + 4 (past the last group the indices wrap: valid, unused).  Every load is issued two slots (LDS) or GPF (L2) before
+      // group t + GPF into the registers just consumed; the row word of group t + GPF + 1; X and Y of group t + 1; the column word of
+      // group t + 2 (past the last group the indices wrap: valid, unused).  Every load is issued one slot (LDS) or GPF (L2) before
       // its use, no branch, and sched_barrier keeps the compiler from sinking them back to their uses.  [Prefetching the next tile
       // pair's first groups across the P step changed nothing: the loop runs at the rate the L1 delivers the B operands.]
       const bool run_tiles = wv < n32 && ngrp > 0 && !(A.debug_phases & 0x100000);
@@ -210,8 +211,8 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, 
         const int k0 = kA + 32 * kt;
         const double* rpl = GA.resp_pad + RESP_PAD + k0 + jj;
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        double b0[GPF], b1[GPF], xv[4], yv[4];
-        unsigned lo[4], hi[4];
+        double b0[GPF], b1[GPF], xv[2], yv[2];
+        unsigned lo[2], hi[2];
 #pragma unroll
         for (int u = 0; u < GPF; u++) {
           const double* q = rpl + row_word(u);
@@ -219,29 +220,25 @@ __global__ void __launch_bounds__(GT, 5) gcorr_kernel(GArgs GA, int TT, int b0, 
           b1[u] = q[16];
         }
         lo[0] = row_word(GPF);
-        lo[1] = row_word(GPF + 1);
-#pragma unroll
-        for (int u = 0; u < 4; u++) hi[u] = col_word(u);
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          xv[u] = *(const double*)(xl + (hi[u] & 0xFFFFu));
-          yv[u] = *(const double*)(yl + (hi[u] >> 16));
-        }
+        hi[0] = col_word(0);
+        hi[1] = col_word(1);
+        xv[0] = *(const double*)(xl + (hi[0] & 0xFFFFu));
+        yv[0] = *(const double*)(yl + (hi[0] >> 16));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int g0 = 0; g0 < ngrp; g0 += GPF) {
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
-            const double a = xv[u & 3] * yv[u & 3];
+            const double a = xv[u & 1] * yv[u & 1];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
-            const double* q = rpl + lo[u & 3];
+            const double* q = rpl + lo[u & 1];
             b0[u] = q[0];
             b1[u] = q[16];
-            lo[(u + 2) & 3] = row_word(g0 + u + GPF + 2);
-            xv[(u + 2) & 3] = *(const double*)(xl + (hi[(u + 2) & 3] & 0xFFFFu));
-            yv[(u + 2) & 3] = *(const double*)(yl + (hi[(u + 2) & 3] >> 16));
-            hi[u & 3] = col_word(g0 + u + 4);
+            lo[(u + 1) & 1] = row_word(g0 + u + GPF + 1);
+            xv[(u + 1) & 1] = *(const double*)(xl + (hi[(u + 1) & 1] & 0xFFFFu));
+            yv[(u + 1) & 1] = *(const double*)(yl + (hi[(u + 1) & 1] >> 16));
+            hi[u & 1] = col_word(g0 + u + 2);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -395,9 +392,10 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
   const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
-  // Launches of the correlation by LDS need (g_lds_class): pairs that fit 16 KB run ten to a CU in the launch over all pairs, the
+  // Launches of the correlation by LDS need (g_lds_class): pairs that fit 13 KB (M = 1: 80 VGPRs, six waves per SIMD; M = 2, whose
+  // kernel spills at 80: 16 KB, 96 VGPRs, five) run twelve (ten) to a CU in the launch over all pairs, the
   // rest -- listed here, counted on the host together with the pool size -- five to a CU at 32 KB or two to three at the caps' size.
-  const int b0 = 16384 - ctx->debug_lds_pad_kb * 1024, b1 = 32768, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
+  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = 32768, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
