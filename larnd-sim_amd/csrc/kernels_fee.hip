@@ -195,17 +195,19 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   __shared__ int s_nh, s_trange[2];
 
   const int64_t p0 = F.uoff[u], p1 = F.uoff[u + 1];
-  // slots: pairs whose ring code is valid (key low nibble != 15), at most M (detsim.py:582-607)
-  int n_valid = 0;
+  // slots: pairs whose ring code is valid (key low nibble != 15), at most M (detsim.py:582-607).  Keys are sorted, the
+  // invalid-distance pairs (nibble 15) sit at the end of the group: their count by one pass of parallel loads (a bisection
+  // was four dependent round trips to memory per pixel)
+  __shared__ int s_nvalid;
+  if (tid == 0) s_nvalid = 0;
+  __syncthreads();
   {
-    // keys are sorted, invalid-distance pairs (nibble 15) sit at the end of the group
-    int64_t lo = p0, hi = p1;
-    while (lo < hi) {
-      int64_t mid = (lo + hi) >> 1;
-      if ((F.pair_key[mid] & 15ull) == 15ull) hi = mid; else lo = mid + 1;
-    }
-    n_valid = (int)(lo - p0);
+    int cnt = 0;
+    for (int64_t p = p0 + tid; p < p1; p += FEE_THREADS) cnt += (F.pair_key[p] & 15ull) != 15ull;
+    if (cnt) atomicAdd(&s_nvalid, cnt);
   }
+  __syncthreads();
+  const int n_valid = s_nvalid;
   const int n_slots = n_valid < M ? n_valid : M;
   const bool overflow = (p1 - p0) > n_slots;
   const int ubatch = F.ubatch[u];
