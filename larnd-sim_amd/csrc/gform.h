@@ -38,10 +38,11 @@ struct GInfo {
 //   per node batch b:
 //     cells     2 + padded / 2              int count padded to a multiple of G_CELLPAD with dummies, int count of real cells,
 //                                           two unused, then u32 row | col << 16 | j << 24 per cell
-//     X         16 * ncol                   X[n][col]
-//     Y         16 * NJ                     Y[n][j]
-//     Z         16 * NUr                    Z[n][u]; NUr = NU rounded up to 16
-//     Zi        popcount(edge_bound) * 16 * NUr   per possible window edge: Z over the slices that are invalid at that edge only
+//     X         rows * ncol                 X[n][col]; rows = the batch's nodes rounded up to 4 (16 for all batches but the last:
+//                                           59 % of the survey workload's pairs end in a batch of 1 .. 4 nodes)
+//     Y         rows * NJ                   Y[n][j]
+//     Z         rows * NUr                  Z[n][u]; NUr = NU rounded up to 16
+//     Zi        popcount(edge_bound) * rows * NUr   per possible window edge: Z over the slices that are invalid at that edge only
 //                                           (gcorr_kernel takes their share of the one tick the edge maps to back: one more
 //                                           16-node product against the column G_n[edge_k] it holds anyway)
 __host__ __device__ __forceinline__ int g_nur(int NU) { return (NU + 15) & ~15; }
@@ -49,11 +50,18 @@ __host__ __device__ __forceinline__ int g_popc3(int m) { return (m & 1) + ((m >>
 __host__ __device__ __forceinline__ unsigned long long g_cells_doubles(int ncol, int NJ) {
   return G_CELL0 / 2 + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
 }
-__host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound) {
-  return g_cells_doubles(ncol, NJ) + 16ull * ncol + 16ull * NJ + 16ull * (1 + g_popc3(edge_bound)) * g_nur(NU);
+// node rows batch b of a rule of NQ nodes stores
+__host__ __device__ __forceinline__ int g_rows(int NQ, int b) {
+  const int nb = NQ - G_NODES * b;
+  return nb >= G_NODES ? G_NODES : ((nb + 3) & ~3);
 }
-__host__ __device__ __forceinline__ unsigned long long g_record_doubles(int NB, int ncol, int NJ, int NU, int edge_bound) {
-  return G_HDR / 2 + (unsigned long long)NB * g_batch_doubles(ncol, NJ, NU, edge_bound);
+__host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound, int rows = G_NODES) {
+  return g_cells_doubles(ncol, NJ) + (unsigned long long)rows * (ncol + NJ + (1 + g_popc3(edge_bound)) * g_nur(NU));
+}
+// (batch b starts b full batches into the record: only the last one is short)
+__host__ __device__ __forceinline__ unsigned long long g_record_doubles(int NB, int NQ, int ncol, int NJ, int NU, int edge_bound) {
+  return G_HDR / 2 + (unsigned long long)(NB - 1) * g_batch_doubles(ncol, NJ, NU, edge_bound) +
+         g_batch_doubles(ncol, NJ, NU, edge_bound, g_rows(NQ, NB - 1));
 }
 
 struct GArgs {

@@ -122,9 +122,10 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
     for (int b = 0; b < NB && n32 > 0; b++) {
       const double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
       const int32_t* cells = (const int32_t*)brec;
+      const int rows = g_rows(NQ, b);                // node rows the record keeps of this batch (the rest: zeros)
       const double* gX = brec + cells_d;
-      const double* gY = gX + 16 * ncol;
-      const double* gZ = gY + 16 * NJ;
+      const double* gY = gX + rows * ncol;
+      const double* gZ = gY + rows * NJ;
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
         // tables: thread (row n = tid / 8, lane of 8) copies its row's columns -- no index division; Z two doubles at a time
@@ -132,11 +133,12 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         {
           const int n = tid >> 3, c8 = tid & 7;
           if (!(GA.dbg & 4)) {
-            for (int cc = c8; cc < ncol; cc += 8) s_X[n * xs + cc] = gX[n * ncol + cc];
-            for (int cc = c8; cc < NJ; cc += 8) s_Y[n * ys + cc] = gY[n * NJ + cc];
+            for (int cc = c8; cc < ncol; cc += 8) s_X[n * xs + cc] = n < rows ? gX[n * ncol + cc] : 0.0;
+            for (int cc = c8; cc < NJ; cc += 8) s_Y[n * ys + cc] = n < rows ? gY[n * NJ + cc] : 0.0;
             if (z_lds)
               for (int cc = 2 * c8; cc < NUr; cc += 16) {
-                const double2 v = *(const double2*)(gZ + n * NUr + cc);
+                double2 v = {0.0, 0.0};
+                if (n < rows) v = *(const double2*)(gZ + n * NUr + cc);
                 s_Z[n * zs + cc] = v.x;
                 s_Z[n * zs + cc + 1] = v.y;
               }
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         auto zrow = [&](int st, double* za) {
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
+            za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : (4 * q + kk < rows ? gZ[(4 * q + kk) * NUr + 16 * st + jj] : 0.0);
         };
         for (int st = 0; st < NU16; st++) {
           double za[4];
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             int et = 0;
             for (int e = 0; e < NEDGE; e++) {
               if (!(ebound & (1 << e))) continue;
-              const double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
+              const double* gZi = gZ + (unsigned long long)rows * NUr * (unsigned long long)(1 + et);
               et++;
               const int ke = edge_k[e];
               if (!(emask & (1 << e)) || ke < k0 || ke >= k0 + 32) continue;
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
               for (int u = lane; u < NU; u += 64) {
                 double cv = 0;
 #pragma unroll 1
-                for (int n0 = 0; n0 < G_NODES; n0 += 4) {       // (four loads in flight: more would spill)
+                for (int n0 = 0; n0 < rows; n0 += 4) {          // (four loads in flight: more would spill)
                   double zv[4];
 #pragma unroll
                   for (int n = 0; n < 4; n++) zv[n] = gZi[(n0 + n) * NUr + u];

@@ -236,9 +236,10 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
     int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
     int n_cells_b = 0;
+    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch
     double* gX = brec + cells_d;
-    double* gY = gX + 16 * ncol;
-    double* gZ = gY + 16 * NJ;
+    double* gY = gX + rows * ncol;
+    double* gZ = gY + rows * NJ;
     __syncthreads();          // the previous batch's tables are no longer read
     // ---- X and Y tables of this node batch: one task per (bin, node), node fastest ---------------------------------------------
     {
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
         }
         __syncthreads();
         if (!(GA.dbg & 16))
-          for (int i = tid; i < G_NODES * pw; i += CUR_THREADS) gdst[(i / pw) * NUr + pu0 + i % pw] = s_Z[i / pw][i % pw];
+          for (int i = tid; i < rows * pw; i += CUR_THREADS) gdst[(i / pw) * NUr + pu0 + i % pw] = s_Z[i / pw][i % pw];
         if (e < 0 && tid < G_NODES) {
           double t = pu0 ? s_zs[tid] : 0.0;
           for (int u = 0; u < pw; u++) t += s_Z[tid][u];
@@ -323,8 +324,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
     __syncthreads();
     // ---- tables to the record -----------------------------------------------------------------------------------------------------
     if (!(GA.dbg & 16)) {
-      for (int i = tid; i < G_NODES * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
-      for (int i = tid; i < G_NODES * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
+      for (int i = tid; i < rows * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
+      for (int i = tid; i < rows * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
     }
     // ---- cells that can carry weight: sum over the nodes and all shifts of X Y Z above the pruning threshold (every
     // (cell, shift) bin the weight kernels would keep lies in such a cell); list in (column, j) order ------------------------------------
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
       int et = 0;
       for (int e = 0; e < NEDGE; e++) {
         if (!(ebound & (1 << e)) || (GA.dbg & 32)) continue;
-        double* gZi = gZ + 16ull * NUr * (unsigned long long)(1 + et);
+        double* gZi = gZ + (unsigned long long)rows * NUr * (unsigned long long)(1 + et);
         et++;
         if (!(emask_seen & (1 << e))) continue;      // (gcorr_kernel skips the table)
         ztable(e, gZi);
@@ -634,9 +635,10 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
     int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
+    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch
     double* gX = brec + cells_d;
-    double* gY = gX + 16 * ncol;
-    double* gZ = gY + 16 * NJ;
+    double* gY = gX + rows * ncol;
+    double* gZ = gY + rows * NJ;
     // this lane's four nodes: position along the segment and weight (a node past the batch's last one: rows of zeros)
     double sn[4], wn[4];
 #pragma unroll
@@ -688,7 +690,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
             const int n = 4 * m + q;
             const double v = n < nb ? sum[m] : 0.0;
             s_XY[n][bi] = v;
-            if (!(GA.dbg & 16)) {
+            if (!(GA.dbg & 16) && n < rows) {
               if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
             }
           }
@@ -703,8 +705,8 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         // table nobody reads)
         const int e0 = emask ? __ffs(emask) - 1 : 0, m1 = emask & (emask - 1), e1 = m1 ? __ffs(m1) - 1 : -1;
         const int m2 = m1 & (m1 - 1), e2 = m2 ? __ffs(m2) - 1 : -1;
-        double* gZi0 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e0) - 1)));
-        double* gZi1 = gZ + 16ull * NUr * (unsigned long long)(1 + (e1 >= 0 ? g_popc3(ebound & ((1 << e1) - 1)) : 0));
+        double* gZi0 = gZ + (unsigned long long)rows * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e0) - 1)));
+        double* gZi1 = gZ + (unsigned long long)rows * NUr * (unsigned long long)(1 + (e1 >= 0 ? g_popc3(ebound & ((1 << e1) - 1)) : 0));
         for (int u0 = 0; u0 < NUr; u0 += 16) {
           const int ub = u0 + u16;
           int k = 0, ke = 0;
@@ -732,19 +734,19 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
             const int n = 4 * m + q;
             const double v = 0.0 + wn[m] * z[m];
             zsp[m] += v;
-            if (!(GA.dbg & 16)) gZ[n * NUr + ub] = v;
+            if (!(GA.dbg & 16) && n < rows) gZ[n * NUr + ub] = v;
           }
           if (!(GA.dbg & 48)) {
   #pragma unroll
             for (int m = 0; m < 4; m++) {
-              if (emask) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
-              if (e1 >= 0) gZi1[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[1][m];
+              if (emask && 4 * m < rows) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
+              if (e1 >= 0 && 4 * m < rows) gZi1[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[1][m];
             }
           }
         }
         // a third edge (a response staged down to index 0 and up to the window's end): its table in a pass of its own
         if (e2 >= 0) {
-          double* gZi2 = gZ + 16ull * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e2) - 1)));
+          double* gZi2 = gZ + (unsigned long long)rows * NUr * (unsigned long long)(1 + g_popc3(ebound & ((1 << e2) - 1)));
           for (int u0 = 0; u0 < NUr; u0 += 16) {
             const int ub = u0 + u16;
             int k = 0, ke = 0;
@@ -763,7 +765,8 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
               }
             }
   #pragma unroll
-            for (int m = 0; m < 4; m++) gZi2[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi2[m];
+            for (int m = 0; m < 4; m++)
+              if (4 * m < rows) gZi2[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi2[m];
           }
         }
       }

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
       }
     }
     Gi.edge_bound = eb;
-    Gi.size = g_record_doubles(Gi.NB, Gi.ncol, Gi.NJ, Gi.NU, eb);
+    Gi.size = g_record_doubles(Gi.NB, Gi.NQ, Gi.ncol, Gi.NJ, Gi.NU, eb);
   }
   gi[pair] = Gi;
 }
