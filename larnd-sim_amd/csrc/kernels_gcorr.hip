@@ -166,16 +166,19 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         auto zrow = [&](int st, double* za) {
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : (4 * q + kk < rows ? gZ[(4 * q + kk) * NUr + 16 * st + jj] : 0.0);
+            if (4 * q < rows) za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
         };
+        const int nq4 = rows >> 2;          // node groups of four the batch has (its last batch: often one)
         for (int st = 0; st < NU16; st++) {
           double za[4];
           zrow(st, za);
           d4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g0acc[q], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g1acc[q], p1, 0, 0, 0);
+            if (q < nq4) {
+              p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g0acc[q], p0, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[q], g1acc[q], p1, 0, 0, 0);
+            }
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             if (on && idx1 >= 0 && idx1 < wlen) atomicAdd(&ow[idx1], p1[r]);
           }
         }
-        n_mfma += 8 * NU16;
+        n_mfma += 2 * nq4 * NU16;
       };
       // A wave owns pairs of adjacent 16-tick tiles (the second one may lie past the range: its products meet zeros or ticks
       // outside the window and are dropped): one A operand (X Y of the lane's node and cell) feeds both products.
