@@ -68,10 +68,16 @@ def main():
     path = os.path.join(REPO, "profiles", os.environ.get("LDSIM_TRAFFIC_FILE", "r03_traffic.json"))
     tab = json.load(open(path)) if os.path.exists(path) else {}
     entry = {}
+    # a kernel launched several times per chain launch (gcorr_kernel: once per LDS class) is summed over them: "per launch" means
+    # per chain launch = per dispatch of pixel_adc_kernel, which runs once in each
+    chain_f, chain_w = fetch.get("pixel_adc_kernel", (0.0, 0))[1], write.get("pixel_adc_kernel", (0.0, 0))[1]
     for k in sorted(set(fetch) | set(write)):
         f_kib, nf = fetch.get(k, (0.0, 0))
         w_kib, nw = write.get(k, (0.0, 0))
-        entry[k] = {"bytes_per_launch": 2.0 * f_kib * 1024 + w_kib * 1024, "fetch_size_kib_avg": f_kib, "write_size_kib_avg": w_kib,
+        per_f = nf / chain_f if chain_f and nf > chain_f else 1.0
+        per_w = nw / chain_w if chain_w and nw > chain_w else 1.0
+        entry[k] = {"bytes_per_launch": 2.0 * f_kib * per_f * 1024 + w_kib * per_w * 1024, "fetch_size_kib_avg": f_kib,
+                    "write_size_kib_avg": w_kib, "dispatches_per_chain_launch": per_f,
                     "launches_profiled": [nf, nw],
                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 per the gfx950 correction"}
     tab[config] = entry
