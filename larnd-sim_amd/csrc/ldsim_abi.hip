@@ -48,6 +48,16 @@ int sort_compact_hits(ldsim_ctx*, const int32_t*, const int32_t*, const int32_t*
                       const double*, int, int64_t, int32_t*);
 // chain glue implemented in chain.hip (needs the kernel argument structs)
 int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fractions);
+extern "C++" int fee_clear_unwritten_fractions(ldsim_ctx* ctx, int64_t U, const int32_t* hit_count, const int64_t* tpm, double* fr);
+// the dense fractions array of the current output set, complete (entries the FEE kernel did not write: zero)
+static int fractions_complete(ldsim_ctx* ctx) {
+  if (ctx->frac_clean_gen == ctx->out_gen) return 0;
+  int rc = fee_clear_unwritten_fractions(ctx, ctx->chain_U, (const int32_t*)ctx->scratch[SB_PAIRPIX].p,
+                                         (const int64_t*)ctx->scratch[SB_TPM].p, (double*)ctx->scratch[SB_FRAC].p);
+  if (rc) return rc;
+  ctx->frac_clean_gen = ctx->out_gen;
+  return 0;
+}
 int chain_tracks_current(ldsim_ctx* ctx, const int32_t* d_pixels, int P, float* d_signals, int T, int mc);
 
 // ---- errors ---------------------------------------------------------------------------------------------------
@@ -1216,6 +1226,7 @@ extern "C" int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* u
   if (tpm) HIPCHK(hipMemcpyAsync(tpm, ctx->scratch[SB_TPM].p, (size_t)U * M * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (fractions) {
     NEED(ctx->want_fractions, "fractions were not requested in the last ldsim_charge_chain call");
+    CK(fractions_complete(ctx));
     HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1251,7 +1262,11 @@ extern "C" int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int3
   if (adc_ticks) HIPCHK(hipMemcpyAsync(adc_ticks, ctx->scratch[SB_TICKS].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, cs));
   if (adc_digit) HIPCHK(hipMemcpyAsync(adc_digit, ctx->scratch[SB_DIGIT].p, (size_t)U * A * 8, hipMemcpyDeviceToHost, cs));
   if (tpm) HIPCHK(hipMemcpyAsync(tpm, ctx->scratch[SB_TPM].p, (size_t)U * M * 8, hipMemcpyDeviceToHost, cs));
-  if (fractions) HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, cs));
+  if (fractions) {
+    CK(fractions_complete(ctx));                        // (on the compute stream: drained before the copy stream reads the rows)
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(fractions, ctx->scratch[SB_FRAC].p, (size_t)U * A * M * 8, hipMemcpyDeviceToHost, cs));
+  }
   ctx->copy_pending = 1;
   ctx->pending_gen = ctx->out_gen;
   return 0;

@@ -125,6 +125,7 @@ struct ldsim_ctx {
   std::vector<double> h_resp_kmax;           // largest |entry| of every response tick over all cells (host)
   int debug_phases = 15;
   int debug_lds_pad_kb = 0;                  // timing tools: KB taken off the LDS budget of gcorr_kernel's small class
+  long long frac_clean_gen = -1;             // out_gen of the output set whose dense fractions array has been completed with zeros
   int gform_wave_tables = 1;                 // 1: gtables_wave_kernel (a wave per pair) for the pairs that fit it, 0: gtables_kernel for all
   int debug_gform = 0;                       // timing tools: parts of gtables_kernel / gcorr_kernel switched off (tools/gform_phases.py)
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
