@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
 #pragma unroll
   for (int k = 0; k < 8; k++) p_i[k] = ((const int*)P)[k];
   const double par_l = lane < PP_COUNT ? ((const double*)((const char*)P + 32))[lane] : 0.0;
+  const double e2_l = g_exp2_64[lane];
   const int status = (A.debug_phases & 0x100) ? 0 : gi0.status;
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
     if (lane == 0 && !list) {
@@ -430,13 +431,14 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   const int NQ = p_i[1], iz_lo = p_i[2], iz_hi = p_i[3], it0 = p_i[4], T = p_i[5], it_w0 = p_i[6], it_w1 = p_i[7];
   const int NUr = g_nur(NU);
 
-  __shared__ double s_par[32];
+  __shared__ double s_par[32], s_e2[64];
   __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
   __shared__ double s_XY[G_NODES][XYS], s_zs[G_NODES];
   __shared__ unsigned char s_invs[ZC];
   __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[G_NUCAP + 1];
 
   if (lane < PP_COUNT) s_par[lane] = par_l;
+  s_e2[lane] = e2_l;
   wsync();
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
@@ -679,7 +681,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
             for (int m = 0; m < 4; m++) {
               if (m < MC) {
                 const double d = dd - cen[m];
-                sum[m] += exp_neg_sel(-d * d * i2T);
+                sum[m] += exp_neg_tab(-d * d * i2T, s_e2);
               }
             }
           }
@@ -721,7 +723,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
               for (int m = 0; m < 4; m++) {
                 if (m < MC) {
                   const double d = dd - cen[m];
-                  const double g = exp_neg_sel(-d * d * i2L);
+                  const double g = exp_neg_tab(-d * d * i2L, s_e2);
                   z[m] += g;
                   zi[0][m] += i0 ? g : 0.0;
                   zi[1][m] += i1 ? g : 0.0;
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
                 for (int m = 0; m < 4; m++) {
                   if (m < MC) {
                     const double d = dd - cen[m];
-                    zi2[m] += exp_neg_sel(-d * d * i2L);
+                    zi2[m] += exp_neg_tab(-d * d * i2L, s_e2);
                   }
                 }
               }
