@@ -418,20 +418,21 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipEventRecord(ctx->ev[3], st));
 
   // ---- compact hit rows (payload of the multi-GPU all-gather) -----------------------------------------------------------------------------
+  // (the rows are sized by their bound, U x MAX_ADC_VALUES -- 140 MB per 100 k segments -- so that the hit count comes back with
+  // the launch's last synchronisation instead of one of its own)
   CK(sort_exclusive_scan_i32(ctx, d_hitcnt, d_hitoff, U));
+  CK(ldsim_ensure(ctx, SB_HITS, (size_t)U * A * 24 + 24));
+  CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
+                       (int32_t*)ctx->scratch[SB_HITS].p));
   unsigned long long h_cnt[16], h_raw[STAT_WORDS];
   HIPCHK(hipMemcpyAsync(h_raw, counters, STAT_BYTES, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
   HIPCHK(hipStreamSynchronize(st));
   stat_sum(h_raw, h_cnt);
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
   stats_from_counters(ctx->stats, h_cnt);
   ctx->n_fallback = (int64_t)h_cnt[6];
-  CK(ldsim_ensure(ctx, SB_HITS, (size_t)ctx->chain_hits * 24 + 24));
-  CK(sort_compact_hits(ctx, d_upix, d_ubatch, d_hitcnt, d_hitoff, F.adc_digit, F.adc_ticks, A, U,
-                       (int32_t*)ctx->scratch[SB_HITS].p));
-  HIPCHK(hipEventRecord(ctx->ev[4], st));
-  HIPCHK(hipStreamSynchronize(st));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->ms_current = ms;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->ms_adc = ms;
