@@ -389,6 +389,45 @@ __global__ void light_replay_kernel(const unsigned long long* __restrict__ keys,
 }
 
 
+// The cells the last truth-slot photon sum wrote (the heads of its sorted records, still in light_tmp[4]) back to their initial
+// values: the next sum on the same buffers starts from arrays that are clean everywhere else (ldsim_dev_sum_light) -- at 50 truth
+// slots and 50 000 ticks clearing 15 GB per batch was half the photon sum's time, the cells written are 3 % of them.
+__global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned long long* __restrict__ keys, int64_t n_rec,
+                                                               int64_t n_ticks, int max_truth, float* __restrict__ out,
+                                                               int64_t* __restrict__ true_id, double* __restrict__ true_ph) {
+  // a workgroup per 256 records: the heads among them (first record of a cell) are collected, then each wave clears whole cells,
+  // lane k slot k
+  __shared__ unsigned s_cell[256];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int SH = LK_RANK_BITS + LK_IP_BITS;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  unsigned cell = 0;
+  bool head = false;
+  if (i < n_rec) {
+    cell = (unsigned)(keys[i] >> SH);
+    head = i == 0 || (unsigned)(keys[i - 1] >> SH) != cell;
+  }
+  const unsigned long long m = __ballot(head);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (head) s_cell[base + __popcll(m & ((1ull << lane) - 1ull))] = cell;
+  __syncthreads();
+  const int nh = s_n;
+  for (int h = wv; h < nh; h += 4) {
+    const unsigned c = s_cell[h];
+    const int64_t o = (int64_t)(c >> LK_TICK_BITS) * n_ticks + (int64_t)(c & ((1u << LK_TICK_BITS) - 1));
+    if (lane == 0) out[o] = 0.f;
+    for (int k = lane; k < max_truth; k += 64) {
+      true_id[o * max_truth + k] = -1;
+      true_ph[o * max_truth + k] = 0.0;
+    }
+  }
+}
+
 // The same replay with a wave per block of RW_BLOCK sorted records (max_truth <= 64): the wave owns the (detector, tick) cells
 // whose first record lies in its block and walks each to its end.  The records are fetched 64 at a time, one per lane (key,
 // photons and track id: three dependent loads, but 64 in flight), and replayed in order from registers; lane k keeps truth
@@ -470,6 +509,14 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
 }
 
 extern "C++" {
+int light_launch_reset_cells(ldsim_ctx* ctx, int64_t n_rec, int64_t n_ticks, int max_truth, float* out, int64_t* true_id,
+                              double* true_ph) {
+  if (n_rec <= 0) return 0;
+  hipLaunchKernelGGL(light_reset_cells_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const unsigned long long*)ctx->light_tmp[4].p, n_rec, n_ticks, max_truth, out, true_id, true_ph);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
@@ -512,7 +559,9 @@ int light_launch_t0_range(ldsim_ctx* ctx, const float* nph, const float* t0det, 
 // [n_det][n]) = the caller's visiting order, or NULL = descending photons per detector.  Uses ctx->light_tmp[].
 int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* voxel, const int64_t* track_id,
                      const float* nph, int n_inc, const int32_t* op_channel, int n_det, const int32_t* sorted_idx,
-                     double start_time, int64_t n_ticks, float* out, int64_t* true_id, double* true_ph, int max_truth) {
+                     double start_time, int64_t n_ticks, float* out, int64_t* true_id, double* true_ph, int max_truth,
+                     int64_t* n_rec_out /* truth path: records left sorted in light_tmp[4] (their cells are what was written) */) {
+  if (n_rec_out) *n_rec_out = 0;
   if (n_det == 0 || n_ticks == 0 || n == 0) return 0;
   LightSum L;
   L.s = ctx->seg; L.c = ctx->d_consts; L.seg0 = seg0; L.n = n; L.voxel = voxel; L.nph = nph; L.n_inc = n_inc;
@@ -568,6 +617,7 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   HIPCHK(hipStreamSynchronize(st));
   const int64_t n_rec = (int64_t)last_off + last_cnt;
   if (n_rec == 0) return 0;
+  if (n_rec_out) *n_rec_out = n_rec;
   if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)n_rec * 8))) return rc;
   if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)n_rec * 8))) return rc;
   if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)n_rec * 4))) return rc;

@@ -35,7 +35,8 @@ int fee_launch_digitize(ldsim_ctx*, const double*, const double*, double*, int64
 int light_launch_incidence(ldsim_ctx*, int64_t, int64_t, int, float*, float*, int32_t*, int);
 int light_launch_t0_range(ldsim_ctx*, const float*, const float*, int64_t, int*);
 int light_launch_sum(ldsim_ctx*, int64_t, int64_t, const int32_t*, const int64_t*, const float*, int, const int32_t*, int,
-                     const int32_t*, double, int64_t, float*, int64_t*, double*, int);
+                     const int32_t*, double, int64_t, float*, int64_t*, double*, int, int64_t*);
+int light_launch_reset_cells(ldsim_ctx*, int64_t, int64_t, int, float*, int64_t*, double*);
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
@@ -822,7 +823,8 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
   }
   CK(light_launch_sum(ctx, 0, n, dv.as<int32_t>(), dti.as<int64_t>(), dn.as<float>(), n_inc, dop.as<int32_t>(), n_det,
                       dsi.as<int32_t>(), start_time, n_ticks, dout.as<float>(), dtid.as<int64_t>(), dtph.as<double>(),
-                      max_truth));
+                      max_truth, nullptr));
+  ctx->light_lazy_valid = 0;          // (light_tmp[] no longer holds the resident sum's records)
   HIPCHK(hipMemcpyAsync(out, dout.p, bo * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (max_truth) {
     HIPCHK(hipMemcpyAsync(true_id, dtid.p, bo * max_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -928,22 +930,48 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
   CK(ldsim_ensure_buf(ctx, &ctx->light_opc, (size_t)n_det * 4));
   HIPCHK(hipMemcpyAsync(ctx->light_opc.p, op_channel, (size_t)n_det * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->evl[2], st));
-  HIPCHK(hipMemsetAsync(ctx->light_out.p, 0, bo * 4, st));
   if (max_truth) {
     CK(ldsim_ensure_buf(ctx, &ctx->light_tid, bo * max_truth * 8 + 16));
     CK(ldsim_ensure_buf(ctx, &ctx->light_tph, bo * max_truth * 8 + 16));
     CK(ldsim_ensure_buf(ctx, &ctx->light_trk, (size_t)(n > 0 ? n : 1) * 8));
-    HIPCHK(hipMemsetAsync(ctx->light_tid.p, 0xFF, bo * max_truth * 8, st));     // -1
-    HIPCHK(hipMemsetAsync(ctx->light_tph.p, 0, bo * max_truth * 8, st));
-    if (n) {
-      NEED(segment_track_id, "segment_track_id is needed for the truth slots");
-      HIPCHK(hipMemcpyAsync(ctx->light_trk.p, segment_track_id, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    }
   }
+  // The arrays start at 0 / -1.  After a truth-slot sum they differ from that only in the cells its records fell into (their sorted
+  // keys are still in light_tmp[4]): when the same buffers are large enough for this batch those cells are reset instead of clearing
+  // everything -- [n_det][n_ticks][50] i8 + f8 is 15 GB at 50 000 ticks, the cells written a few per cent of it.
+  const bool lazy = max_truth > 0 && ctx->light_lazy_valid && ctx->light_lazy_mt == max_truth && ctx->light_lazy_out == ctx->light_out.p &&
+                    ctx->light_lazy_tid == ctx->light_tid.p && ctx->light_lazy_tph == ctx->light_tph.p &&
+                    ctx->light_lazy_cap[0] == ctx->light_out.bytes && ctx->light_lazy_cap[1] == ctx->light_tid.bytes &&
+                    ctx->light_lazy_cap[2] == ctx->light_tph.bytes &&      // (a buffer that grew was reallocated: contents undefined)
+                    ctx->light_clean_cells >= bo;
+  if (lazy) {
+    CK(light_launch_reset_cells(ctx, ctx->light_lazy_nrec, ctx->light_lazy_nticks, max_truth, (float*)ctx->light_out.p,
+                                (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p));
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->light_out.p, 0, bo * 4, st));
+    if (max_truth) {
+      HIPCHK(hipMemsetAsync(ctx->light_tid.p, 0xFF, bo * max_truth * 8, st));     // -1
+      HIPCHK(hipMemsetAsync(ctx->light_tph.p, 0, bo * max_truth * 8, st));
+    }
+    ctx->light_clean_cells = bo;
+  }
+  ctx->light_lazy_valid = 0;
+  if (max_truth && n) {
+    NEED(segment_track_id, "segment_track_id is needed for the truth slots");
+    HIPCHK(hipMemcpyAsync(ctx->light_trk.p, segment_track_id, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  }
+  int64_t n_rec = 0;
   CK(light_launch_sum(ctx, seg_begin, n, (const int32_t*)ctx->light_vox.p + seg_begin * 3, (const int64_t*)ctx->light_trk.p,
                       (const float*)ctx->light_nph.p + (size_t)seg_begin * ctx->light_n_out, ctx->light_n_out,
                       (const int32_t*)ctx->light_opc.p, n_det, nullptr, start_time, n_ticks, (float*)ctx->light_out.p,
-                      (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p, max_truth));
+                      (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p, max_truth, &n_rec));
+  if (max_truth) {                       // what the next call has to undo
+    ctx->light_lazy_valid = 1;
+    ctx->light_lazy_mt = max_truth;
+    ctx->light_lazy_nrec = n_rec;
+    ctx->light_lazy_nticks = n_ticks;
+    ctx->light_lazy_out = ctx->light_out.p; ctx->light_lazy_tid = ctx->light_tid.p; ctx->light_lazy_tph = ctx->light_tph.p;
+    ctx->light_lazy_cap[0] = ctx->light_out.bytes; ctx->light_lazy_cap[1] = ctx->light_tid.bytes; ctx->light_lazy_cap[2] = ctx->light_tph.bytes;
+  }
   HIPCHK(hipEventRecord(ctx->evl[3], st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0;

@@ -155,6 +155,12 @@ struct ldsim_ctx {
   DevBuf light_out, light_tid, light_tph, light_opc, light_trk;   // last photon sum: [n_det][n_ticks] f32, truth ids / photons
   int32_t light_sum_ndet = 0, light_sum_nticks = 0, light_sum_truth = 0;
   DevBuf light_tmp[9];
+  // lazy clear of the resident photon-sum arrays (ldsim_dev_sum_light): valid = the arrays are clean over `light_clean_cells`
+  // (detector, tick) cells except where the records still sorted in light_tmp[4] fell
+  int light_lazy_valid = 0, light_lazy_mt = 0;
+  long long light_lazy_nrec = 0, light_lazy_nticks = 0;
+  size_t light_clean_cells = 0, light_lazy_cap[3] = {0, 0, 0};
+  void *light_lazy_out = nullptr, *light_lazy_tid = nullptr, *light_lazy_tph = nullptr;
   // resident waveform stages on the last photon sum (ldsim_dev_light_response): scintillation profile (+ truth), Poisson
   // fluctuated rate, detector response (+ truth), all [light_sum_ndet][light_sum_nticks]
   DevBuf light_scint, light_scint_tid, light_scint_tph, light_disc, light_resp, light_resp_tid, light_resp_tph, light_w[2],
