@@ -1031,6 +1031,38 @@ def test_resident_light_leg_golden(cfg):
     np.testing.assert_allclose(out3, ref, rtol=1e-5, atol=0)
 
 
+@pytest.mark.gpu
+def test_resident_photon_sums_in_a_row_start_from_clean_arrays():
+    """ldsim_dev_sum_light with truth slots does not clear its arrays when the same buffers served the sum before: it resets the
+    cells that sum wrote.  Sums of different batches, tick counts and slot counts in a row on one context must equal the same sums
+    each taken right after a sum without truth slots (which makes the next one clear everything): bit for bit."""
+    cfg = "2x2_no_modvar" if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "light_2x2_no_modvar.npz")) else "module0"
+    H.load_cfg(cfg)
+    g = H.gold(f"light_{cfg}.npz")
+    r = H.quench_drift(O, g["segments_in"])
+    n = len(r)
+    lut = synth.make_lut((14, 26, 8), 48, int(g["n_prof"]), int(g["lut_seed"]))
+    opc = g["op_channel"]
+    nt = int(g["n_ticks"])
+    ch = ChargeChain()
+    ch.upload(r, np.zeros(n, dtype=np.int32))
+    ch.light_incidence(lut)
+    ids = np.arange(n, dtype='i8')
+    # (first, last, truth slots, ticks): overlapping and disjoint segment ranges, a shorter tick axis, another slot count
+    calls = [(0, n, 4, nt), (0, n // 2, 4, nt), (n // 3, n, 4, max(nt // 2, 64)), (0, n, 4, nt), (0, n, 2, nt), (n // 2, n, 2, nt)]
+
+    def one(b, e, mt, ticks):
+        ch.sum_light(b, e, opc, ids[b:e], max_truth=mt, max_ticks=ticks)
+        return ch.download_light()
+
+    got = [one(*c) for c in calls]                       # in a row: every sum after the first may take the lazy path
+    for c, (out, tid, tph) in zip(calls, got):
+        ch.sum_light(0, n, opc, max_truth=0, max_ticks=nt)          # no truth slots: invalidates the lazy state
+        ref_out, ref_tid, ref_tph = one(*c)
+        assert np.array_equal(out, ref_out) and np.array_equal(tid, ref_tid) and np.array_equal(tph, ref_tph), c
+    assert any((t[1] != -1).any() for t in got)
+
+
 def _lsb_mismatch(got, ref, lsb):
     """fraction of values that differ, and whether every difference is exactly one digitiser LSB"""
     d = np.abs(np.asarray(got) - np.asarray(ref))
