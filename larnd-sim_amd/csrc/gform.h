@@ -27,8 +27,8 @@ struct GInfo {
   int32_t ncol, NJ, jmin, u_min, NU, edge_bound, NB, status;   // edge_bound: superset of the edges that need a Z table
   int32_t NQ, it0, T, it_w0, it_w1;                             // copies of the PairParams fields gcorr_kernel needs
   int32_t emask;                                                // written by gtables_kernel: the edges some slice is invalid at
-  int32_t wave_ok;                                              // gtables_wave_kernel takes the pair (one chunk of slices, <= 128 shifts): 1 = X | Y bins <= 54,
-                                                                // 2 = <= 80 (its wide instantiation, over a list); 0 = gtables_kernel
+  int32_t wave_ok;                                              // gtables_wave_kernel takes the pair (one chunk of slices): 1 = <= 128 shifts, X | Y bins <= 54,
+                                                                // 2 = <= 256 / <= 80 (its wide instantiation, over a list); 0 = gtables_kernel
   int32_t pad;
   unsigned long long off;                                       // record offset in doubles (exclusive scan of `size`)
   unsigned long long size;                                      // record size in doubles

@@ -425,11 +425,11 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
       n1++;
       nb2 += g.NB > 1;
       if (g.wave_ok) continue;
-      if (g.NU > G_NUCAP) nu++;
+      if (g.NU > 2 * G_NUCAP) nu++;
       else if (g.ncol + g.NJ > 80) xy++;
       else sl++;
     }
-    fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 128: %ld, X | Y bins > 80: %ld, "
+    fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 256: %ld, X | Y bins > 80: %ld, "
             "slices > 64: %ld), wide wave tables kernel %llu, correlation launches at 32 KB / %d KB of LDS: %llu / %llu pairs, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl,
             n_w2, b2 >> 10, n_cls[1], n_cls[2], total * 8e-9);
   }

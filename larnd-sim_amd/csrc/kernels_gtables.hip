@@ -396,14 +396,15 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 // carrying nodes q, 4 + q, 8 + q, 12 + q of its bin -- so a bin's member loop is shared by four nodes, the invalid-slice tables
 // of the window edges accumulate in the same pass as Z from the same Gaussians, and no index needs a division.
 // Entry for entry the same expressions and term order as gtables_kernel (the cell test sums the Z totals in another order).
-// XYS = row stride of the joint X | Y table: 55 (ncol + NJ <= 54, 9.7 KB of LDS, 16 pairs per CU) for the launch over all pairs,
-// 81 (<= 80, 13 KB, 12 per CU, no register spill at 3 waves per SIMD) over the list of the pairs that need it (wide diffusion:
-// a sixth of the ndlar pairs)
+// XYS = row stride of the joint X | Y table: 55 (ncol + NJ <= 54, <= 128 shifts, 10 KB of LDS, 16 pairs per CU) for the launch over
+// all pairs, 81 (<= 80, <= 256 shifts, 13 KB, 12 per CU, no register spill at 3 waves per SIMD) over the list of the pairs that need
+// it (wide diffusion or steep segments: a fifth of the ndlar pairs)
 
 template <int M, int XYS>
 __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list) {
   const CurArgs& A = GA.c;
   const LdsimConsts* c = A.c;
+  constexpr int NUW = XYS <= 55 ? G_NUCAP : 2 * G_NUCAP;       // shifts of a pair this instantiation takes
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
   const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
   __shared__ double s_XY[G_NODES][XYS], s_zs[G_NODES];
   __shared__ unsigned char s_invs[ZC];
-  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[G_NUCAP + 1];
+  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[NUW + 1];
 
   if (lane < PP_COUNT) s_par[lane] = par_l;
   s_e2[lane] = e2_l;
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     n_sl = nmax;
     lo_c = lo;
     NUc = hi - lo + 1;
-    if (nmax != iz_hi - iz_lo + 1 || NUc > G_NUCAP || NUc != NU || lo != u_min) bad = true;
+    if (nmax != iz_hi - iz_lo + 1 || NUc > NUW || NUc != NU || lo != u_min) bad = true;
     if (!bad) {
       const bool in = lane < nmax;
       const unsigned long long lane_lt = (1ull << lane) - 1ull, lane_le = lane_lt | (1ull << lane);
@@ -566,8 +567,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         const int run_end = above ? __ffsll((long long)above) - 1 : nmax;
         posn = down ? (nmax - run_end) + (lane - run_first) : lane;
         // bin starts: a run's first position at its shift, empty bins take the next start (a suffix minimum, 64 bins at a time)
-        s_ustart[lane] = -1;
-        s_ustart[lane + 64] = -1;
+        for (int k = lane; k <= NUc; k += 64) s_ustart[k] = -1;
         wsync();
         if (in && lane == run_first) s_ustart[sh - lo] = (short)posn;
         wsync();
@@ -585,17 +585,21 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         }
         if (lane == 0) s_ustart[NUc] = (short)nmax;
       } else {
-        int below = 0, below2 = 0;
+        int below[NUW / 64];
+#pragma unroll
+        for (int k = 0; k < NUW / 64; k++) below[k] = 0;
         for (int bs = lo; bs <= hi; bs++) {                    // the distinct shifts, one ballot each
           const unsigned long long bal = __ballot(in && sh == bs);
           const int cnt = __popcll(bal);
           if (in && sh > bs) posn += cnt;
           if (in && sh == bs) posn += __popcll(bal & lane_lt);
-          if (bs < lo + lane) below += cnt;
-          if (bs < lo + lane + 64) below2 += cnt;
+#pragma unroll
+          for (int k = 0; k < NUW / 64; k++)
+            if (bs < lo + lane + 64 * k) below[k] += cnt;
         }
-        if (lane < NUc) s_ustart[lane] = (short)below;
-        if (lane + 64 < NUc) s_ustart[lane + 64] = (short)below2;
+#pragma unroll
+        for (int k = 0; k < NUW / 64; k++)
+          if (lane + 64 * k < NUc) s_ustart[lane + 64 * k] = (short)below[k];
         if (lane == 0) s_ustart[NUc] = (short)nmax;
       }
       if (in) {

@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   Gi.NB = (P.NQ + G_NODES - 1) / G_NODES;
   Gi.status = P.status;
   Gi.NQ = P.NQ; Gi.it0 = it0; Gi.T = T; Gi.it_w0 = it_w0; Gi.it_w1 = it_w1;
-  Gi.wave_ok = (iz_hi - iz_lo + 1 <= ZC && Gi.NU <= G_NUCAP) ? (Gi.ncol + Gi.NJ <= 54 ? 1 : (Gi.ncol + Gi.NJ <= 80 ? 2 : 0)) : 0;
+  Gi.wave_ok = 0;
+  if (iz_hi - iz_lo + 1 <= ZC) {
+    if (Gi.NU <= G_NUCAP && Gi.ncol + Gi.NJ <= 54) Gi.wave_ok = 1;
+    else if (Gi.NU <= 2 * G_NUCAP && Gi.ncol + Gi.NJ <= 80) Gi.wave_ok = 2;
+  }
   if (P.status == 1 && (Gi.ncol > G_NCOL || Gi.NJ > NJ_MAX || Gi.ncol * Gi.NJ > G_CELLCAP - G_CELLPAD)) {
     Gi.status = 2;
     pp[pair].status = 2;
