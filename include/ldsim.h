@@ -148,6 +148,9 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows
  * staged in LDS; bit-identical results), "light_incidence_scalar" (1 = calculate_light_incidence with one channel per lane
  * instead of four (the form used when n_out or the LUT's detector count is not a multiple of 4); identical bits; default 0),
+ * "light_sum_no_list" (1 = ldsim_dev_sum_light without truth slots launches a workgroup per (detector, tick tile) and clears
+ * the whole array first, instead of summing over the device-built list of the lit tiles; same cells, values to the order of
+ * the f64 additions; default 0),
  * "numba_f32" (1 = the sub-expressions Numba types float32 for f4 record fields are evaluated in float, detsim.py:74-79,
  * 116-118,141,387; 0 = all-f64, what the reference computes for f8 records and what the goldens pin; default 0),
  * "mc_current" (1 = the fused chain takes its induced currents from tracks_current_mc like the reference driver does;
@@ -398,7 +401,11 @@ int ldsim_dev_light_t0_range(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end,
  * light_sample_inc [n_det][n_ticks] f4 and, with max_truth = MAX_MC_TRUTH_IDS > 0, the truth slots [n_det][n_ticks][max_truth]
  * (i8 ids from segment_track_id[seg_end - seg_begin], f8 photons) are initialised (0 / -1) and filled in HBM.  Segments are
  * visited per detector in descending n_photons_det like the driver's argsort (cli/simulate_pixels.py:1141-1144; equal
- * values, which numpy's unstable sort leaves unpinned, by descending index). */
+ * values, which numpy's unstable sort leaves unpinned, by descending index).
+ * Without truth slots (max_truth = 0) the call returns with its kernels in flight on the ctx's stream (every consumer --
+ * ldsim_dev_light_download, ldsim_dev_light_response, ldsim_light_kernel_ms -- is ordered after them); the array is brought back to
+ * zero by clearing the tick tiles the previous such sum lit when the same buffer serves again (a batch lights its own TPCs' rows
+ * only), and op_channel is checked and sent again only when it differs from the last call's. */
 int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, const int32_t* op_channel, int32_t n_det,
                         const int64_t* segment_track_id, int32_t max_truth, double start_time, int32_t n_ticks);
 /* results of the last ldsim_dev_sum_light to host; any pointer may be NULL */

@@ -235,7 +235,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
     int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
-    int n_cells_b = 0;
     const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch
     double* gX = brec + cells_d;
     double* gY = gX + rows * ncol;
@@ -365,7 +364,6 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
         cells[G_CELL0 + base + tid] = (int)(0x80000000u | (unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) | (c0 << 16) | (j0 << 24));
       }
       if (tid == 0) { cells[0] = padded; cells[1] = base; }
-      n_cells_b = base;
     }
     // ---- window edges some slice of the pair is invalid at (detsim.py:418-428): the correlation uses every slice's weight at
     // every tick; the Z table over the invalid slices alone (the same table code) lets gcorr_kernel take their share of the one
@@ -521,7 +519,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   if (ncol != ncol_g || NJ != NJ_g || jmin != gi0.jmin || ncol + NJ > XYS - 1) bad = true;
 
   // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
-  int n_sl, lo_c, NUc, anyinv = 0;
+  int NUc, anyinv = 0;
   {
     const int nmax = min(ZC, iz_hi - iz_lo + 1);
     int sh = 0, inval = 0;
@@ -548,8 +546,6 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
       }
     }
     const int lo = wave_min_i32(lane < nmax ? sh : (1 << 30)), hi = wave_max_i32(lane < nmax ? sh : -(1 << 30));
-    n_sl = nmax;
-    lo_c = lo;
     NUc = hi - lo + 1;
     if (nmax != iz_hi - iz_lo + 1 || NUc > NUW || NUc != NU || lo != u_min) bad = true;
     if (!bad) {

@@ -235,10 +235,8 @@ struct LightSum {
 // f(tick, profile bin, photons).  The tick is the one whose open window (start, end) holds the arrival time, tested
 // with the reference's own expressions on the three candidates around floor((t - start) / tick) (light_sim.py:81-82,100,117)
 template <class F>
-__device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int idet, F f) {
+__device__ __forceinline__ void light_deposits_ph(const LightSum& L, int64_t r, int opch, float ph, F f) {
   const LdsimConsts* c = L.c;
-  const int opch = L.op_channel[idet];
-  const float ph = L.nph[r * L.n_inc + opch];
   if (!(ph > 0)) return;
   const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
   const double track_time = L.s.f[LDSIM_T0][L.seg0 + r];
@@ -267,11 +265,16 @@ __device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int
     at(track_time + (double)L.t0_avg[lb] * ns / mus, 0, (double)ph / tick);
   }
 }
+template <class F>
+__device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int idet, F f) {
+  const int opch = L.op_channel[idet];
+  light_deposits_ph(L, r, opch, L.nph[r * L.n_inc + opch], f);
+}
 
 // ---- without truth slots: scatter into an LDS tick tile ------------------------------------------------------------------
 // The accumulation order differs from the reference's sorted loop (f64 tile, one f4 rounding at the end), so the f4
 // result can differ from the reference's in the last bits.
-#define LTILE 8192
+#define LTILE LIGHT_TILE
 __global__ void __launch_bounds__(256) sum_light_scatter_kernel(LightSum L, float* __restrict__ out) {
   __shared__ double acc[LTILE];
   const int idet = blockIdx.x;
@@ -293,6 +296,88 @@ __global__ void __launch_bounds__(256) sum_light_scatter_kernel(LightSum L, floa
     const int64_t o = (int64_t)idet * L.n_ticks + tile0 + i;
     if (acc[i] != 0.0) out[o] = (float)((double)out[o] + acc[i]);
   }
+}
+
+// ---- the same sum over a list of the (detector, tick tile) cells that receive light -----------------------------------------------------
+// A batch of the driver's loop lights the channels of its own TPCs only (ndlar: 96 of 3360 rows), and the dense
+// [n_det][n_ticks] array is 148 MB there: a grid over every (detector, tile) and a memset of the whole array per batch cost
+// 50 us of which 2 are work.  light_active_kernel marks the tiles some deposit falls into (reads of the incidence rows
+// coalesced along the channels, 16 segments in flight per lane) and appends each newly marked one to a list;
+// sum_light_list_kernel is sum_light_scatter_kernel over that list (same accumulation: f64 LDS tile, one f4 rounding);
+// light_clear_list_kernel zeroes the listed tiles again before the next batch's sum (ldsim_dev_sum_light).
+#define LACT_SEGS 16
+__device__ __forceinline__ void light_clear_entries(const unsigned* __restrict__ count, const int32_t* __restrict__ list, int ntile,
+                                                    int64_t n_ticks, float* __restrict__ out, unsigned long long* __restrict__ dmask,
+                                                    int first, int stride) {
+  const int cnt = (int)*count;
+  for (int e = first; e < cnt; e += stride) {
+    const int code = list[e];
+    const int idet = code / ntile;
+    const int64_t tile0 = (int64_t)(code - idet * ntile) * LTILE;
+    const int tlen = (int)min((int64_t)LTILE, n_ticks - tile0);
+    float* o = out + (int64_t)idet * n_ticks + tile0;
+    for (int i = threadIdx.x; i < tlen; i += 256) o[i] = 0.f;
+    if (threadIdx.x == 0) dmask[idet] = 0ull;
+  }
+}
+
+// rows blockIdx.y < ny_active: 64 detectors x 4 x LACT_SEGS segments per block, the tiles their deposits fall into marked and
+// listed; the rows past them: the previous sum's listed tiles back to zero (they touch the array and the other half of the
+// buffer only)
+__global__ void __launch_bounds__(256) light_active_kernel(LightSum L, LightAct A, int ny_active, float* __restrict__ out) {
+  if ((int)blockIdx.y >= ny_active) {
+    if (A.clear)
+      light_clear_entries(A.p_count, A.p_list, A.p_ntile, A.p_nticks, out, A.p_dmask,
+                          ((int)blockIdx.y - ny_active) * (int)gridDim.x + (int)blockIdx.x, ((int)gridDim.y - ny_active) * (int)gridDim.x);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idet = blockIdx.x * 64 + lane;
+  const int64_t r0 = ((int64_t)blockIdx.y * 4 + wv) * LACT_SEGS;
+  if (idet >= L.n_det || r0 >= L.n) return;
+  const int opch = L.op_channel[idet];
+  float ph[LACT_SEGS];
+#pragma unroll
+  for (int k = 0; k < LACT_SEGS; k++) ph[k] = (r0 + k < L.n) ? L.nph[(r0 + k) * L.n_inc + opch] : 0.f;
+  unsigned long long mask = 0;
+#pragma unroll
+  for (int k = 0; k < LACT_SEGS; k++)
+    light_deposits_ph(L, r0 + k, opch, ph[k], [&](int64_t it, int, double photons) {
+      if (photons != 0.0) mask |= 1ull << (int)(it / LTILE);
+    });
+  if (!mask) return;
+  const unsigned long long old = atomicOr(&A.dmask[idet], mask);
+  for (unsigned long long nb = mask & ~old; nb; nb &= nb - 1)
+    A.list[atomicAdd(A.count, 1u)] = idet * A.ntile + (__ffsll((long long)nb) - 1);
+}
+
+__global__ void __launch_bounds__(256) sum_light_list_kernel(LightSum L, LightAct A, float* __restrict__ out) {
+  __shared__ double acc[LTILE];
+  if (A.clear && blockIdx.x == 0 && threadIdx.x == 0) *A.p_count = 0u;      // (light_active_kernel's clearing rows are done with it)
+  const int cnt = (int)*A.count, ntile = A.ntile;
+  for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+    const int code = A.list[e];
+    const int idet = code / ntile;
+    const int64_t tile0 = (int64_t)(code - idet * ntile) * LTILE;
+    const int tlen = (int)min((int64_t)LTILE, L.n_ticks - tile0);
+    for (int i = threadIdx.x; i < tlen; i += 256) acc[i] = 0;
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < L.n; r += 256)
+      light_deposits(L, r, idet, [&](int64_t it, int, double photons) {
+        if (it >= tile0 && it < tile0 + tlen && photons != 0.0) atomicAdd(&acc[it - tile0], photons);
+      });
+    __syncthreads();
+    for (int i = threadIdx.x; i < tlen; i += 256) {
+      const int64_t o = (int64_t)idet * L.n_ticks + tile0 + i;
+      if (acc[i] != 0.0) out[o] = (float)((double)out[o] + acc[i]);
+    }
+    __syncthreads();
+  }
+}
+
+// the same clearing on its own (a sum over an empty range launches nothing else)
+__global__ void __launch_bounds__(256) light_clear_list_kernel(LightAct A, float* __restrict__ out) {
+  light_clear_entries(A.p_count, A.p_list, A.p_ntile, A.p_nticks, out, A.p_dmask, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- with truth slots: records sorted into the reference's visiting order --------------------------------------------------------
@@ -450,7 +535,6 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, l);
   };
   bool open = false;                 // a cell of this wave is being replayed
-  unsigned cur_cell = 0;
   int64_t o = 0;
   float acc = 0.f;
   int64_t slot_id = -1;              // lane k: truth slot k of the open cell
@@ -485,7 +569,6 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
         if (open) { close_cell(); open = false; }
         if (c0 + t >= b1) { done = true; break; }          // the next block's cell
         open = true;
-        cur_cell = ct;
         o = (int64_t)(ct >> LK_TICK_BITS) * n_ticks + (int64_t)(ct & ((1u << LK_TICK_BITS) - 1));
         acc = out[o];
         slot_id = lane < max_truth ? true_id[o * max_truth + lane] : -2;
@@ -517,6 +600,13 @@ int light_launch_reset_cells(ldsim_ctx* ctx, int64_t n_rec, int64_t n_ticks, int
   HIPCHK(hipGetLastError());
   return 0;
 }
+int light_launch_clear_list(ldsim_ctx* ctx, const LightAct* act, float* out) {
+  hipLaunchKernelGGL(light_clear_list_kernel, dim3(256), dim3(256), 0, ctx->stream, *act, out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(act->p_count, 0, 4, ctx->stream));
+  return 0;
+}
+
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
@@ -560,15 +650,28 @@ int light_launch_t0_range(ldsim_ctx* ctx, const float* nph, const float* t0det, 
 int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* voxel, const int64_t* track_id,
                      const float* nph, int n_inc, const int32_t* op_channel, int n_det, const int32_t* sorted_idx,
                      double start_time, int64_t n_ticks, float* out, int64_t* true_id, double* true_ph, int max_truth,
-                     int64_t* n_rec_out /* truth path: records left sorted in light_tmp[4] (their cells are what was written) */) {
+                     int64_t* n_rec_out /* truth path: records left sorted in light_tmp[4] (their cells are what was written) */,
+                     const LightAct* act /* no truth slots: sum over a device-built list of the lit (detector, tile) cells */) {
   if (n_rec_out) *n_rec_out = 0;
-  if (n_det == 0 || n_ticks == 0 || n == 0) return 0;
+  if (n_det == 0 || n_ticks == 0 || n == 0) {
+    if (max_truth == 0 && act && act->clear) return light_launch_clear_list(ctx, act, out);
+    return 0;
+  }
   LightSum L;
   L.s = ctx->seg; L.c = ctx->d_consts; L.seg0 = seg0; L.n = n; L.voxel = voxel; L.nph = nph; L.n_inc = n_inc;
   L.op_channel = op_channel; L.n_det = n_det; L.t0_avg = ctx->d_lut_t0avg; L.time_dist = ctx->d_lut_td;
   L.ny = ctx->lut_ny; L.nz = ctx->lut_nz; L.ndet_lut = ctx->lut_ndet; L.nprof = ctx->lut_nprof;
   L.start_time = start_time; L.n_ticks = n_ticks;
   hipStream_t st = ctx->stream;
+  if (max_truth == 0 && act) {
+    const unsigned gx = (unsigned)nblk(n_det, 64), gy = (unsigned)nblk(n, 4 * LACT_SEGS);
+    const unsigned gclear = act->clear ? (255u + gx) / gx : 0u;
+    hipLaunchKernelGGL(light_active_kernel, dim3(gx, gy + gclear), dim3(256), 0, st, L, *act, (int)gy, out);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_light_list_kernel, dim3(512), dim3(256), 0, st, L, *act, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (max_truth == 0) {
     hipLaunchKernelGGL(sum_light_scatter_kernel, dim3(n_det, (unsigned)((n_ticks + LTILE - 1) / LTILE)), dim3(256), 0, st,
                        L, out);

@@ -64,7 +64,6 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     return 1ull << ((h >> 56) & 63ull);
   };
   if (!RESPONSE && Mt > 0 && live) {
-    const int64_t dst = ((int64_t)d * T + i) * Mt;
     prefix_ok = true;
     bool seen_empty = false;
     for (int b = 0; b < Mt; b++) {
@@ -80,7 +79,6 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
   int row_f = Mt;
   bool row_unique = false;
   if (RESPONSE && Mt > 0 && live) {
-    const int64_t dst = ((int64_t)d * T + i) * Mt;
     for (int b = 0; b < Mt; b++)
       if (tid_sm[O(b)] == -1) { row_f = b; break; }
     row_unique = true;
@@ -147,7 +145,7 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
       const double bound = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t_l), t), __builtin_amdgcn_readlane(__double2loint(t_l), t));
       const bool walk = mine && !(RESPONSE ? (fabs(w) * bound < truth_threshold) : (w >= 0.0 && w * bound < truth_threshold));
       if (!__ballot(walk)) continue;
-      const int64_t src = ((int64_t)d * T + j) * Mt, dst = ((int64_t)d * T + i) * Mt;
+      const int64_t src = ((int64_t)d * T + j) * Mt;
       const bool staged = Mt <= 64;
       // the slots some lane's product can pass on: lane a holds slot a while it stages it, so with the largest weight among the
       // walking lanes this is one ballot -- the walk visits those slots only, in ascending order, instead of all filled ones

@@ -35,7 +35,7 @@ int fee_launch_digitize(ldsim_ctx*, const double*, const double*, double*, int64
 int light_launch_incidence(ldsim_ctx*, int64_t, int64_t, int, float*, float*, int32_t*, int);
 int light_launch_t0_range(ldsim_ctx*, const float*, const float*, int64_t, int*);
 int light_launch_sum(ldsim_ctx*, int64_t, int64_t, const int32_t*, const int64_t*, const float*, int, const int32_t*, int,
-                     const int32_t*, double, int64_t, float*, int64_t*, double*, int, int64_t*);
+                     const int32_t*, double, int64_t, float*, int64_t*, double*, int, int64_t*, const LightAct* = nullptr);
 int light_launch_reset_cells(ldsim_ctx*, int64_t, int64_t, int, float*, int64_t*, double*);
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
@@ -281,6 +281,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     ctx->gform_max_support = value > 1e9 ? 1000000000 : (int)value;
   }
   else if (!strcmp(name, "light_incidence_scalar")) ctx->light_incidence_scalar = value != 0;
+  else if (!strcmp(name, "light_sum_no_list")) ctx->light_sum_no_list = value != 0;
   else if (!strcmp(name, "mac_mode")) {
     if (!(value == 0 || value == 1)) { ldsim_set_error("mac_mode must be 0 or 1"); return LDSIM_EINVAL; }
     ctx->mac_mode = (int)value;
@@ -912,6 +913,16 @@ extern "C" int ldsim_dev_light_t0_range(ldsim_ctx* ctx, int64_t seg_begin, int64
   return 0;
 }
 
+static int light_sum_time(ldsim_ctx* ctx) {
+  if (ctx->light_sum_timed) return 0;
+  HIPCHK(hipEventSynchronize(ctx->evl[3]));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->evl[2], ctx->evl[3]));
+  ctx->ms_light_sum = ms;
+  ctx->light_sum_timed = 1;
+  return 0;
+}
+
 // a18 for the resident segments [seg_begin, seg_end) = one batch of the reference's loop (cli/simulate_pixels.py:1120-1153):
 // light_sample_inc [n_det][n_ticks] f4 (+ truth slots) is zero / -1 initialised here and stays in HBM.
 extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, const int32_t* op_channel,
@@ -921,14 +932,24 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
   NEED_LIGHT_INC(ctx);
   NEED(ctx->d_lut_t0avg, "light LUT not set");
   NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
-  for (int i = 0; i < n_det; i++) NEED(op_channel[i] >= 0 && op_channel[i] < ctx->light_n_out, "op_channel outside the incidence array");
+  // (the driver passes the same channel list batch after batch: checked and sent when it changes)
+  const bool same_opc = ctx->light_opc.p && (int64_t)ctx->h_opc.size() == n_det && ctx->h_opc_n_out == ctx->light_n_out &&
+                        memcmp(ctx->h_opc.data(), op_channel, (size_t)n_det * 4) == 0;
+  if (!same_opc)
+    for (int i = 0; i < n_det; i++) NEED(op_channel[i] >= 0 && op_channel[i] < ctx->light_n_out, "op_channel outside the incidence array");
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = seg_end - seg_begin;
   const size_t bo = (size_t)n_det * n_ticks;
   hipStream_t st = ctx->stream;
   CK(ldsim_ensure_buf(ctx, &ctx->light_out, bo * 4 + 16));
-  CK(ldsim_ensure_buf(ctx, &ctx->light_opc, (size_t)n_det * 4));
-  HIPCHK(hipMemcpyAsync(ctx->light_opc.p, op_channel, (size_t)n_det * 4, hipMemcpyHostToDevice, st));
+  if (!same_opc) {
+    ctx->h_opc.clear();
+    CK(ldsim_ensure_buf(ctx, &ctx->light_opc, (size_t)n_det * 4));
+    HIPCHK(hipMemcpyAsync(ctx->light_opc.p, op_channel, (size_t)n_det * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));              // (pageable source: the copy must have left it before the call returns)
+    ctx->h_opc.assign(op_channel, op_channel + n_det);
+    ctx->h_opc_n_out = ctx->light_n_out;
+  }
   HIPCHK(hipEventRecord(ctx->evl[2], st));
   if (max_truth) {
     CK(ldsim_ensure_buf(ctx, &ctx->light_tid, bo * max_truth * 8 + 16));
@@ -943,10 +964,60 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
                     ctx->light_lazy_cap[0] == ctx->light_out.bytes && ctx->light_lazy_cap[1] == ctx->light_tid.bytes &&
                     ctx->light_lazy_cap[2] == ctx->light_tph.bytes &&      // (a buffer that grew was reallocated: contents undefined)
                     ctx->light_clean_cells >= bo;
+  // Without truth slots the sum runs over a device-built list of the lit (detector, tick tile) cells (LightAct); the array
+  // differs from zero in those tiles only, and the next such sum into the same buffer clears them instead of everything
+  // (ndlar: 96 of 3360 rows are lit per batch, the whole array is 148 MB).
+  const int ntile = (int)((n_ticks + LIGHT_TILE - 1) / LIGHT_TILE);
+  const bool use_list = max_truth == 0 && n_ticks > 0 && ntile <= 64 && (int64_t)n_det * ntile < 0x7fffffffLL && !ctx->light_sum_no_list;
+  LightAct act{};
+  bool act_fresh = false;
+  if (use_list) {
+    // two halves of one buffer: [cap] u64 masks | count (16 bytes) | [list_cap] i32 -- this sum's and the previous one's
+    if (n_det > ctx->light_nt_ndet_cap || (int64_t)n_det * ntile > ctx->light_nt_list_cap || !ctx->light_act.p) {
+      const int cap_det = n_det > ctx->light_nt_ndet_cap ? n_det : ctx->light_nt_ndet_cap;
+      const int64_t want_list = (int64_t)cap_det * (ntile > 8 ? ntile : 8);
+      const int cap_list = (int)(want_list > ctx->light_nt_list_cap ? want_list : ctx->light_nt_list_cap);
+      const size_t half = (((size_t)cap_det * 8 + 16 + (size_t)cap_list * 4 + 255) / 256) * 256;
+      ctx->light_nt_ndet_cap = ctx->light_nt_list_cap = 0;
+      ctx->light_nt_valid = 0;
+      if (ctx->light_act.p) { HIPCHK(hipFree(ctx->light_act.p)); ctx->light_act.p = nullptr; ctx->light_act.bytes = 0; }
+      CK(ldsim_ensure_buf(ctx, &ctx->light_act, 2 * half));
+      ctx->light_nt_ndet_cap = cap_det;
+      ctx->light_nt_list_cap = cap_list;
+      act_fresh = true;
+    }
+    const size_t half = (((size_t)ctx->light_nt_ndet_cap * 8 + 16 + (size_t)ctx->light_nt_list_cap * 4 + 255) / 256) * 256;
+    auto fill = [&](int h, unsigned long long** m, unsigned** c, int32_t** l) {
+      char* base = (char*)ctx->light_act.p + (size_t)h * half;
+      *m = (unsigned long long*)base;
+      *c = (unsigned*)(base + (size_t)ctx->light_nt_ndet_cap * 8);
+      *l = (int32_t*)(base + (size_t)ctx->light_nt_ndet_cap * 8 + 16);
+    };
+    const bool nt_lazy0 = !act_fresh && ctx->light_nt_valid && ctx->light_nt_out == ctx->light_out.p &&
+                          ctx->light_nt_cap == ctx->light_out.bytes && ctx->light_clean_cells >= bo;
+    const int cur = nt_lazy0 ? 1 - ctx->light_nt_half : 0;
+    int32_t* pl = nullptr;
+    fill(cur, &act.dmask, &act.count, &act.list);
+    fill(1 - cur, &act.p_dmask, &act.p_count, &pl);
+    act.p_list = pl;
+    act.ntile = ntile;
+    act.clear = nt_lazy0 ? 1 : 0;
+    act.p_ntile = ctx->light_nt_ntile;
+    act.p_nticks = ctx->light_nt_nticks;
+    ctx->light_nt_half = cur;
+  }
+  const bool nt_lazy = use_list && act.clear;
+  ctx->light_nt_valid = 0;
+  // (nt_lazy: the previous sum's tiles are cleared by this sum's first kernel, beside its own marking pass)
   if (lazy) {
     CK(light_launch_reset_cells(ctx, ctx->light_lazy_nrec, ctx->light_lazy_nticks, max_truth, (float*)ctx->light_out.p,
                                 (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p));
-  } else {
+  } else if (!nt_lazy) {
+    if (use_list) {                        // masks and counts of both halves
+      const size_t half = (((size_t)ctx->light_nt_ndet_cap * 8 + 16 + (size_t)ctx->light_nt_list_cap * 4 + 255) / 256) * 256;
+      HIPCHK(hipMemsetAsync(ctx->light_act.p, 0, (size_t)ctx->light_nt_ndet_cap * 8 + 16, st));
+      HIPCHK(hipMemsetAsync((char*)ctx->light_act.p + half, 0, (size_t)ctx->light_nt_ndet_cap * 8 + 16, st));
+    }
     HIPCHK(hipMemsetAsync(ctx->light_out.p, 0, bo * 4, st));
     if (max_truth) {
       HIPCHK(hipMemsetAsync(ctx->light_tid.p, 0xFF, bo * max_truth * 8, st));     // -1
@@ -963,7 +1034,14 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
   CK(light_launch_sum(ctx, seg_begin, n, (const int32_t*)ctx->light_vox.p + seg_begin * 3, (const int64_t*)ctx->light_trk.p,
                       (const float*)ctx->light_nph.p + (size_t)seg_begin * ctx->light_n_out, ctx->light_n_out,
                       (const int32_t*)ctx->light_opc.p, n_det, nullptr, start_time, n_ticks, (float*)ctx->light_out.p,
-                      (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p, max_truth, &n_rec));
+                      (int64_t*)ctx->light_tid.p, (double*)ctx->light_tph.p, max_truth, &n_rec, use_list ? &act : nullptr));
+  if (use_list) {                        // what the next such call has to undo
+    ctx->light_nt_valid = 1;
+    ctx->light_nt_ntile = ntile;
+    ctx->light_nt_nticks = n_ticks;
+    ctx->light_nt_out = ctx->light_out.p;
+    ctx->light_nt_cap = ctx->light_out.bytes;
+  }
   if (max_truth) {                       // what the next call has to undo
     ctx->light_lazy_valid = 1;
     ctx->light_lazy_mt = max_truth;
@@ -973,10 +1051,10 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
     ctx->light_lazy_cap[0] = ctx->light_out.bytes; ctx->light_lazy_cap[1] = ctx->light_tid.bytes; ctx->light_lazy_cap[2] = ctx->light_tph.bytes;
   }
   HIPCHK(hipEventRecord(ctx->evl[3], st));
-  HIPCHK(hipStreamSynchronize(st));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->evl[2], ctx->evl[3]));
-  ctx->ms_light_sum = ms;
+  // (the list-driven sum has nothing to bring back: the call returns with its kernels in flight, like a chain launch's stages;
+  // ldsim_light_kernel_ms waits for the events when it is asked)
+  ctx->light_sum_timed = 0;
+  if (!use_list) CK(light_sum_time(ctx));
   ctx->light_sum_ndet = n_det; ctx->light_sum_nticks = n_ticks; ctx->light_sum_truth = max_truth;
   ctx->light_resp_valid = 0;
   return 0;
@@ -1001,7 +1079,10 @@ extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc,
 extern "C" int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms) {
   NEED(ctx, "null ctx");
   if (incidence_ms) *incidence_ms = ctx->ms_light_inc;
-  if (sum_ms) *sum_ms = ctx->ms_light_sum;
+  if (sum_ms) {
+    CK(light_sum_time(ctx));
+    *sum_ms = ctx->ms_light_sum;
+  }
   return 0;
 }
 

@@ -83,6 +83,22 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// photon sum without truth slots over a device-built list of the lit (detector, tick tile) cells (kernels_light.hip)
+#define LIGHT_TILE 8192
+struct LightAct {
+  unsigned long long* dmask;    // [n_det] tiles of a detector row already listed
+  unsigned* count;              // entries in `list`
+  int32_t* list;                // idet * ntile + tile
+  int ntile;
+  // the sum before this one into the same array (the other half of the buffer): its listed tiles are zeroed again, its masks
+  // and its count reset, by the kernels of this sum (clear = 0: nothing to undo, the array was cleared whole)
+  int clear, p_ntile;
+  long long p_nticks;
+  unsigned long long* p_dmask;
+  unsigned* p_count;
+  const int32_t* p_list;
+};
+
 struct ldsim_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -161,6 +177,16 @@ struct ldsim_ctx {
   long long light_lazy_nrec = 0, light_lazy_nticks = 0;
   size_t light_clean_cells = 0, light_lazy_cap[3] = {0, 0, 0};
   void *light_lazy_out = nullptr, *light_lazy_tid = nullptr, *light_lazy_tph = nullptr;
+  // the same for a sum without truth slots: clean except the tiles in light_act's list (LightAct; geometry of that sum below)
+  DevBuf light_act;                            // two halves (this sum's, the previous one's) of: [cap] u64 masks, count u32, list i32
+  int light_nt_valid = 0, light_nt_ntile = 0, light_nt_ndet_cap = 0, light_nt_half = 0, light_nt_list_cap = 0;
+  long long light_nt_nticks = 0;
+  void* light_nt_out = nullptr;
+  size_t light_nt_cap = 0;
+  int32_t h_opc_n_out = 0;
+  int light_sum_no_list = 0;                   // option: 1 = the grid over every (detector, tile) and a full clear (A/B checks)
+  std::vector<int32_t> h_opc;                  // host copy of light_opc's contents (validated once, re-sent only when it changes)
+  int light_sum_timed = 1;                     // 0: evl[2..3] of the last sum not yet read into ms_light_sum
   // resident waveform stages on the last photon sum (ldsim_dev_light_response): scintillation profile (+ truth), Poisson
   // fluctuated rate, detector response (+ truth), all [light_sum_ndet][light_sum_nticks]
   DevBuf light_scint, light_scint_tid, light_scint_tph, light_disc, light_resp, light_resp_tid, light_resp_tph, light_w[2],

@@ -1063,6 +1063,55 @@ def test_resident_photon_sums_in_a_row_start_from_clean_arrays():
     assert any((t[1] != -1).any() for t in got)
 
 
+@pytest.mark.gpu
+def test_resident_photon_sums_without_truth_slots_over_the_lit_tiles():
+    """ldsim_dev_sum_light without truth slots sums over a device-built list of the (detector, tick tile) cells some deposit falls
+    into and, when the same buffer served such a sum before, clears only the tiles that sum listed.  ndlar batches (each lights its
+    own TPCs' rows of 3360), tick axes of one and two tiles, a shorter channel list and an empty range in a row on one context:
+    every array equals the one the grid over all (detector, tile) cells writes into a fully cleared array
+    (option light_sum_no_list) -- the same cells non-zero, values to the order of the f64 additions."""
+    seg, bid = _prepared_set("ndlar", 20_000, 5)
+    synth.set_synthetic_light(48)
+    lut = synth.make_lut((14, 26, 8), 48, 100, synth.SEED_BASE + 5)
+    opc = consts.light.TPC_TO_OP_CHANNEL[:].ravel().astype('i4')
+    n_sim = int((bid >= 0).sum())
+    edges = np.flatnonzero(np.r_[True, bid[1:n_sim] != bid[:n_sim - 1], True])
+    assert len(edges) > 40
+    rng = np.random.default_rng(11)
+    calls = []
+    for k, (b, e) in enumerate(zip(edges[:-1], edges[1:])):
+        if k >= 36:
+            break
+        ticks = [11000, 11000, 5000, 8192, 8193][k % 5]
+        ch_list = opc if k % 7 else np.ascontiguousarray(opc[rng.permutation(len(opc))[:1000]])
+        calls.append((int(b), int(e), ch_list, ticks))
+    calls.insert(5, (int(edges[3]), int(edges[3]), opc, 11000))            # an empty range: everything back to zero
+    calls.append((0, n_sim, opc, 11000))                                    # every batch at once: many rows lit
+
+    def run(no_list):
+        ch = ChargeChain()
+        lib.set_option("light_sum_no_list", 1 if no_list else 0, ch.ctx)
+        ch.upload(seg, bid)
+        ch.quench_drift()
+        ch.light_incidence(lut)
+        outs = []
+        for b, e, cl, ticks in calls:
+            n_ticks, _ = ch.sum_light(b, e, cl, max_truth=0, max_ticks=ticks)
+            assert n_ticks == ticks
+            outs.append(ch.download_light()[0])
+        return outs
+
+    got, ref = run(False), run(True)
+    lit_rows = set()
+    for c, a, r in zip(calls, got, ref):
+        assert a.shape == r.shape == (len(c[2]), c[3])
+        assert np.array_equal(a != 0, r != 0), c[:2]
+        np.testing.assert_allclose(a, r, rtol=1e-6, atol=0)
+        lit_rows.add(tuple(np.flatnonzero((r != 0).any(axis=1))[:4]))
+    assert not got[5].any() and got[-1].any()
+    assert len(lit_rows) > 10           # the batches really light different rows: a tile left uncleared would have shown
+
+
 def _lsb_mismatch(got, ref, lsb):
     """fraction of values that differ, and whether every difference is exactly one digitiser LSB"""
     d = np.abs(np.asarray(got) - np.asarray(ref))
