@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--config", default="module0", choices=["module0", "2x2_no_modvar", "ndlar"],
                     help="detector configuration of the synthetic workload (SURVEY 8d seeds); the contract line is the "
                          "default, module0 = BASELINE configs[1]")
+    ap.add_argument("--light-stream", default="own", choices=["own", "main"],
+                    help="photon sums without truth slots on a stream of their own beside the charge chain (own, default) or "
+                         "in the ctx's stream ahead of it (main)")
     ap.add_argument("--light", default="auto", choices=["auto", "on", "off"],
                     help="time the light leg (incidence + per-batch photon sum) with the charge chain; auto = ndlar only "
                          "(BASELINE configs[4], synthetic light set-up of SURVEY 8d)")
@@ -208,6 +211,9 @@ def main():
     lib.set_option("weights_mode", a.weights_mode, ch.ctx)
     if a.trim_response_log is not None:
         lib.set_option("trim_response_log", a.trim_response_log, ch.ctx)
+    light_own_stream = bool(light_on and consts.sim.MAX_MC_TRUTH_IDS == 0 and a.light_stream != "main")
+    if light_own_stream:
+        lib.set_option("light_sum_async", 1, ch.ctx)
     cm = lcomm.Communicator(ch.ctx, rank, world) if use_dist else None
     t_up = time.perf_counter()
     ch.upload(seg, bid)                      # H2D happens here, outside the timed region
@@ -232,15 +238,19 @@ def main():
             ch.light_incidence(lut)
             if record:
                 acc["inc_ms"] += ch.light_kernel_ms()["incidence_ms"]; acc["inc_n"] += 1
-            # one photon sum per (event, TPC group) batch, like the driver.  Timed as a whole, host calls included (a sum without
-            # truth slots returns with its kernels in flight; asking every call for its event time would serialise them)
+            # one photon sum per (event, TPC group) batch, like the driver.  Without truth slots a sum returns with its kernels
+            # in flight, and on their own stream (option light_sum_async) they run beside the charge chain of the same segments:
+            # what is timed here is the host issuing them; their duration on the GPU is tools/light_sum_loop.py's figure.
+            # With truth slots (2x2) every sum ends in a host read-back: the loop's wall time is the sums' time.
             if record:
-                ch.synchronize()
+                if not light_own_stream:
+                    ch.synchronize()
                 t_sum = time.perf_counter()
             for b, e in zip(bedges[:-1], bedges[1:]):
                 ch.sum_light(int(b), int(e), op_all)
             if record:
-                ch.synchronize()
+                if not light_own_stream:
+                    ch.synchronize()
                 acc["sum_ms"] += 1e3 * (time.perf_counter() - t_sum); acc["sum_n"] += len(bedges) - 1
                 # (the photon sums stay in HBM in the PCIe-inclusive passes too: their consumers -- scintillation, SiPM response,
                 # triggers -- run on the device, in the reference as here; what reaches the host is the digitised trigger windows)
@@ -397,6 +407,8 @@ def main():
         what = "charge chain quench->drift->pixels->tracks_current->pixel sum->ADC+digitize"
         if light_on:
             what += " + light incidence (all segments) + photon sum per (event, TPC group) batch"
+            if light_own_stream:
+                what += " (sums on their own stream beside the charge chain)"
         out = {
             "metric": f"edep segments/s end-to-end (quench->ADC), {a.config} config",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -482,7 +494,10 @@ def main():
                 "note": "streaming write of the dense [segment][channel] f4 array(s); torch.zero_() of the same size runs at "
                         "5.0-6.9 TB/s on this GPU (tools/fill_bw.py)",
                 "photon_sum_ms_avg": acc["sum_ms"] / max(acc["sum_n"], 1), "photon_sums": acc["sum_n"] // max(a.steps, 1),
-                "photon_sum_note": "wall time of a step's photon-sum loop over its batches (host calls included) / batches"}
+                "photon_sum_note": ("host time to issue a step's photon sums / batches: they run on their own stream beside the "
+                                    "charge chain (option light_sum_async) and end inside the step's timed region"
+                                    if light_own_stream else
+                                    "wall time of a step's photon-sum loop over its batches (host calls included) / batches")}
         out.update(extras)
         if world > 1:
             # timed on rank 0 of the single-GPU run only: at N > 1 it would keep the other ranks waiting at the barrier

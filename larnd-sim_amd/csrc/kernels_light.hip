@@ -274,7 +274,7 @@ __device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int
 // ---- without truth slots: scatter into an LDS tick tile ------------------------------------------------------------------
 // The accumulation order differs from the reference's sorted loop (f64 tile, one f4 rounding at the end), so the f4
 // result can differ from the reference's in the last bits.
-#define LTILE LIGHT_TILE
+#define LTILE 8192
 __global__ void __launch_bounds__(256) sum_light_scatter_kernel(LightSum L, float* __restrict__ out) {
   __shared__ double acc[LTILE];
   const int idet = blockIdx.x;
@@ -313,8 +313,8 @@ __device__ __forceinline__ void light_clear_entries(const unsigned* __restrict__
   for (int e = first; e < cnt; e += stride) {
     const int code = list[e];
     const int idet = code / ntile;
-    const int64_t tile0 = (int64_t)(code - idet * ntile) * LTILE;
-    const int tlen = (int)min((int64_t)LTILE, n_ticks - tile0);
+    const int64_t tile0 = (int64_t)(code - idet * ntile) * LIGHT_TILE;
+    const int tlen = (int)min((int64_t)LIGHT_TILE, n_ticks - tile0);
     float* o = out + (int64_t)idet * n_ticks + tile0;
     for (int i = threadIdx.x; i < tlen; i += 256) o[i] = 0.f;
     if (threadIdx.x == 0) dmask[idet] = 0ull;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) light_active_kernel(LightSum L, LightAct 
 #pragma unroll
   for (int k = 0; k < LACT_SEGS; k++)
     light_deposits_ph(L, r0 + k, opch, ph[k], [&](int64_t it, int, double photons) {
-      if (photons != 0.0) mask |= 1ull << (int)(it / LTILE);
+      if (photons != 0.0) mask |= 1ull << (int)(it / LIGHT_TILE);
     });
   if (!mask) return;
   const unsigned long long old = atomicOr(&A.dmask[idet], mask);
@@ -352,14 +352,14 @@ __global__ void __launch_bounds__(256) light_active_kernel(LightSum L, LightAct 
 }
 
 __global__ void __launch_bounds__(256) sum_light_list_kernel(LightSum L, LightAct A, float* __restrict__ out) {
-  __shared__ double acc[LTILE];
+  __shared__ double acc[LIGHT_TILE];
   if (A.clear && blockIdx.x == 0 && threadIdx.x == 0) *A.p_count = 0u;      // (light_active_kernel's clearing rows are done with it)
   const int cnt = (int)*A.count, ntile = A.ntile;
   for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
     const int code = A.list[e];
     const int idet = code / ntile;
-    const int64_t tile0 = (int64_t)(code - idet * ntile) * LTILE;
-    const int tlen = (int)min((int64_t)LTILE, L.n_ticks - tile0);
+    const int64_t tile0 = (int64_t)(code - idet * ntile) * LIGHT_TILE;
+    const int tlen = (int)min((int64_t)LIGHT_TILE, L.n_ticks - tile0);
     for (int i = threadIdx.x; i < tlen; i += 256) acc[i] = 0;
     __syncthreads();
     for (int64_t r = threadIdx.x; r < L.n; r += 256)

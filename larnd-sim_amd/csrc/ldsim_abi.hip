@@ -118,6 +118,18 @@ struct Tmp {
     }                              \
   } while (0)
 
+// Photon sums issued on the light stream (option light_sum_async) read the segment store, the incidence arrays, the LUT and the
+// constants, and write the resident photon-sum array: every entry point that writes one of the former or reads the latter makes
+// the ctx's stream wait for the last of them first.
+static int light_join(ldsim_ctx* ctx) {
+  if (ctx->light_pending) {
+    HIPCHK(hipEventRecord(ctx->ev_light_done, ctx->light_stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_light_done, 0));
+    ctx->light_pending = 0;
+  }
+  return 0;
+}
+
 extern "C" int ldsim_host_alloc(void** p, size_t bytes) {
   NEED(p, "null argument");
   *p = nullptr;
@@ -199,6 +211,7 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
 
 extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
   NEED(ctx && consts, "null argument");
+  CK(light_join(ctx));
   NEED(consts->n_tpc >= 0 && consts->n_tpc <= LDSIM_MAX_TPC, "n_tpc out of range");
   // another configuration has another demand on the split path's weight pool (ndlar needs ~4x module0's): relearn it
   // instead of keeping the high-water mark of everything this process has ever run
@@ -222,6 +235,12 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
+  if (ctx->light_stream) {
+    (void)hipStreamSynchronize(ctx->light_stream);
+    (void)hipStreamDestroy(ctx->light_stream);
+  }
+  if (ctx->ev_light_in) (void)hipEventDestroy(ctx->ev_light_in);
+  if (ctx->ev_light_done) (void)hipEventDestroy(ctx->ev_light_done);
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
   for (auto& b : ctx->out_alt)
@@ -248,6 +267,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
 
 extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
   NEED(ctx, "null ctx");
+  CK(light_join(ctx));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -282,6 +302,10 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   }
   else if (!strcmp(name, "light_incidence_scalar")) ctx->light_incidence_scalar = value != 0;
   else if (!strcmp(name, "light_sum_no_list")) ctx->light_sum_no_list = value != 0;
+  else if (!strcmp(name, "light_sum_async")) {
+    CK(light_join(ctx));
+    ctx->light_async = value != 0;
+  }
   else if (!strcmp(name, "mac_mode")) {
     if (!(value == 0 || value == 1)) { ldsim_set_error("mac_mode must be 0 or 1"); return LDSIM_EINVAL; }
     ctx->mac_mode = (int)value;
@@ -392,6 +416,7 @@ extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_
 
 extern "C" int ldsim_set_light_channels(ldsim_ctx* ctx, const double* eff, const int32_t* ch2tpc, int32_t n) {
   NEED(ctx && n >= 0, "bad light channels");
+  CK(light_join(ctx));
   if (ctx->d_eff) HIPCHK(hipFree(ctx->d_eff));
   if (ctx->d_ch2tpc) HIPCHK(hipFree(ctx->d_ch2tpc));
   ctx->d_eff = nullptr; ctx->d_ch2tpc = nullptr; ctx->n_light_ch = n;
@@ -410,6 +435,7 @@ extern "C" int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float
                                    const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet,
                                    int32_t nprof) {
   NEED(ctx && vis && t0 && t0_avg && time_dist, "null LUT plane");
+  CK(light_join(ctx));
   size_t nv = (size_t)nx * ny * nz * ndet;
   float** dst[] = {&ctx->d_lut_vis, &ctx->d_lut_t0, &ctx->d_lut_t0avg, &ctx->d_lut_td};
   const float* src[] = {vis, t0, t0_avg, time_dist};
@@ -461,6 +487,7 @@ static int upload_tracks(ldsim_ctx* ctx, const void* tracks, int64_t n, const Ld
   NEED(ctx && lay && n >= 0 && (tracks || n == 0), "bad tracks argument");
   NEED(lay->itemsize > 0, "bad layout");
   HIPCHK(hipSetDevice(ctx->device));
+  CK(light_join(ctx));
   CK(seg_reserve(ctx, n));
   ctx->seg.n = n;
   ctx->seg_owner = batch_id_is_resident ? 1 : 2;
@@ -539,6 +566,7 @@ extern "C" int ldsim_segments_reset(ldsim_ctx* ctx) {
   NEED_RESIDENT(ctx);
   NEED(ctx->seg.n == 0 || ctx->raw.p, "no uploaded records");
   HIPCHK(hipSetDevice(ctx->device));
+  CK(light_join(ctx));
   ctx->light_n = -1;
   return seg_launch_unpack(ctx, &ctx->seg_layout, ctx->seg.n);
 }
@@ -565,6 +593,7 @@ static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {
 extern "C" int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode) {
   NEED(ctx, "null ctx");
   NEED_RESIDENT(ctx);
+  CK(light_join(ctx));
   return run_quench_drift(ctx, mode, 1, 1);
 }
 
@@ -844,6 +873,7 @@ extern "C" int ldsim_dev_light_incidence(ldsim_ctx* ctx, int32_t n_out) {
   NEED(ctx->d_lut_vis && ctx->d_eff, "light LUT / channel tables not set");
   NEED(n_out <= ctx->n_light_ch, "more output channels than light channels configured");
   HIPCHK(hipSetDevice(ctx->device));
+  CK(light_join(ctx));
   const int64_t n = ctx->seg.n;
   const size_t bc = (size_t)n * n_out * 4;
   const bool trig0 = ctx->h_consts.light_trig_mode == 0;
@@ -940,6 +970,43 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = seg_end - seg_begin;
   const size_t bo = (size_t)n_det * n_ticks;
+  // Without truth slots the sum runs over a device-built list of the lit (detector, tick tile) cells (LightAct); the array
+  // differs from zero in those tiles only, and the next such sum into the same buffer clears them instead of everything
+  // (ndlar: 96 of 3360 rows are lit per batch, the whole array is 148 MB).
+  const int ntile = (int)((n_ticks + LIGHT_TILE - 1) / LIGHT_TILE);
+  const bool use_list = max_truth == 0 && n_ticks > 0 && ntile <= 64 && (int64_t)n_det * ntile < 0x7fffffffLL && !ctx->light_sum_no_list;
+  // Option light_sum_async: such a sum goes to the light stream, ordered after everything the ctx's stream holds so far and
+  // beside what it gets next (the charge chain of the same segments); light_join brings it back.  Everything below, helpers
+  // included, launches on ctx->stream: it points at the light stream until the call returns.
+  const bool on_light = use_list && ctx->light_async;
+  struct StreamScope {
+    ldsim_ctx* c;
+    hipStream_t keep;
+    bool on_light;
+    ~StreamScope() {
+      if (on_light) c->light_pending = 1;
+      c->stream = keep;
+    }
+  };
+  if (on_light) {
+    if (!ctx->light_stream) {
+      int prio_lo = 0, prio_hi = 0;          // (the small sums ahead of the charge chain's grids when both have workgroups to place)
+      HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIPCHK(hipStreamCreateWithPriority(&ctx->light_stream, hipStreamNonBlocking, prio_hi));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_in, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_done, hipEventDisableTiming));
+    }
+    // (the first sum since the last join waits for what the ctx's stream holds; while sums are pending, whatever writes their
+    // inputs there joins first -- light_join -- so the following sums have nothing new to wait for)
+    if (!ctx->light_pending) {
+      HIPCHK(hipEventRecord(ctx->ev_light_in, ctx->stream));
+      HIPCHK(hipStreamWaitEvent(ctx->light_stream, ctx->ev_light_in, 0));
+    }
+  } else {
+    CK(light_join(ctx));
+  }
+  StreamScope scope{ctx, ctx->stream, on_light};
+  if (on_light) ctx->stream = ctx->light_stream;
   hipStream_t st = ctx->stream;
   CK(ldsim_ensure_buf(ctx, &ctx->light_out, bo * 4 + 16));
   if (!same_opc) {
@@ -964,11 +1031,6 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
                     ctx->light_lazy_cap[0] == ctx->light_out.bytes && ctx->light_lazy_cap[1] == ctx->light_tid.bytes &&
                     ctx->light_lazy_cap[2] == ctx->light_tph.bytes &&      // (a buffer that grew was reallocated: contents undefined)
                     ctx->light_clean_cells >= bo;
-  // Without truth slots the sum runs over a device-built list of the lit (detector, tick tile) cells (LightAct); the array
-  // differs from zero in those tiles only, and the next such sum into the same buffer clears them instead of everything
-  // (ndlar: 96 of 3360 rows are lit per batch, the whole array is 148 MB).
-  const int ntile = (int)((n_ticks + LIGHT_TILE - 1) / LIGHT_TILE);
-  const bool use_list = max_truth == 0 && n_ticks > 0 && ntile <= 64 && (int64_t)n_det * ntile < 0x7fffffffLL && !ctx->light_sum_no_list;
   LightAct act{};
   bool act_fresh = false;
   if (use_list) {
@@ -1063,6 +1125,7 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
 extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* true_track_id,
                                         double* true_photons) {
   NEED(ctx, "null ctx");
+  CK(light_join(ctx));
   const size_t bo = (size_t)ctx->light_sum_ndet * ctx->light_sum_nticks;
   if (bo == 0) return 0;
   if (light_sample_inc) HIPCHK(hipMemcpyAsync(light_sample_inc, ctx->light_out.p, bo * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1203,6 +1266,7 @@ extern "C" int ldsim_dev_light_response(ldsim_ctx* ctx, const double* light_gain
                                         int32_t n_impulse, int32_t fluctuate) {
   NEED(ctx && light_gain, "bad argument");
   NEED(ctx->light_sum_ndet > 0, "no resident photon sum (ldsim_dev_sum_light)");
+  CK(light_join(ctx));
   const LdsimConsts& h = ctx->h_consts;
   NEED(h.light_tick_size > 0 && h.tau_s > 0 && h.tau_t > 0, "light constants not set");
   NEED(h.sipm_response_model == 0 || (h.sipm_response_model == 1 && impulse_model && n_impulse > 0 && h.impulse_tick_size > 0),

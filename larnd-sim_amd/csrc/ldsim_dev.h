@@ -84,7 +84,7 @@ struct DevBuf {
 };
 
 // photon sum without truth slots over a device-built list of the lit (detector, tick tile) cells (kernels_light.hip)
-#define LIGHT_TILE 8192
+#define LIGHT_TILE 2048      // ticks of a tile (16 KB of f64 sums in LDS: the sum kernel finds room beside the charge chain's workgroups)
 struct LightAct {
   unsigned long long* dmask;    // [n_det] tiles of a detector row already listed
   unsigned* count;              // entries in `list`
@@ -186,6 +186,11 @@ struct ldsim_ctx {
   int32_t h_opc_n_out = 0;
   int light_sum_no_list = 0;                   // option: 1 = the grid over every (detector, tile) and a full clear (A/B checks)
   std::vector<int32_t> h_opc;                  // host copy of light_opc's contents (validated once, re-sent only when it changes)
+  // option light_sum_async: the sums without truth slots run on a stream of their own, beside whatever the ctx's stream carries
+  // next (the charge chain).  light_pending: the last such sum has not been joined into ctx->stream yet (light_join, ldsim_abi.hip)
+  hipStream_t light_stream = nullptr;
+  hipEvent_t ev_light_in = nullptr, ev_light_done = nullptr;
+  int light_async = 0, light_pending = 0;
   int light_sum_timed = 1;                     // 0: evl[2..3] of the last sum not yet read into ms_light_sum
   // resident waveform stages on the last photon sum (ldsim_dev_light_response): scintillation profile (+ truth), Poisson
   // fluctuated rate, detector response (+ truth), all [light_sum_ndet][light_sum_nticks]

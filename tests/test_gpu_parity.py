@@ -1067,7 +1067,7 @@ def test_resident_photon_sums_in_a_row_start_from_clean_arrays():
 def test_resident_photon_sums_without_truth_slots_over_the_lit_tiles():
     """ldsim_dev_sum_light without truth slots sums over a device-built list of the (detector, tick tile) cells some deposit falls
     into and, when the same buffer served such a sum before, clears only the tiles that sum listed.  ndlar batches (each lights its
-    own TPCs' rows of 3360), tick axes of one and two tiles, a shorter channel list and an empty range in a row on one context:
+    own TPCs' rows of 3360), tick axes of one to six tiles (whole and ragged), a shorter channel list and an empty range in a row on one context:
     every array equals the one the grid over all (detector, tile) cells writes into a fully cleared array
     (option light_sum_no_list) -- the same cells non-zero, values to the order of the f64 additions."""
     seg, bid = _prepared_set("ndlar", 20_000, 5)
@@ -1082,34 +1082,51 @@ def test_resident_photon_sums_without_truth_slots_over_the_lit_tiles():
     for k, (b, e) in enumerate(zip(edges[:-1], edges[1:])):
         if k >= 36:
             break
-        ticks = [11000, 11000, 5000, 8192, 8193][k % 5]
+        ticks = [11000, 2048, 5000, 8192, 2049][k % 5]
         ch_list = opc if k % 7 else np.ascontiguousarray(opc[rng.permutation(len(opc))[:1000]])
         calls.append((int(b), int(e), ch_list, ticks))
     calls.insert(5, (int(edges[3]), int(edges[3]), opc, 11000))            # an empty range: everything back to zero
     calls.append((0, n_sim, opc, 11000))                                    # every batch at once: many rows lit
 
-    def run(no_list):
-        ch = ChargeChain()
+    def run(no_list, own_stream=False):
+        ch = ChargeChain(H.response_for("survey")) if own_stream else ChargeChain()
         lib.set_option("light_sum_no_list", 1 if no_list else 0, ch.ctx)
-        ch.upload(seg, bid)
-        ch.quench_drift()
-        ch.light_incidence(lut)
-        outs = []
-        for b, e, cl, ticks in calls:
-            n_ticks, _ = ch.sum_light(b, e, cl, max_truth=0, max_ticks=ticks)
-            assert n_ticks == ticks
-            outs.append(ch.download_light()[0])
-        return outs
+        lib.set_option("light_sum_async", 1 if own_stream else 0, ch.ctx)
+        try:
+            ch.upload(seg, bid)
+            ch.quench_drift()
+            ch.light_incidence(lut)
+            outs = []
+            for k, (b, e, cl, ticks) in enumerate(calls):
+                n_ticks, _ = ch.sum_light(b, e, cl, max_truth=0, max_ticks=ticks)
+                assert n_ticks == ticks
+                if own_stream and k % 3 == 0 and e > b:      # the charge chain of the same batch in the ctx's stream meanwhile
+                    ch.run(b, min(e, b + 300))
+                if own_stream and k % 4 == 1:                # sums in a row on the light stream, no consumer between them
+                    continue
+                outs.append((k, ch.download_light()[0]))
+            return outs
+        finally:
+            lib.set_option("light_sum_no_list", 0, ch.ctx)
+            lib.set_option("light_sum_async", 0, ch.ctx)
 
     got, ref = run(False), run(True)
     lit_rows = set()
-    for c, a, r in zip(calls, got, ref):
+    for c, (_, a), (_, r) in zip(calls, got, ref):
         assert a.shape == r.shape == (len(c[2]), c[3])
         assert np.array_equal(a != 0, r != 0), c[:2]
         np.testing.assert_allclose(a, r, rtol=1e-6, atol=0)
         lit_rows.add(tuple(np.flatnonzero((r != 0).any(axis=1))[:4]))
-    assert not got[5].any() and got[-1].any()
+    assert not got[5][1].any() and got[-1][1].any()
     assert len(lit_rows) > 10           # the batches really light different rows: a tile left uncleared would have shown
+    # the same sums on the light stream (option light_sum_async), charge-chain launches and further sums in between: every
+    # array a consumer fetches is the one the sum in the ctx's stream gave
+    ref_by_k = dict(ref)
+    own = run(False, own_stream=True)
+    assert 20 < len(own) < len(calls)
+    for k, a in own:
+        assert np.array_equal(a != 0, ref_by_k[k] != 0), calls[k][:2]
+        np.testing.assert_allclose(a, ref_by_k[k], rtol=1e-6, atol=0)
 
 
 def _lsb_mismatch(got, ref, lsb):
