@@ -150,7 +150,10 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * instead of four (the form used when n_out or the LUT's detector count is not a multiple of 4); identical bits; default 0),
  * "light_sum_no_list" (1 = ldsim_dev_sum_light without truth slots launches a workgroup per (detector, tick tile) and clears
  * the whole array first, instead of summing over the device-built list of the lit tiles; same cells, values to the order of
- * the f64 additions; default 0),
+ * the f64 additions; default 0), "light_sum_async" (1 = the ldsim_dev_sum_light calls without truth slots launch on a stream of the
+ * ctx's own beside whatever its main stream carries next, e.g. the charge chain of the same segments; every entry point that
+ * writes what they read -- segment upload / reset / quench-drift, incidence, LUT, channel tables, constants -- or reads their array
+ * -- ldsim_dev_light_download, ldsim_dev_light_response, ldsim_synchronize -- waits for them first; default 0),
  * "numba_f32" (1 = the sub-expressions Numba types float32 for f4 record fields are evaluated in float, detsim.py:74-79,
  * 116-118,141,387; 0 = all-f64, what the reference computes for f8 records and what the goldens pin; default 0),
  * "mc_current" (1 = the fused chain takes its induced currents from tracks_current_mc like the reference driver does;
