@@ -52,7 +52,7 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
 }
 
 // the launch a pair belongs to: the smallest LDS budget its tables fit (0: the launch over all pairs, 16 KB, ten pairs per CU;
-// 1: 32 KB, five per CU; 2: the largest pair the caps allow, two to three per CU -- launches over lists)
+// 1: 22 KB, seven per CU; 2: the largest pair the caps allow, two to three per CU -- launches over lists)
 __host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, int TT, int b0, int b1) {
   if (g_lds_layout(ncol, NJ, NU, TT, b0).bytes <= b0) return 0;
   return g_lds_layout(ncol, NJ, NU, TT, b1).bytes <= b1 ? 1 : 2;
@@ -399,8 +399,9 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
   // Launches of the correlation by LDS need (g_lds_class): pairs that fit 13 KB (M = 1: 80 VGPRs, six waves per SIMD; M = 2, whose
   // kernel spills at 80: 16 KB, 96 VGPRs, five) run twelve (ten) to a CU in the launch over all pairs, the
-  // rest -- listed here, counted on the host together with the pool size -- five to a CU at 32 KB or two to three at the caps' size.
-  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = 32768, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
+  // rest -- listed here, counted on the host together with the pool size -- seven to a CU at 22 KB (every such pair of the ndlar
+  // workload fits it; at 32 KB they ran five to a CU: 18.8 -> 17.6 ms per 50 k segments, tools/lds_b1_sweep.py) or two to three at the caps' size.
+  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
@@ -430,8 +431,8 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
       else sl++;
     }
     fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 256: %ld, X | Y bins > 80: %ld, "
-            "slices > 64: %ld), wide wave tables kernel %llu, correlation launches at 32 KB / %d KB of LDS: %llu / %llu pairs, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl,
-            n_w2, b2 >> 10, n_cls[1], n_cls[2], total * 8e-9);
+            "slices > 64: %ld), wide wave tables kernel %llu, correlation launches at %d KB / %d KB of LDS: %llu / %llu pairs, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl,
+            n_w2, b1 >> 10, b2 >> 10, n_cls[1], n_cls[2], total * 8e-9);
   }
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));

@@ -140,6 +140,7 @@ struct ldsim_ctx {
   double trim_response_log = 23.0;           // response ticks below exp(-v) of the table's largest entry are not read (0: exact zeros only)
   std::vector<double> h_resp_kmax;           // largest |entry| of every response tick over all cells (host)
   int debug_phases = 15;
+  int debug_lds_b1_kb = 0;                   // timing tools: LDS budget of gcorr_kernel's second class in KB (0 = 32)
   int debug_lds_pad_kb = 0;                  // timing tools: KB taken off the LDS budget of gcorr_kernel's small class
   long long frac_clean_gen = -1;             // out_gen of the output set whose dense fractions array has been completed with zeros
   int gform_wave_tables = 1;                 // 1: gtables_wave_kernel (a wave per pair) for the pairs that fit it, 0: gtables_kernel for all
