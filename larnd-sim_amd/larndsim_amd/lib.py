@@ -78,6 +78,12 @@ def set_light_shape(shape):
     _light_shape = tuple(int(v) for v in shape)
 
 
+def set_light_shape_tuple(shape):
+    """the same for a tuple of ints already made (the per-batch fast path of ChargeChain.sum_light)"""
+    global _light_shape
+    _light_shape = shape
+
+
 def context_light_shape():
     return _light_shape
 
