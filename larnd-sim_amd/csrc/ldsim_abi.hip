@@ -994,9 +994,9 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
       int prio_lo = 0, prio_hi = 0;          // (the small sums ahead of the charge chain's grids when both have workgroups to place)
       HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
       HIPCHK(hipStreamCreateWithPriority(&ctx->light_stream, hipStreamNonBlocking, prio_hi));
-      HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_in, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_done, hipEventDisableTiming));
     }
+    if (!ctx->ev_light_in) HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_in, hipEventDisableTiming));
+    if (!ctx->ev_light_done) HIPCHK(hipEventCreateWithFlags(&ctx->ev_light_done, hipEventDisableTiming));
     // (the first sum since the last join waits for what the ctx's stream holds; while sums are pending, whatever writes their
     // inputs there joins first -- light_join -- so the following sums have nothing new to wait for)
     if (!ctx->light_pending) {
