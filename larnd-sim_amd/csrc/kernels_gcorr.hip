@@ -35,7 +35,7 @@ struct GLds {
   int xs, ys, zs, cellcap, bytes;
   bool z_lds;
 };
-__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT, int budget) {
+__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT, int budget, int M) {
   GLds L;
   L.xs = (ncol + 1) | 1;                             // odd strides: the 16 node rows fall on distinct banks; column `ncol` of X
   L.ys = NJ | 1;                                     //   holds zeros (the weightless padding cells of the list point at it)
@@ -44,7 +44,9 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys) + L.cellcap) + 16;
   // Z in LDS where the pair's budget has room for it; else (and for the steepest long segments, NU > G_NUCAP) the P step reads
   // it from the record: a pair never drops to the low-occupancy class because of its Z table
-  const int zs = (nur & 31) == 16 ? nur : nur + 16;  // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
+  // M = 1: == 16 mod 32, the four 16-shift runs of an A operand read conflict-free; M = 2 reads every other shift (one parity):
+  // an odd stride puts the runs of neighbouring node rows on the other half of the bank pairs
+  const int zs = M == 2 ? nur + 1 : ((nur & 31) == 16 ? nur : nur + 16);
   L.z_lds = NU <= G_NUCAP && rest + 8 * G_NODES * zs <= budget;
   L.zs = L.z_lds ? zs : 0;
   L.bytes = rest + 8 * G_NODES * L.zs;
@@ -53,9 +55,9 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
 
 // the launch a pair belongs to: the smallest LDS budget its tables fit (0: the launch over all pairs, 16 KB, ten pairs per CU;
 // 1: 22 KB, seven per CU; 2: the largest pair the caps allow, two to three per CU -- launches over lists)
-__host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, int TT, int b0, int b1) {
-  if (g_lds_layout(ncol, NJ, NU, TT, b0).bytes <= b0) return 0;
-  return g_lds_layout(ncol, NJ, NU, TT, b1).bytes <= b1 ? 1 : 2;
+__host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, int TT, int b0, int b1, int M) {
+  if (g_lds_layout(ncol, NJ, NU, TT, b0, M).bytes <= b0) return 0;
+  return g_lds_layout(ncol, NJ, NU, TT, b1, M).bytes <= b1 ? 1 : 2;
 }
 
 template <int M>
@@ -87,8 +89,8 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
-  if (g_lds_class(ncol, NJ, NU, TT, b0, b1) != cls) return;      // another launch's pair
-  const GLds L = g_lds_layout(ncol, NJ, NU, TT, cls == 0 ? b0 : (cls == 1 ? b1 : b2));
+  if (g_lds_class(ncol, NJ, NU, TT, b0, b1, M) != cls) return;      // another launch's pair
+  const GLds L = g_lds_layout(ncol, NJ, NU, TT, cls == 0 ? b0 : (cls == 1 ? b1 : b2), M);
   const double* __restrict__ rec = GA.rec + gip->off;
   const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
   const int NUr = g_nur(NU), NU16 = NUr >> 4;
@@ -169,6 +171,47 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             if (4 * q < rows) za[q] = z_lds ? s_Z[(4 * q + kk) * zs + 16 * st + jj] : gZ[(4 * q + kk) * NUr + 16 * st + jj];
         };
         const int nq4 = rows >> 2;          // node groups of four the batch has (its last batch: often one)
+        if constexpr (M == 2) {
+          // M = 2: out[(k - u_min - u) / 2] takes P[u][k] only where k - u_min - u is even.  The wave's two tiles hold the even and
+          // the odd response indices of its 32 (tile_run below): each meets the shifts of one parity only, so the products run over
+          // 16 shifts of that parity at a time -- none is computed to be dropped (half of them were).
+          const int par0 = (k0 - u_min) & 1, par1 = par0 ^ 1;
+          const int NV16 = (((NU + 1) >> 1) + 15) >> 4;
+          for (int st = 0; st < NV16; st++) {
+            const int ue = 2 * (16 * st + jj);
+            // (the two Z entries of a node group are fetched one group ahead of their products: two operand pairs live, like the
+            // M = 1 form's four single ones)
+            const bool in0 = ue + par0 < NUr, in1 = ue + par1 < NUr;
+            auto zpair = [&](int q, double& a0, double& a1) {
+              const int n = 4 * q + kk;
+              a0 = in0 ? (z_lds ? s_Z[n * zs + ue + par0] : gZ[n * NUr + ue + par0]) : 0.0;
+              a1 = in1 ? (z_lds ? s_Z[n * zs + ue + par1] : gZ[n * NUr + ue + par1]) : 0.0;
+            };
+            d4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+            double a0, a1, n0 = 0, n1 = 0;
+            zpair(0, a0, a1);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (q < nq4) {
+                if (q + 1 < nq4) zpair(q + 1, n0, n1);
+                p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, g0acc[q], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g1acc[q], p1, 0, 0, 0);
+                a0 = n0; a1 = n1;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int v = 16 * st + 4 * r + kk;
+              const int u0 = 2 * v + par0, u1 = 2 * v + par1;
+              const int idx0 = ((k0 + 2 * jj - (u_min + u0)) >> 1) - sup0;          // (even numerators by construction)
+              const int idx1 = ((k0 + 2 * jj + 1 - (u_min + u1)) >> 1) - sup0;
+              if (u0 < NU && idx0 >= 0 && idx0 < wlen) atomicAdd(&ow[idx0], p0[r]);
+              if (u1 < NU && idx1 >= 0 && idx1 < wlen) atomicAdd(&ow[idx1], p1[r]);
+            }
+          }
+          n_mfma += 2 * nq4 * NV16;
+          return;
+        }
         for (int st = 0; st < NU16; st++) {
           double za[4];
           zrow(st, za);
@@ -214,7 +257,9 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       auto col_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk) + 1]; };
       for (int kt = wv; kt < n32 && run_tiles; kt += GW) {
         const int k0 = kA + 32 * kt;
-        const double* rpl = GA.resp_pad + RESP_PAD + k0 + jj;
+        // (M = 2: tile 0 holds the even, tile 1 the odd indices of the 32 -- lane jj loads k0 + 2 jj and k0 + 2 jj + 1, adjacent)
+        const double* rpl = GA.resp_pad + RESP_PAD + k0 + (M == 2 ? 2 * jj : jj);
+        constexpr int B1 = M == 2 ? 1 : 16;
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double b0[GPF], b1[GPF], xv[2], yv[2];
         unsigned lo[2], hi[2];
@@ -222,7 +267,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         for (int u = 0; u < GPF; u++) {
           const double* q = rpl + row_word(u);
           b0[u] = q[0];
-          b1[u] = q[16];
+          b1[u] = q[B1];
         }
         lo[0] = row_word(GPF);
         hi[0] = col_word(0);
@@ -239,7 +284,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
             const double* q = rpl + lo[u & 1];
             b0[u] = q[0];
-            b1[u] = q[16];
+            b1[u] = q[B1];
             lo[(u + 1) & 1] = row_word(g0 + u + GPF + 1);
             xv[(u + 1) & 1] = *(const double*)(xl + (hi[(u + 1) & 1] & 0xFFFFu));
             yv[(u + 1) & 1] = *(const double*)(yl + (hi[(u + 1) & 1] >> 16));
@@ -261,8 +306,8 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
               et++;
               const int ke = edge_k[e];
               if (!(emask & (1 << e)) || ke < k0 || ke >= k0 + 32) continue;
-              const bool upper = ke >= k0 + 16;
-              if (jj == ((ke - k0) & 15)) {
+              const bool upper = M == 2 ? ((ke - k0) & 1) != 0 : ke >= k0 + 16;
+              if (jj == (M == 2 ? (ke - k0) >> 1 : ((ke - k0) & 15))) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_gs[wv * G_NODES + 4 * r + kk] = upper ? acc1[r] : acc0[r];
               }
@@ -309,13 +354,13 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
 }
 
 // the pairs of the launches after the first (g_lds_class 1, 2), one atomic per wave and list
-__global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict__ gi, int64_t n, int TT, int b0, int b1,
+__global__ void __launch_bounds__(256) gbig_list_kernel(const GInfo* __restrict__ gi, int64_t n, int TT, int b0, int b1, int M,
                                                         int32_t* __restrict__ lists /* [2][n] */,
                                                         unsigned long long* __restrict__ counts /* [2] */) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int cls = 0;
-  if (i < n && gi[i].status == 1) cls = g_lds_class(gi[i].ncol, gi[i].NJ, gi[i].NU, TT, b0, b1);
+  if (i < n && gi[i].status == 1) cls = g_lds_class(gi[i].ncol, gi[i].NJ, gi[i].NU, TT, b0, b1, M);
   for (int c = 1; c <= 2; c++) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
@@ -401,11 +446,11 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // kernel spills at 80: 16 KB, 96 VGPRs, five) run twelve (ten) to a CU in the launch over all pairs, the
   // rest -- listed here, counted on the host together with the pool size -- seven to a CU at 22 KB (every such pair of the ndlar
   // workload fits it; at 32 KB they ran five to a CU: 18.8 -> 17.6 ms per 50 k segments, tools/lds_b1_sweep.py) or two to three at the caps' size.
-  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30).bytes;
+  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, M).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
-  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, b0, b1, d_big, d_total + 1);
+  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, b0, b1, M, d_big, d_total + 1);
   HIPCHK(hipGetLastError());
   GA.gi = gi;
   GA.dbg = (ctx->debug_gform & ~64) | (ctx->gform_wave_tables ? 0 : 64);
