@@ -397,7 +397,8 @@ def main():
         mac_s = (acc["m_ms"] if split else acc["cur_ms"]) * 1e-3
         tflops = 2.0 * acc["dfma"] / mac_s / 1e12 if mac_s > 0 else 0.0
         nl = max(acc["launches"], 1)
-        default_workload = (a.segments == SEGS_PER_GPU and a.response == "survey" and a.fractions and split and seed_index == 2)
+        default_workload = (a.segments == SEGS_PER_GPU and a.response == "survey" and a.fractions and split and
+                            seed_index == {"module0": 2, "2x2_no_modvar": 3, "ndlar": 5}.get(a.config))
         traffic, traffic_src = profiled_traffic(a.config, dom_name) if default_workload else (None, "not the profiled workload")
         what = "charge chain quench->drift->pixels->tracks_current->pixel sum->ADC+digitize"
         if light_on:
