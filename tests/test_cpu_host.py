@@ -505,3 +505,56 @@ def test_light_output_datasets_golden(cfg):
     for f in assn.dtype.names:
         assert np.array_equal(assn[f], g["assn_" + f]), f
     assert len(assn) > 100 and len(np.unique(assn["trigger_id"])) > 2
+
+
+def test_sum_light_wrapper_keeps_its_arguments_only_for_the_same_channel_array(monkeypatch):
+    """ChargeChain.sum_light without truth slots (trigger mode 1) keeps the channel array's pointer and the fixed arguments of the
+    library call between batches.  No GPU: the library call is replaced by a recorder.  The same array object re-uses them (changes
+    of its contents are the library's business: it compares against its copy); another object, another tick cap or another light
+    window refreshes them; an array that had to be converted is never kept; truth slots take the general path."""
+    from larndsim_amd import chain
+    H.load_cfg("ndlar")
+    synth.set_synthetic_light(48)
+    calls = []
+
+    class FakeLib:
+        def ldsim_dev_sum_light(self, ctx, b, e, opc, n_det, tid, mt, t_start, n_ticks):
+            calls.append((b.value, e.value, C.cast(opc, C.c_void_p).value, n_det.value, tid is None or not bool(tid), mt.value,
+                          t_start.value, n_ticks.value))
+            return 0
+
+    fake = FakeLib()
+    monkeypatch.setattr(lib, "load", lambda: fake)
+    monkeypatch.setattr(lib, "consts_generation", lambda: 7)
+    ch = chain.ChargeChain.__new__(chain.ChargeChain)
+    ch.ctx, ch._generation, ch.n = None, 7, 0
+    opc = consts.light.TPC_TO_OP_CHANNEL[:].ravel().astype(np.int32)
+    n_ticks_full = int((consts.light.LIGHT_WINDOW[1] + consts.light.LIGHT_WINDOW[0]) / consts.light.LIGHT_TICK_SIZE)
+    assert consts.sim.MAX_MC_TRUTH_IDS == 0 and consts.light.LIGHT_TRIG_MODE != 0
+    assert ch.sum_light(0, 200, opc) == (n_ticks_full, 0)
+    first = ch._sum_light_fast
+    assert ch.sum_light(200, 450, opc) == (n_ticks_full, 0) and ch._sum_light_fast is first
+    assert calls[0][2] == calls[1][2] == opc.ctypes.data and calls[1][:2] == (200, 450) and calls[1][3] == len(opc)
+    assert ch._light_shape == (len(opc), n_ticks_full, 0) and lib.context_light_shape() == ch._light_shape
+    # another array object (same contents), another tick cap: refreshed
+    opc2 = opc.copy()
+    ch.sum_light(0, 10, opc2)
+    assert ch._sum_light_fast is not first and calls[-1][2] == opc2.ctypes.data
+    second = ch._sum_light_fast
+    assert ch.sum_light(0, 10, opc2, max_ticks=5000) == (5000, 0) and ch._sum_light_fast is not second and calls[-1][7] == 5000
+    # an int64 list is converted for the call and not kept
+    kept = ch._sum_light_fast
+    ch.sum_light(0, 10, opc.astype(np.int64))
+    assert ch._sum_light_fast is kept and calls[-1][3] == len(opc)
+    # a changed light window changes the tick count of the next call
+    w = consts.light.LIGHT_WINDOW
+    try:
+        consts.light.LIGHT_WINDOW = (w[0], w[1] + 1)
+        n2, _ = ch.sum_light(0, 10, opc2, max_ticks=int(5e4))
+        assert n2 == n_ticks_full + int(1 / consts.light.LIGHT_TICK_SIZE) and calls[-1][7] == n2
+    finally:
+        consts.light.LIGHT_WINDOW = w
+    # truth slots: the general path (ids made for the range)
+    n_before = len(calls)
+    ch.sum_light(5, 9, opc2, max_truth=3)
+    assert len(calls) == n_before + 1 and calls[-1][5] == 3 and calls[-1][4] is False
