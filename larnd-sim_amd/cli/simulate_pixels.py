@@ -284,6 +284,11 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     if not rand_seed:
         rand_seed = SEED
     print("Random seed:", rand_seed)
+    if int(getattr(sim, "WRITE_BATCH_SIZE", 1)) != 1:
+        # (cli/simulate_pixels.py:1207-1214 gathers WRITE_BATCH_SIZE batches per export; an export starts with the timestamp / sync /
+        # trigger packets of its first event, so the hits are the same and only those per-export packets are more here)
+        print(f"write_batch_size = {sim.WRITE_BATCH_SIZE} is not used: packets and light datasets are exported once per batch "
+              "(as with write_batch_size 1)")
     bad_list = None
     if bad_channels:
         import yaml
@@ -538,12 +543,9 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             seg_ids, trj_ids = seg_ids_all[lo:], trj_ids_all[lo:]
             tpm = r["track_pixel_map"][m]
             digit, ticks_b, upix_b, frac_b = r["adc_digit"][m], r["adc_ticks_list"][m], r["unique_pix"][m], r["current_fractions"][m]
-            if "first_of_batch" in r and len(tpm) and not r["first_of_batch"][m][0]:
-                # compact form: the batch's first unique pixel holds no hit and is not among the rows.  The reference's exporter
-                # keeps its clock-rollover state in row 0 of what it is handed (fee.py:164-183, 267-277): hand it that hit-less row.
-                pad = lambda a, v: np.concatenate([np.full((1,) + a.shape[1:], v, dtype=a.dtype), a])      # noqa: E731
-                tpm, digit, ticks_b, frac_b = pad(tpm, -1), pad(digit, packets._digitize0()), pad(ticks_b, 0), pad(frac_b, 0)
-                upix_b = pad(upix_b, upix_b[0])
+            # (compact form: a batch whose first unique pixel holds no hit comes with that hit-less row in front --
+            # expand_compact(lead_rows=True) -- because the reference's exporter keeps its clock-rollover state in row 0 of what
+            # it is handed, fee.py:164-183, 267-277)
             track_ids = np.where(tpm >= 0, seg_ids[np.maximum(tpm, 0)], -1)
             traj_ids = np.where(tpm >= 0, trj_ids[np.maximum(tpm, 0)], -1)
             event = table[int(bb)][0]
@@ -577,7 +579,7 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             continue
         chain.run(int(b), int(e), want_fractions=True)
         if not raw_arrays:
-            export_chunk(expand_compact(chain.download_compact()))
+            export_chunk(expand_compact(chain.download_compact(), lead_rows=True))
             b = e
             continue
         if not overlapped:

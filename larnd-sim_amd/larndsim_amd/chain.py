@@ -336,35 +336,55 @@ class ChargeChain:
         return p.value, n.value, rb.value
 
 
-def expand_compact(c):
+def expand_compact(c, lead_rows=False):
     """Dense rows of the hit pixels from ``ChargeChain.download_compact()``: the arrays ``download()`` returns, restricted to
     the unique pixels that hold a hit (``row`` = their index in the full arrays): ``unique_pix``, ``batch``, ``adc_list``,
     ``first_of_batch`` (the pixel is row 0 of its batch in the full arrays: the exporter's clock-rollover bookkeeping looks at the
     first row it is handed), ``adc_ticks_list``, ``adc_digit`` [n][A] (slots past a pixel's last hit: charge 0, tick 0, the pedestal code -- what the dense
     arrays hold there), ``track_pixel_map`` [n][M] (-1 pad) and ``current_fractions`` [n][A][M] (written slots only: the dense
-    array's un-normalised residue in the slot after the last hit, fee.py:572-573, is not part of the result)."""
+    array's un-normalised residue in the slot after the last hit, fee.py:572-573, is not part of the result).
+
+    ``lead_rows``: a batch whose first unique pixel holds no hit gets that hit-less row back in front of its hit pixels (no charge,
+    no track, the pixel id of the row after it, ``row`` -1) -- the reference's exporter keeps its clock-rollover state in row 0 of
+    what it is handed (fee.py:164-183, 267-277), and inserting the row here costs nothing where padding every batch's slice of
+    the 12 KB-per-pixel fraction array afterwards copied it once more."""
     from . import packets
     A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
     hp = c["hit_pixels"]
-    n = hp.shape[0]
+    n0 = hp.shape[0]
     nh, nt = hp[:, 3].astype(np.int64), (hp[:, 4] & 255).astype(np.int64)
+    first = (hp[:, 4] & 256) != 0
     ped = float(packets._digitize0())                   # fee.digitize(0): what an unwritten slot digitises to
-    out = dict(row=hp[:, 0].copy(), first_of_batch=(hp[:, 4] & 256) != 0, unique_pix=hp[:, 1].copy(), batch=hp[:, 2].copy(),
-               adc_list=np.zeros((n, A)),
+    pos = np.arange(n0)                                 # output row of hit pixel i
+    n = n0
+    if lead_rows and n0:
+        need = np.r_[True, hp[1:, 2] != hp[:-1, 2]] & ~first          # batches that start with a hit-less pixel
+        pos = pos + np.cumsum(need)
+        n = n0 + int(need.sum())
+    out = dict(row=np.full(n, -1, dtype=hp.dtype), first_of_batch=np.ones(n, dtype=bool), unique_pix=np.zeros(n, dtype=hp.dtype),
+               batch=np.zeros(n, dtype=hp.dtype), adc_list=np.zeros((n, A)),
                adc_ticks_list=np.zeros((n, A)), adc_digit=np.full((n, A), ped), track_pixel_map=np.full((n, M), -1, dtype=np.int64))
+    out["row"][pos] = hp[:, 0]
+    out["first_of_batch"][pos] = first
+    out["unique_pix"][pos] = hp[:, 1]
+    out["batch"][pos] = hp[:, 2]
+    if n != n0:
+        lead = pos[need] - 1
+        out["unique_pix"][lead] = hp[need, 1]
+        out["batch"][lead] = hp[need, 2]
     # hits: pixel after pixel, slot 0 up
-    pix_of_hit = np.repeat(np.arange(n), nh)
+    pix_of_hit = np.repeat(pos, nh)
     slot = c["hit_rows"]["slot"].astype(np.int64)
     out["adc_list"][pix_of_hit, slot] = c["hit_charge"]
     out["adc_ticks_list"][pix_of_hit, slot] = c["hit_rows"]["tick"]
     out["adc_digit"][pix_of_hit, slot] = c["hit_rows"]["adc"]
     # track slots: pixel after pixel
-    pix_of_trk = np.repeat(np.arange(n), nt)
+    pix_of_trk = np.repeat(pos, nt)
     m_of_trk = np.arange(int(nt.sum())) - np.repeat(np.cumsum(nt) - nt, nt)
     out["track_pixel_map"][pix_of_trk, m_of_trk] = c["track_segments"]
     if c.get("has_fractions"):
         fr = np.zeros((n, A, M))
-        per_hit = nt[pix_of_hit]                                    # fraction entries of every hit
+        per_hit = np.repeat(nt, nh)                                 # fraction entries of every hit
         h_of_f = np.repeat(np.arange(len(pix_of_hit)), per_hit)
         m_of_f = np.arange(int(per_hit.sum())) - np.repeat(np.cumsum(per_hit) - per_hit, per_hit)
         fr[pix_of_hit[h_of_f], slot[h_of_f], m_of_f] = c["fractions"]

@@ -558,3 +558,45 @@ def test_sum_light_wrapper_keeps_its_arguments_only_for_the_same_channel_array(m
     n_before = len(calls)
     ch.sum_light(5, 9, opc2, max_truth=3)
     assert len(calls) == n_before + 1 and calls[-1][5] == 3 and calls[-1][4] is False
+
+
+def test_expand_compact_lead_rows_equal_padding_each_batch():
+    """chain.expand_compact(lead_rows=True) hands the exporter, for a batch whose first unique pixel holds no hit, that hit-less row in
+    front of the batch's hit pixels: the same rows as expanding without it and padding every batch's slices afterwards (what the
+    driver did before, copying the fraction array once more); the default form is unchanged."""
+    from larndsim_amd import chain, packets
+    H.load_cfg("module0")
+    A = consts.sim.MAX_ADC_VALUES
+    rng = np.random.default_rng(1)
+    n = 60
+    batch = np.sort(rng.integers(0, 8, n))
+    nh, nt = rng.integers(1, min(4, A) + 1, n), rng.integers(1, 5, n)
+    starts = np.r_[True, batch[1:] != batch[:-1]]
+    first = np.zeros(n, bool)
+    first[starts] = rng.random(int(starts.sum())) < 0.5
+    assert first.any() and (~first[starts]).any()
+    hp = np.zeros((n, 5), np.int64)
+    hp[:, 0], hp[:, 1], hp[:, 2], hp[:, 3], hp[:, 4] = np.arange(n) * 3, rng.integers(0, 1000, n), batch, nh, nt | (first.astype(int) << 8)
+    n_hits = int(nh.sum())
+    hit_rows = np.zeros(n_hits, dtype=[('slot', 'i4'), ('tick', 'f8'), ('adc', 'f8')])
+    hit_rows['slot'] = np.concatenate([np.arange(k) for k in nh])
+    hit_rows['tick'], hit_rows['adc'] = rng.random(n_hits) * 100, rng.integers(70, 200, n_hits)
+    c = dict(hit_pixels=hp, hit_rows=hit_rows, hit_charge=rng.random(n_hits) * 1e4, track_segments=rng.integers(0, 500, int(nt.sum())),
+             has_fractions=True, fractions=rng.random(int(np.repeat(nt, nh).sum())))
+    old, new = chain.expand_compact(c), chain.expand_compact(c, lead_rows=True)
+    assert np.array_equal(old["row"], hp[:, 0]) and np.array_equal(old["first_of_batch"], first)
+    ped = packets._digitize0()
+    fill = dict(track_pixel_map=-1, adc_digit=ped, adc_ticks_list=0, current_fractions=0, adc_list=0)
+    for k in ("track_pixel_map", "adc_digit", "adc_ticks_list", "current_fractions", "adc_list", "unique_pix", "batch"):
+        blocks = []
+        for bb in np.unique(batch):
+            blk = old[k][old["batch"] == bb]
+            if not old["first_of_batch"][old["batch"] == bb][0]:
+                v = fill.get(k, blk[0])
+                blk = np.concatenate([np.full((1,) + blk.shape[1:], v, dtype=blk.dtype), blk])
+            blocks.append(blk)
+        ref = np.concatenate(blocks)
+        assert ref.shape == new[k].shape and np.array_equal(ref, new[k]), k
+    assert len(new["batch"]) == n + int((starts & ~first).sum())
+    assert new["first_of_batch"][np.r_[True, new["batch"][1:] != new["batch"][:-1]]].all()
+    assert (new["row"][new["row"] >= 0] == hp[:, 0]).all() and (new["row"] == -1).sum() == len(new["batch"]) - n
