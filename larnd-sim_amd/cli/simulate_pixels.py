@@ -284,11 +284,6 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     if not rand_seed:
         rand_seed = SEED
     print("Random seed:", rand_seed)
-    if int(getattr(sim, "WRITE_BATCH_SIZE", 1)) != 1:
-        # (cli/simulate_pixels.py:1207-1214 gathers WRITE_BATCH_SIZE batches per export; an export starts with the timestamp / sync /
-        # trigger packets of its first event, so the hits are the same and only those per-export packets are more here)
-        print(f"write_batch_size = {sim.WRITE_BATCH_SIZE} is not used: packets and light datasets are exported once per batch "
-              "(as with write_batch_size 1)")
     bad_list = None
     if bad_channels:
         import yaml
@@ -529,9 +524,35 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
     seg_ids_all = tracks["segment_id"].astype(np.int64)            # (once: a copy of the tail per batch is quadratic in a spill)
     trj_ids_all = tracks[traj_field].astype(np.int64)
 
+    # Batches per export (sim.WRITE_BATCH_SIZE, default 1; cli/simulate_pixels.py:1207-1214): the reference gathers that many
+    # batches' arrays and hands fee.export_to_hdf5 their concatenation (save_results, :179-258) -- one set of timestamp / sync /
+    # trigger packets per event of the export, clock-rollover state from its first row -- and exports what is left after the event
+    # loop.  A batch counts when it holds a pixel the chain returns rows for.
+    write_batch = max(int(getattr(sim, "WRITE_BATCH_SIZE", 1)), 1)
+    pending = []            # (event, arrays of the batch, its light triggers or None)
+
+    def flush_pending():
+        if not pending:
+            return
+        events = [p[0] for p in pending]
+        cat = [np.concatenate([p[1][k] for p in pending]) if len(pending) > 1 else pending[0][1][k] for k in range(7)]
+        uniq = np.unique(np.asarray(events))
+        ev_time = np.array([event_times[int(e) % sim.MAX_EVENTS_PER_FILE] for e in uniq])
+        if all(p[2] is None for p in pending):
+            # each event triggers once at perfect t0 (:218-222)
+            lt_times, lt_events, lt_mods = np.zeros(len(uniq)), uniq, np.ones(len(uniq))
+        else:
+            # the simulated triggers of the export's batches (:209-216); a batch without any keeps the perfect one
+            trip = [p[2] if p[2] is not None else (np.zeros(1), np.array([p[0]]), np.ones(1)) for p in pending]
+            lt_times, lt_events, lt_mods = (np.concatenate([np.atleast_1d(t[k]) for t in trip]) for k in range(3))
+        pk, assn = packets.build_packets(*cat, ev_time, light_trigger_times=lt_times, light_trigger_event_id=lt_events,
+                                         light_trigger_modules=lt_mods, bad_channels=bad_list, i_mod=i_mod)
+        out.append_packets(pk, assn)
+        res["n_packets"] += len(pk)
+        pending.clear()
+
     def export_chunk(r):
         """packets and association rows of one chain launch (`r`: the launch's per-pixel arrays)"""
-        # one export per batch, like save_results with WRITE_BATCH_SIZE = 1 (:179-258, 1207-1214)
         # the chain returns the unique pixels ordered by batch: a batch is a contiguous run (a view, not a 12 KB-per-pixel copy
         # of the backtracking array); an unordered result falls back to masks
         rb = r["batch"]
@@ -551,15 +572,11 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             event = table[int(bb)][0]
             announce_until(event)
             ev_ids = np.full(digit.shape, event)
-            ev_time = np.array([event_times[int(event) % sim.MAX_EVENTS_PER_FILE]])
-            # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger
-            lt_times, lt_events, lt_mods = light_trig_of.get((int(event), int(table[int(bb)][1])),
-                                                             (np.zeros(1), np.array([event]), np.ones(1)))
-            pk, assn = packets.build_packets(ev_ids, digit, ticks_b, upix_b, frac_b, track_ids, traj_ids, ev_time,
-                                             light_trigger_times=lt_times, light_trigger_event_id=lt_events,
-                                             light_trigger_modules=lt_mods, bad_channels=bad_list, i_mod=i_mod)
-            out.append_packets(pk, assn)
-            res["n_packets"] += len(pk)
+            # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger per event
+            pending.append((event, (ev_ids, digit, ticks_b, upix_b, frac_b, track_ids, traj_ids),
+                            light_trig_of.get((int(event), int(table[int(bb)][1])))))
+            if len(pending) >= write_batch:
+                flush_pending()
         res["n_hits"] += int((r["adc_list"] != 0).sum())
         if raw_arrays:
             r = {k: np.array(v) for k, v in r.items()}       # (views of page-locked buffers that later launches reuse)
@@ -596,6 +613,7 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         export_chunk(in_flight)
     if len(all_events):
         announce_until(all_events[-1])
+    flush_pending()                                  # (what is left after the event loop, :1219-1222)
     if raw_arrays and parts:
         for k in parts[0]:
             out.put(("raw/" if not m2m else f"raw_mod{i_mod - 1}/") + k, np.concatenate([p[k] for p in parts]))

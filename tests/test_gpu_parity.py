@@ -2014,6 +2014,76 @@ def test_cli_end_to_end(tmp_path):
         cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / "out2.npz"), config="2x2_mpvmpr")
 
 
+def test_cli_write_batch_size(tmp_path, monkeypatch):
+    """sim.WRITE_BATCH_SIZE (cli/simulate_pixels.py:1207-1222): the driver gathers that many batches per export.  module0
+    (self-triggered light: an export starts every event it holds with timestamp / sync / trigger packets; events cut into three
+    batches each).  With one batch per export and
+    with two (exports that cut events): the same data packets and association rows in the same order, fewer per-export timestamp / sync / trigger packets.
+    With more batches per export than the run has, everything is exported once after the event loop: the file ends with exactly
+    what the reference's hit loop (tests/packets_loop.py, pinned by the packet goldens) makes of the concatenated per-pixel
+    arrays."""
+    from larndsim_amd import packets
+    from packets_loop import build_packets_loop
+    cli = _load_cli()
+    H.load_cfg("module0")
+    assert consts.light.LIGHT_TRIG_MODE == 0 and not consts.sim.IS_SPILL_SIM
+    seg = synth.make_segments(200, seed=12, segs_per_event=50, max_track_len=6.0)
+    np.save(tmp_path / "in.npy", seg)
+    resp = synth.make_response("survey", response_sampling=consts.detector.RESPONSE_SAMPLING)
+    np.save(tmp_path / "resp.npy", resp)
+    real_load = consts.load_snapshot
+
+    def run(k, name):
+        def load(snap):
+            r = real_load(snap)
+            consts.sim.WRITE_BATCH_SIZE = k
+            consts.sim.BATCH_SIZE = 20           # an event's 50 segments in three batches: exports can cut an event
+            return r
+        monkeypatch.setattr(consts, "load_snapshot", load)
+        res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / name), config="module0",
+                                 response_file=str(tmp_path / "resp.npy"), rand_seed=5, raw_arrays=True)
+        monkeypatch.setattr(consts, "load_snapshot", real_load)
+        return res, np.load(tmp_path / name)
+
+    (_, o1), (_, o3), (_, oall) = run(1, "o1.npz"), run(2, "o2.npz"), run(1000, "oall.npz")
+    n_batches = len(np.unique(o1["raw__batch"]))
+    assert n_batches >= 6
+    for k in ("raw__unique_pix", "raw__adc_digit", "raw__adc_ticks_list", "raw__batch"):
+        assert np.array_equal(o1[k], o3[k]) and np.array_equal(o1[k], oall[k])
+    d1, d3, da = (o["packets"]["packet_type"] == 0 for o in (o1, o3, oall))
+    assert d1.sum() == d3.sum() == da.sum() > 100
+    for o, d in ((o3, d3), (oall, da)):
+        assert o["packets"][d].tobytes() == o1["packets"][d1].tobytes()
+        assert o["mc_packets_assn"][d].tobytes() == o1["mc_packets_assn"][d1].tobytes()
+    assert len(o1["packets"]) > len(o3["packets"]) > len(oall["packets"])
+    # one export of everything: rebuild its arguments from the raw arrays the way the driver does
+    H.load_cfg("module0", noise_zero=False)
+    consts.sim.BATCH_SIZE = 20
+    tr = cli.prepare_tracks(seg.copy())
+    tr = tr[batching.select_active_volume(tr, consts.detector.TPC_BORDERS)]
+    bid, order, table = batching.assign_batches(tr)
+    tr, bid = np.ascontiguousarray(tr[order]), bid[order]
+    rb, tpm = oall["raw__batch"], oall["raw__track_pixel_map"]
+    first_seg = np.searchsorted(bid[:int((bid >= 0).sum())], rb, side="left")     # a batch's rows count its segments from its first one
+    seg_of = np.where(tpm >= 0, first_seg[:, None] + np.maximum(tpm, 0), 0)
+    track_ids = np.where(tpm >= 0, tr["segment_id"].astype(np.int64)[seg_of], -1)
+    traj_field = "file_traj_id" if "file_traj_id" in tr.dtype.names else "traj_id"
+    traj_ids = np.where(tpm >= 0, tr[traj_field].astype(np.int64)[seg_of], -1)
+    events = np.array([t[0] for t in table])[rb]
+    ev_ids = np.repeat(events[:, None], oall["raw__adc_digit"].shape[1], axis=1)
+    uniq = np.unique(events)
+    num_evids = int(tr[consts.sim.EVENT_SEPARATOR].max() % consts.sim.MAX_EVENTS_PER_FILE) + 1
+    event_times = cli.gen_event_times(num_evids, np.random.default_rng(5))          # the driver's, from rand_seed
+    ev_time = event_times[uniq % consts.sim.MAX_EVENTS_PER_FILE]
+    pk, assn = build_packets_loop(ev_ids, oall["raw__adc_digit"], oall["raw__adc_ticks_list"], oall["raw__unique_pix"],
+                                  oall["raw__current_fractions"], track_ids, traj_ids, ev_time,
+                                  light_trigger_times=np.zeros(len(uniq)), light_trigger_event_id=uniq,
+                                  light_trigger_modules=np.ones(len(uniq)))
+    assert len(pk) > da.sum()
+    assert oall["packets"][-len(pk):].tobytes() == pk.tobytes()
+    assert oall["mc_packets_assn"][-len(pk):].tobytes() == assn.tobytes()
+
+
 def test_cli_module_variation(tmp_path):
     """--config 2x2: the reference's module-variation keyword (per-module constants: module 3 has the 3.88 mm pixel layout,
     all four 50 ns response sampling).  The driver's module loop (cli/simulate_pixels.py:676-715): every module simulated
