@@ -22,6 +22,16 @@ with_light = len(sys.argv) > 3 and sys.argv[3] == "light"
 spec = importlib.util.spec_from_file_location("ldsim_cli", os.path.join(REPO, "larnd-sim_amd", "cli", "simulate_pixels.py"))
 cli = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(cli)
+write_batch = int(os.environ.get("LDSIM_WRITE_BATCH_SIZE", "0"))      # simulation property write_batch_size (0: the configuration's)
+if write_batch:
+    from larndsim_amd import consts
+    _load = consts.load_snapshot
+
+    def _load_with_write_batch(name):
+        r = _load(name)
+        consts.sim.WRITE_BATCH_SIZE = write_batch
+        return r
+    consts.load_snapshot = _load_with_write_batch
 H.load_cfg(cfg)
 seg = synth.make_segments(n, seed=synth.SEED_BASE + 2, segs_per_event=5000)
 with tempfile.TemporaryDirectory() as d:
@@ -38,5 +48,5 @@ with tempfile.TemporaryDirectory() as d:
     res = cli.run_simulation(os.path.join(d, "in.npy"), os.path.join(d, "out.npz"), **kw)
     pr.disable()
     dt = time.time() - t0
-print(f"{cfg}{' + light' if with_light else ''}: {n} segments in {dt:.2f} s = {n / dt:.3g} segments/s; packets {res.get('n_packets')}")
+print(f"{cfg}{' + light' if with_light else ''}{f', write_batch_size {write_batch}' if write_batch else ''}: {n} segments in {dt:.2f} s = {n / dt:.3g} segments/s; packets {res.get('n_packets')}")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
