@@ -535,7 +535,13 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         if not pending:
             return
         events = [p[0] for p in pending]
-        cat = [np.concatenate([p[1][k] for p in pending]) if len(pending) > 1 else pending[0][1][k] for k in range(7)]
+        cat = [np.concatenate([p[1][k] for p in pending]) if len(pending) > 1 else pending[0][1][k] for k in range(7) if k != 4]
+        # (the fraction rows, 12 KB per pixel: batches that follow each other in one launch's array are one slice of it)
+        src = [p[3] for p in pending]
+        one_run = all(a is not None and b is not None and a[0] is b[0] and a[2] == b[1] for a, b in zip(src[:-1], src[1:]))
+        frac = src[0][0][src[0][1]:src[-1][2]] if (one_run and src[0] is not None) else \
+            (np.concatenate([p[1][4] for p in pending]) if len(pending) > 1 else pending[0][1][4])
+        cat.insert(4, frac)
         uniq = np.unique(np.asarray(events))
         ev_time = np.array([event_times[int(e) % sim.MAX_EVENTS_PER_FILE] for e in uniq])
         if all(p[2] is None for p in pending):
@@ -574,9 +580,15 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             ev_ids = np.full(digit.shape, event)
             # light triggers embedded in the charge stream (:209-221): the simulated ones, else one perfect trigger per event
             pending.append((event, (ev_ids, digit, ticks_b, upix_b, frac_b, track_ids, traj_ids),
-                            light_trig_of.get((int(event), int(table[int(bb)][1])))))
+                            light_trig_of.get((int(event), int(table[int(bb)][1]))),
+                            (r["current_fractions"], m.start, m.stop) if ordered else None))
             if len(pending) >= write_batch:
                 flush_pending()
+        # batches that wait for the next launch's: their rows are views of this launch's arrays, which a later download may
+        # overwrite (page-locked buffers are reused) -- keep copies
+        for i, p in enumerate(pending):
+            if p[3] is not None:
+                pending[i] = (p[0], tuple(np.array(a) for a in p[1]), p[2], None)
         res["n_hits"] += int((r["adc_list"] != 0).sum())
         if raw_arrays:
             r = {k: np.array(v) for k, v in r.items()}       # (views of page-locked buffers that later launches reuse)

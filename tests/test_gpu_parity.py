@@ -2041,7 +2041,8 @@ def test_cli_write_batch_size(tmp_path, monkeypatch):
             return r
         monkeypatch.setattr(consts, "load_snapshot", load)
         res = cli.run_simulation(str(tmp_path / "in.npy"), str(tmp_path / name), config="module0",
-                                 response_file=str(tmp_path / "resp.npy"), rand_seed=5, raw_arrays=True)
+                                 response_file=str(tmp_path / "resp.npy"), rand_seed=5, raw_arrays=True,
+                                 chunk_segments=60)       # four chain launches: exports gather batches of different launches
         monkeypatch.setattr(consts, "load_snapshot", real_load)
         return res, np.load(tmp_path / name)
 
