@@ -1015,7 +1015,11 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
     CK(ldsim_ensure_buf(ctx, &ctx->light_opc, (size_t)n_det * 4));
     HIPCHK(hipMemcpyAsync(ctx->light_opc.p, op_channel, (size_t)n_det * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));              // (pageable source: the copy must have left it before the call returns)
-    ctx->h_opc.assign(op_channel, op_channel + n_det);
+    try {
+      ctx->h_opc.assign(op_channel, op_channel + n_det);
+    } catch (const std::exception&) {      // (nothing may throw across the C ABI; without the copy the list is sent again next time)
+      ctx->h_opc.clear();
+    }
     ctx->h_opc_n_out = ctx->light_n_out;
   }
   HIPCHK(hipEventRecord(ctx->evl[2], st));
