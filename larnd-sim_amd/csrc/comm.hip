@@ -34,6 +34,7 @@ extern "C" int ldsim_comm_unique_id(void* id) {
 }
 
 extern "C" int ldsim_comm_init(ldsim_ctx* ctx, const void* id, int32_t rank, int32_t world) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx && id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
   NEEDC(!ctx->comm, "communicator already initialised");
   HIPCHK(hipSetDevice(ctx->device));
@@ -50,6 +51,7 @@ extern "C" int ldsim_comm_init(ldsim_ctx* ctx, const void* id, int32_t rank, int
 // ranks in the communicator as RCCL reports them (ncclCommCount / ncclCommUserRank): lets a caller check that every rank of the
 // launch really joined, instead of trusting the environment it was started with
 extern "C" int ldsim_comm_count(ldsim_ctx* ctx, int32_t* n_ranks, int32_t* rank) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx && ctx->comm && n_ranks, "no communicator / null argument");
   int n = 0, r = 0;
   NCCLCHK(ncclCommCount((ncclComm_t)ctx->comm, &n));
@@ -60,6 +62,7 @@ extern "C" int ldsim_comm_count(ldsim_ctx* ctx, int32_t* n_ranks, int32_t* rank)
 }
 
 extern "C" int ldsim_comm_destroy(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   if (!ctx || !ctx->comm) return 0;
   (void)hipStreamSynchronize(ctx->stream);
   NCCLCHK(ncclCommDestroy((ncclComm_t)ctx->comm));
@@ -70,6 +73,7 @@ extern "C" int ldsim_comm_destroy(ldsim_ctx* ctx) {
 
 // value (host, in/out) reduced over the ranks: op 0 = sum, 1 = max.  Doubles as the barrier (every rank leaves after all entered).
 extern "C" int ldsim_comm_allreduce_f64(ldsim_ctx* ctx, double* value, int32_t op) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx && value && ctx->comm, "no communicator");
   HIPCHK(hipSetDevice(ctx->device));
   int rc = ldsim_ensure_buf(ctx, &ctx->comm_tmp, 64 + 8 * (size_t)ctx->comm_world);
@@ -85,6 +89,7 @@ extern "C" int ldsim_comm_allreduce_f64(ldsim_ctx* ctx, double* value, int32_t o
 // Keep the compact hit rows of the chain calls of one pass: reset != 0 starts a new pass, then the last chain call's rows
 // are appended (device-to-device, on the ctx stream, before the next chain call reuses its buffer).
 extern "C" int ldsim_hits_accumulate(ldsim_ctx* ctx, int32_t reset) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx, "null ctx");
   HIPCHK(hipSetDevice(ctx->device));
   if (reset) ctx->hits_acc_rows = 0;
@@ -110,6 +115,7 @@ extern "C" int ldsim_hits_accumulate(ldsim_ctx* ctx, int32_t reset) {
 // All-gather-v of the accumulated rows.  counts[world] (host, may be NULL) receives every rank's row count; *gathered is a
 // device pointer owned by the ctx (valid until the next call) holding the rows of rank 0, 1, .. back to back.
 extern "C" int ldsim_comm_allgather_hits(ldsim_ctx* ctx, void** gathered, int64_t* total_rows, int64_t* counts) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx && gathered && total_rows && ctx->comm, "no communicator / null argument");
   HIPCHK(hipSetDevice(ctx->device));
   const int W = ctx->comm_world;
@@ -150,6 +156,7 @@ extern "C" int ldsim_comm_allgather_hits(ldsim_ctx* ctx, void** gathered, int64_
 
 // rows [0, n) of the gathered buffer to host (tests / the driver's output writer)
 extern "C" int ldsim_comm_gathered_download(ldsim_ctx* ctx, void* rows, int64_t n) {
+  LDSIM_ENTER(ctx);
   NEEDC(ctx && (rows || n == 0), "null argument");
   if (n == 0) return 0;
   NEEDC((size_t)n * 24 <= ctx->hits_all.bytes, "more rows requested than gathered");

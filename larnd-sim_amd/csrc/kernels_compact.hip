@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) compact_fill_kernel(const int32_t* __rest
 
 // gathers the compact form of the last chain launch in HBM; sizes[4] = hit pixels, hits, track entries, fraction entries
 extern "C" int ldsim_chain_compact_build(ldsim_ctx* ctx, int64_t* sizes) {
+  LDSIM_ENTER(ctx);
   if (!ctx || !sizes) { ldsim_set_error("null argument"); return LDSIM_EINVAL; }
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t U = ctx->chain_U;
@@ -104,6 +105,7 @@ extern "C" int ldsim_chain_compact_build(ldsim_ctx* ctx, int64_t* sizes) {
 // the compact arrays to host buffers sized from ldsim_chain_compact_build's sizes; any pointer may be NULL
 extern "C" int ldsim_chain_compact_download(ldsim_ctx* ctx, int32_t* hit_pixels /* [n_hp][5] */, int64_t* track_segments,
                                             void* hit_rows /* [n_hits] 24-byte rows */, double* hit_charge, double* fractions) {
+  LDSIM_ENTER(ctx);
   if (!ctx) { ldsim_set_error("null ctx"); return LDSIM_EINVAL; }
   if (ctx->cpt_gen != ctx->out_gen) {
     ldsim_set_error("ldsim_chain_compact_build has not run for the last chain launch");

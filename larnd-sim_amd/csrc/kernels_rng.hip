@@ -127,6 +127,7 @@ int rng_launch_advance(ldsim_ctx* ctx, int64_t U, const int32_t* n_draws) {
 
 // numba.cuda.random.create_xoroshiro128p_states(n, seed) (cli/simulate_pixels.py:92-104,396)
 extern "C" int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states) {
+  LDSIM_ENTER(ctx);
   if (!ctx || n_states < 0) {
     ldsim_set_error("bad argument");
     return LDSIM_EINVAL;
@@ -151,6 +152,7 @@ extern "C" int ldsim_rng_seed(ldsim_ctx* ctx, uint64_t seed, int64_t n_states) {
 // maybe_create_rng_states(n, seed, rng_states) (cli/simulate_pixels.py:92-104): no table yet -> create n states from `seed`;
 // a shorter table -> append create_xoroshiro128p_states(n - len, seed); long enough -> untouched
 extern "C" int ldsim_rng_extend(ldsim_ctx* ctx, int64_t n_states, uint64_t seed) {
+  LDSIM_ENTER(ctx);
   if (!ctx || n_states < 0) {
     ldsim_set_error("bad argument");
     return LDSIM_EINVAL;
@@ -169,6 +171,7 @@ extern "C" int64_t ldsim_rng_count(ldsim_ctx* ctx) { return ctx && ctx->rng_seed
 
 // forget the table: noisy calls are refused again until the next ldsim_rng_seed
 extern "C" int ldsim_rng_clear(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   if (!ctx) return 0;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->d_rng.p) (void)hipFree(ctx->d_rng.p);
@@ -180,6 +183,7 @@ extern "C" int ldsim_rng_clear(ldsim_ctx* ctx) {
 
 // states [0, n) as they stand (s0, s1 pairs), for tests and for a driver that wants to checkpoint them
 extern "C" int ldsim_rng_states_download(ldsim_ctx* ctx, uint64_t* states, int64_t n) {
+  LDSIM_ENTER(ctx);
   if (!ctx || !states || n < 0 || n > ctx->rng_n) {
     ldsim_set_error("bad argument (the table holds %lld states)", ctx ? (long long)ctx->rng_n : 0LL);
     return LDSIM_EINVAL;

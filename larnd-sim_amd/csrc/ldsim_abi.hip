@@ -210,6 +210,7 @@ extern "C" int ldsim_ctx_create(int device, const LdsimConsts* consts, ldsim_ctx
 }
 
 extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && consts, "null argument");
   CK(light_join(ctx));
   NEED(consts->n_tpc >= 0 && consts->n_tpc <= LDSIM_MAX_TPC, "n_tpc out of range");
@@ -224,6 +225,15 @@ extern "C" int ldsim_set_consts(ldsim_ctx* ctx, const LdsimConsts* consts) {
 
 extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   if (!ctx) return 0;
+  {
+    // a ctx another thread is inside is not torn down under it; the claim is kept until the object is gone
+    const std::thread::id me = std::this_thread::get_id();
+    std::thread::id none{};
+    if (ctx->owner.load(std::memory_order_acquire) != me && !ctx->owner.compare_exchange_strong(none, me, std::memory_order_acq_rel)) {
+      ldsim_set_error("ctx in use by another thread: not destroyed");
+      return LDSIM_ESTATE;
+    }
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
@@ -266,6 +276,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
 }
 
 extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   CK(light_join(ctx));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -275,6 +286,7 @@ extern "C" int ldsim_synchronize(ldsim_ctx* ctx) {
 static void resp_support_update(ldsim_ctx* ctx);
 
 extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && name, "null argument");
   if (!strcmp(name, "prune_log")) ctx->prune_log = value;
   else if (!strcmp(name, "tail_log")) ctx->tail_log = value;
@@ -314,11 +326,14 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "numba_f32")) ctx->numba_f32 = value != 0;
   else if (!strcmp(name, "mc_current")) ctx->mc_current = value != 0;
   else if (!strcmp(name, "quad_accuracy_log10")) {
-    // relative quadrature error of the weights stage as a power of ten of the peak weight: 10 (default) or 12 (fits of
-    // tools/quad_nodes.py: N = ceil(4.8 + 1.6 r) / ceil(6 + 1.9 r) nodes for a segment r Gaussian widths long)
-    if (value == 10) { ctx->quad_n0 = 4.8; ctx->quad_slope = 1.6; }
-    else if (value == 12) { ctx->quad_n0 = 6.0; ctx->quad_slope = 1.9; }
-    else { ldsim_set_error("quad_accuracy_log10 must be 10 or 12"); return LDSIM_EINVAL; }
+    // relative quadrature error of the tables / weights stage as a power of ten of the peak weight (fits of tools/quad_nodes.py,
+    // upper envelopes: N = ceil(n0 + slope r) nodes for a segment r Gaussian widths long)
+    static const struct { int acc; double n0, slope; } rules[] = {
+      {7, 3.4, 1.38}, {8, 3.8, 1.46}, {9, 4.4, 1.54}, {10, 4.8, 1.6}, {12, 6.0, 1.9}};
+    bool ok = false;
+    for (const auto& r : rules)
+      if (value == r.acc) { ctx->quad_n0 = r.n0; ctx->quad_slope = r.slope; ok = true; }
+    if (!ok) { ldsim_set_error("quad_accuracy_log10 must be 7, 8, 9, 10 or 12"); return LDSIM_EINVAL; }
   }
   else if (!strcmp(name, "quad_max_nodes")) {
     if (!(value >= 8 && value <= 256)) { ldsim_set_error("quad_max_nodes must be in [8, 256]"); return LDSIM_EINVAL; }
@@ -356,17 +371,20 @@ static int set_pixel_table(ldsim_ctx* ctx, double** slot, const int32_t* keys, c
 
 extern "C" int ldsim_set_pixel_thresholds(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n,
                                           double default_value) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   return set_pixel_table(ctx, &ctx->d_pix_thr, keys, values, n, default_value);
 }
 
 extern "C" int ldsim_set_pixel_gains(ldsim_ctx* ctx, const int32_t* keys, const double* values, int64_t n,
                                      double default_value) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   return set_pixel_table(ctx, &ctx->d_pix_gain, keys, values, n, default_value);
 }
 
 extern "C" int ldsim_clear_pixel_tables(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -394,6 +412,7 @@ static void resp_support_update(ldsim_ctx* ctx) {
 }
 
 extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_t ni, int32_t nj, int32_t nk) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && response && ni > 0 && nj > 0 && nk > 0, "bad response table");
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->d_resp) HIPCHK(hipFree(ctx->d_resp));
@@ -416,6 +435,7 @@ extern "C" int ldsim_set_response(ldsim_ctx* ctx, const double* response, int32_
 }
 
 extern "C" int ldsim_set_light_channels(ldsim_ctx* ctx, const double* eff, const int32_t* ch2tpc, int32_t n) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && n >= 0, "bad light channels");
   CK(light_join(ctx));
   if (ctx->d_eff) HIPCHK(hipFree(ctx->d_eff));
@@ -435,6 +455,7 @@ extern "C" int ldsim_set_light_channels(ldsim_ctx* ctx, const double* eff, const
 extern "C" int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const float* t0_avg,
                                    const float* time_dist, int32_t nx, int32_t ny, int32_t nz, int32_t ndet,
                                    int32_t nprof) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && vis && t0 && t0_avg && time_dist, "null LUT plane");
   CK(light_join(ctx));
   size_t nv = (size_t)nx * ny * nz * ndet;
@@ -521,6 +542,7 @@ static int download_tracks(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimT
 
 extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                      const int32_t* batch_id) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   // validated into a local copy: the ctx keeps describing the segments that are resident until the new ones really are
   std::vector<int32_t> ids;
@@ -557,12 +579,14 @@ extern "C" int ldsim_segments_upload(ldsim_ctx* ctx, const void* tracks, int64_t
 }
 
 extern "C" int ldsim_segments_download(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && tracks && layout, "null argument");
   NEED_RESIDENT(ctx);
   return download_tracks(ctx, tracks, n, layout);
 }
 
 extern "C" int ldsim_segments_reset(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   NEED_RESIDENT(ctx);
   NEED(ctx->seg.n == 0 || ctx->raw.p, "no uploaded records");
@@ -592,6 +616,7 @@ static int run_quench_drift(ldsim_ctx* ctx, int mode, int do_q, int do_d) {
 }
 
 extern "C" int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   NEED_RESIDENT(ctx);
   CK(light_join(ctx));
@@ -600,12 +625,14 @@ extern "C" int ldsim_dev_quench_drift(ldsim_ctx* ctx, int32_t mode) {
 
 // ---- (1) stage-by-stage host-buffer API ---------------------------------------------------------------------------
 extern "C" int ldsim_quench(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout, int32_t mode) {
+  LDSIM_ENTER(ctx);
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   CK(run_quench_drift(ctx, mode, 1, 0));
   return download_tracks(ctx, tracks, n, layout);
 }
 
 extern "C" int ldsim_drift(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimTrackLayout* layout) {
+  LDSIM_ENTER(ctx);
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   CK(run_quench_drift(ctx, 2, 0, 1));
   return download_tracks(ctx, tracks, n, layout);
@@ -613,6 +640,7 @@ extern "C" int ldsim_drift(ldsim_ctx* ctx, void* tracks, int64_t n, const LdsimT
 
 extern "C" int ldsim_max_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                 int64_t* n_max_pixels) {
+  LDSIM_ENTER(ctx);
   NEED(n_max_pixels, "null output");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   CK(ldsim_ensure(ctx, SB_MISC, MISC_BYTES));
@@ -629,6 +657,7 @@ extern "C" int ldsim_max_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, c
 extern "C" int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                 int32_t radius, int32_t* active, int32_t max_active, int32_t* neigh, int32_t* nrad,
                                 int32_t P, double* n_list) {
+  LDSIM_ENTER(ctx);
   NEED(active && neigh && nrad && max_active >= 0 && P >= 0 && radius >= 0, "bad get_pixels arguments");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   size_t ba = (size_t)n * max_active * 4, bn = (size_t)n * P * 4;
@@ -652,6 +681,7 @@ extern "C" int ldsim_get_pixels(ldsim_ctx* ctx, const void* tracks, int64_t n, c
 
 extern "C" int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                     double* track_starts, int64_t* time_max) {
+  LDSIM_ENTER(ctx);
   NEED(track_starts && time_max, "null output");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
   CK(ldsim_ensure(ctx, SB_STARTS, (size_t)n * 8 + 8));
@@ -669,6 +699,7 @@ extern "C" int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t 
 
 extern "C" int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                     const int32_t* pixels, int32_t P, float* signals, int32_t T) {
+  LDSIM_ENTER(ctx);
   NEED(pixels && signals && P >= 0 && T >= 0, "bad tracks_current arguments");
   NEED(ctx && ctx->d_resp, "no response table set (ldsim_set_response)");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
@@ -684,6 +715,7 @@ extern "C" int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t 
 }
 
 extern "C" int ldsim_tracks_current_stats(ldsim_ctx* ctx, LdsimChainStats* stats) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && stats, "null argument");
   *stats = ctx->stage_stats;
   return 0;
@@ -691,6 +723,7 @@ extern "C" int ldsim_tracks_current_stats(ldsim_ctx* ctx, LdsimChainStats* stats
 
 extern "C" int ldsim_tracks_current_mc(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                        const int32_t* pixels, int32_t P, float* signals, int32_t T) {
+  LDSIM_ENTER(ctx);
   NEED(pixels && signals && P >= 0 && T >= 0, "bad tracks_current_mc arguments");
   NEED(ctx && ctx->d_resp, "no response table set (ldsim_set_response)");
   CK(upload_tracks(ctx, tracks, n, layout, nullptr));
@@ -708,6 +741,7 @@ extern "C" int ldsim_tracks_current_mc(ldsim_ctx* ctx, const void* tracks, int64
 extern "C" int ldsim_track_pixel_map(ldsim_ctx* ctx, const int32_t* unique_pix, int64_t U, const int32_t* pixels,
                                      const int32_t* distances, int64_t n, int32_t P, int32_t max_distance,
                                      int64_t* track_pixel_map, int32_t M) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && track_pixel_map && (unique_pix || U == 0), "bad track_pixel_map arguments");
   HIPCHK(hipSetDevice(ctx->device));
   Tmp du, dp, dd, dm;
@@ -728,6 +762,7 @@ extern "C" int ldsim_track_pixel_map(ldsim_ctx* ctx, const int32_t* unique_pix, 
 extern "C" int ldsim_sum_pixel_signals(ldsim_ctx* ctx, const float* signals, int64_t n, int32_t P, int32_t T,
                                        const double* track_starts, const int64_t* pim, const int64_t* tpm, int32_t M,
                                        int64_t U, double* pixels_signals, double* pts, double* overflow) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && signals && track_starts && pim && tpm && pixels_signals && overflow, "null argument");
   HIPCHK(hipSetDevice(ctx->device));
   const int NT = ctx->h_consts.n_time_ticks;
@@ -756,6 +791,7 @@ extern "C" int ldsim_sum_pixel_signals(ldsim_ctx* ctx, const float* signals, int
 extern "C" int ldsim_get_adc_values(ldsim_ctx* ctx, const double* ps, const double* pts, int64_t U, int32_t NT,
                                     int32_t M, const double* time_ticks, int32_t n_time_ticks, double time_padding,
                                     const double* thresholds, double* adc_list, double* adc_ticks, double* fractions) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && ps && thresholds && adc_list && adc_ticks, "null argument");
   NEED(n_time_ticks == NT + 1 && time_ticks, "time_ticks must be linspace(0, stop, N_t+1)");
   HIPCHK(hipSetDevice(ctx->device));
@@ -791,6 +827,7 @@ extern "C" int ldsim_get_adc_values(ldsim_ctx* ctx, const double* ps, const doub
 }
 
 extern "C" int ldsim_digitize(ldsim_ctx* ctx, const double* integral, int64_t n, const double* gain, double* adcs) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && integral && adcs, "null argument");
   HIPCHK(hipSetDevice(ctx->device));
   Tmp di, dg, dout;
@@ -806,6 +843,7 @@ extern "C" int ldsim_digitize(ldsim_ctx* ctx, const double* integral, int64_t n,
 
 extern "C" int ldsim_light_incidence(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                                      int32_t n_out, float* nph, float* t0det, int32_t* voxel) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && nph && t0det && voxel && n_out >= 0, "null argument");
   NEED(ctx->d_lut_vis && ctx->d_eff, "light LUT / channel tables not set");
   NEED(n_out <= ctx->n_light_ch, "more output channels than light channels configured");
@@ -831,6 +869,7 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
                                        const int32_t* op_channel, int32_t n_det, const int32_t* sorted_indices,
                                        double start_time, int32_t n_ticks, float* out, int64_t* true_id,
                                        double* true_ph, int32_t max_truth) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && voxel && track_id && nph && op_channel && sorted_indices && out, "null argument");
   NEED(ctx->d_lut_t0avg, "light LUT not set");
   NEED(max_truth == 0 || (true_id && true_ph), "truth arrays missing");
@@ -869,6 +908,7 @@ extern "C" int ldsim_sum_light_signals(ldsim_ctx* ctx, const void* tracks, int64
 // a17 over all resident segments (cli/simulate_pixels.py:795-797, after quench + drift): n_photons_det / t0_det / voxel stay
 // in HBM for the per-batch photon sums.
 extern "C" int ldsim_dev_light_incidence(ldsim_ctx* ctx, int32_t n_out) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && n_out > 0, "bad argument");
   NEED_RESIDENT(ctx);
   NEED(ctx->d_lut_vis && ctx->d_eff, "light LUT / channel tables not set");
@@ -905,6 +945,7 @@ extern "C" int ldsim_dev_light_incidence(ldsim_ctx* ctx, int32_t n_out) {
 
 extern "C" int ldsim_dev_light_incidence_download(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* nph,
                                                   float* t0det, int32_t* voxel) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   NEED_LIGHT_INC(ctx);
   NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
@@ -925,6 +966,7 @@ extern "C" int ldsim_dev_light_incidence_download(ldsim_ctx* ctx, int64_t seg_be
 // the expression so that its scalar typing stays the caller's
 extern "C" int ldsim_dev_light_t0_range(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, float* t0_min, float* t0_max,
                                         int32_t* any) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && t0_min && t0_max && any, "null argument");
   NEED_LIGHT_INC(ctx);
   NEED(seg_begin >= 0 && seg_end >= seg_begin && seg_end <= ctx->seg.n, "segment range outside the resident store");
@@ -959,6 +1001,7 @@ static int light_sum_time(ldsim_ctx* ctx) {
 extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, const int32_t* op_channel,
                                    int32_t n_det, const int64_t* segment_track_id, int32_t max_truth, double start_time,
                                    int32_t n_ticks) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && op_channel && n_det > 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
   NEED_LIGHT_INC(ctx);
   NEED(ctx->d_lut_t0avg, "light LUT not set");
@@ -1129,6 +1172,7 @@ extern "C" int ldsim_dev_sum_light(ldsim_ctx* ctx, int64_t seg_begin, int64_t se
 
 extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc, int64_t* true_track_id,
                                         double* true_photons) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   CK(light_join(ctx));
   const size_t bo = (size_t)ctx->light_sum_ndet * ctx->light_sum_nticks;
@@ -1145,6 +1189,7 @@ extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc,
 }
 
 extern "C" int ldsim_light_kernel_ms(ldsim_ctx* ctx, double* incidence_ms, double* sum_ms) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   if (incidence_ms) *incidence_ms = ctx->ms_light_inc;
   if (sum_ms) {
@@ -1230,6 +1275,7 @@ static int light_response_stage(ldsim_ctx* ctx, bool response, const float* inc,
 extern "C" int ldsim_scintillation_effect(ldsim_ctx* ctx, const float* light_sample_inc, const int64_t* true_track_id,
                                           const double* true_photons, int32_t n_det, int32_t n_ticks, int32_t max_truth,
                                           float* scint, int64_t* scint_true_track_id, double* scint_true_photons) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && light_sample_inc && scint && n_det >= 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
   NEED(max_truth == 0 || (true_track_id && true_photons && scint_true_track_id && scint_true_photons),
        "truth arrays missing");
@@ -1248,6 +1294,7 @@ extern "C" int ldsim_light_detector_response(ldsim_ctx* ctx, const float* light_
                                              int32_t max_truth, const double* light_gain, const double* impulse_model,
                                              int32_t n_impulse, float* response, int64_t* response_true_track_id,
                                              double* response_true_photons) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && light_sample_inc && response && light_gain && n_det >= 0 && n_ticks >= 0 && max_truth >= 0, "bad argument");
   NEED(max_truth == 0 || (true_track_id && true_photons && response_true_track_id && response_true_photons),
        "truth arrays missing");
@@ -1269,6 +1316,7 @@ int light_launch_stat_fluct(ldsim_ctx* ctx, const float* inc, float* out, int64_
 
 extern "C" int ldsim_dev_light_response(ldsim_ctx* ctx, const double* light_gain, const double* impulse_model,
                                         int32_t n_impulse, int32_t fluctuate) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && light_gain, "bad argument");
   NEED(ctx->light_sum_ndet > 0, "no resident photon sum (ldsim_dev_sum_light)");
   CK(light_join(ctx));
@@ -1343,6 +1391,7 @@ extern "C" int ldsim_dev_light_response(ldsim_ctx* ctx, const double* light_gain
 
 extern "C" int ldsim_dev_light_response_download(ldsim_ctx* ctx, float* scint, float* disc, float* response,
                                                  int64_t* response_true_track_id, double* response_true_photons) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   NEED(ctx->light_resp_valid, "no resident detector response (ldsim_dev_light_response)");
   const size_t bo = (size_t)ctx->light_sum_ndet * ctx->light_sum_nticks, bt = bo * (size_t)ctx->light_sum_truth;
@@ -1358,6 +1407,7 @@ extern "C" int ldsim_dev_light_response_download(ldsim_ctx* ctx, float* scint, f
 }
 
 extern "C" int ldsim_light_response_ms(ldsim_ctx* ctx, double* scint_ms, double* fluct_ms, double* response_ms) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   if (scint_ms) *scint_ms = ctx->ms_light_resp[0];
   if (fluct_ms) *fluct_ms = ctx->ms_light_resp[1];
@@ -1368,6 +1418,7 @@ extern "C" int ldsim_light_response_ms(ldsim_ctx* ctx, double* scint_ms, double*
 // ---- (2) chain -------------------------------------------------------------------------------------------------------
 extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int32_t want_fractions,
                                   LdsimChainStats* stats) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   NEED(ctx->d_resp, "no response table set (ldsim_set_response)");
   NEED_RESIDENT(ctx);
@@ -1387,6 +1438,7 @@ extern "C" int ldsim_charge_chain(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg
 extern "C" int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
                                     double* adc_list, double* adc_ticks, double* adc_digit, int64_t* tpm,
                                     double* fractions) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   const int64_t U = ctx->chain_U;
   if (capacity < U) {
@@ -1417,6 +1469,7 @@ extern "C" int ldsim_chain_download(ldsim_ctx* ctx, int64_t capacity, int32_t* u
 extern "C" int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int32_t* unique_pix, int32_t* batch,
                                           double* adc_list, double* adc_ticks, double* adc_digit, int64_t* tpm,
                                           double* fractions) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   const int64_t U = ctx->chain_U;
   if (capacity < U) {
@@ -1451,6 +1504,7 @@ extern "C" int ldsim_chain_download_async(ldsim_ctx* ctx, int64_t capacity, int3
 }
 
 extern "C" int ldsim_chain_download_wait(ldsim_ctx* ctx) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   if (ctx->copy_pending) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1461,6 +1515,7 @@ extern "C" int ldsim_chain_download_wait(ldsim_ctx* ctx) {
 }
 
 extern "C" int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t* n_rows, int32_t* row_bytes) {
+  LDSIM_ENTER(ctx);
   NEED(ctx && dev_rows && n_rows && row_bytes, "null argument");
   *dev_rows = ctx->scratch[SB_HITS].p;
   *n_rows = ctx->chain_hits;
@@ -1469,6 +1524,7 @@ extern "C" int ldsim_chain_compact_hits(ldsim_ctx* ctx, void** dev_rows, int64_t
 }
 
 extern "C" int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   if (current_ms) *current_ms = ctx->ms_current;
   if (adc_ms) *adc_ms = ctx->ms_adc;
@@ -1477,6 +1533,7 @@ extern "C" int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double*
 }
 
 extern "C" int ldsim_chain_kernel_ms_detail(ldsim_ctx* ctx, double* weights_ms, double* mac_ms, double* fallback_ms) {
+  LDSIM_ENTER(ctx);
   NEED(ctx, "null ctx");
   if (weights_ms) *weights_ms = ctx->ms_weights;
   if (mac_ms) *mac_ms = ctx->ms_mac;

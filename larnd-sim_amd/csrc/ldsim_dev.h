@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <exception>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldsim.h"
@@ -100,6 +102,11 @@ struct LightAct {
 };
 
 struct ldsim_ctx {
+  // The thread inside an entry point of this ctx (CtxEnter below): a ctx is thread-compatible, not thread-safe -- a second
+  // thread entering while a call is in progress gets LDSIM_ESTATE before it touches any buffer (two threads in one ctx once
+  // freed the same scratch buffer twice under running kernels: GPU memory access fault, gpurun_out/r03_h25.log).
+  std::atomic<std::thread::id> owner{};
+  int owner_depth = 0;          // entry points call each other (ldsim_ctx_create -> ldsim_set_consts ...): re-entrant for the owner
   int device = 0;
   hipStream_t stream = nullptr;
   LdsimConsts h_consts;
@@ -155,6 +162,7 @@ struct ldsim_ctx {
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2
   double* d_glw = nullptr;
   int gl_nmax = 0;
+  int n_cu = 0;                     // compute units of the device (persistent grids)
   double wbuf_learned = 0;          // high-water demand per pair seen so far (x1.25): later calls size the pool with it
   int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments
@@ -228,12 +236,40 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN, SB_GWORK
 };
 
 void ldsim_set_error(const char* fmt, ...);
 int ldsim_ensure(ldsim_ctx* ctx, int slot, size_t bytes);
 int ldsim_ensure_buf(ldsim_ctx* ctx, DevBuf* b, size_t bytes);
+
+// Claims the ctx for the calling thread for the duration of an extern "C" entry point.
+struct CtxEnter {
+  ldsim_ctx* c;
+  bool ok;
+  explicit CtxEnter(ldsim_ctx* ctx) : c(ctx), ok(true) {
+    if (!c) return;                                  // (the entry point's own argument check reports a null ctx)
+    const std::thread::id me = std::this_thread::get_id();
+    if (c->owner.load(std::memory_order_acquire) == me) {
+      c->owner_depth++;
+      return;
+    }
+    std::thread::id none{};
+    ok = c->owner.compare_exchange_strong(none, me, std::memory_order_acq_rel);
+    if (ok) c->owner_depth = 1;
+  }
+  ~CtxEnter() {
+    if (c && ok && --c->owner_depth == 0) c->owner.store(std::thread::id{}, std::memory_order_release);
+  }
+  CtxEnter(const CtxEnter&) = delete;
+  CtxEnter& operator=(const CtxEnter&) = delete;
+};
+#define LDSIM_ENTER(ctx)                                                                                      \
+  CtxEnter enter_(ctx);                                                                                       \
+  if (!enter_.ok) {                                                                                           \
+    ldsim_set_error("ctx in use by another thread (a ctx is thread-compatible, not thread-safe: one per thread)"); \
+    return LDSIM_ESTATE;                                                                                      \
+  }
 
 #define HIPCHK(expr)                                                                      \
   do {                                                                                    \

@@ -682,6 +682,7 @@ static int sim_triggers_run(ldsim_ctx* ctx, const float* d_signal, const int32_t
 // ======================================================================================================================
 extern "C" int ldsim_stat_fluctuations(ldsim_ctx* ctx, const float* light_sample_inc, int32_t n_det, int32_t n_ticks,
                                        float* light_sample_inc_disc) {
+  LDSIM_ENTER(ctx);
   LW_NEED(ctx && light_sample_inc && light_sample_inc_disc && n_det >= 0 && n_ticks >= 0, "bad argument");
   LW_NEED(ctx->h_consts.light_tick_size > 0, "light constants not set");
   HIPCHK(hipSetDevice(ctx->device));
@@ -700,6 +701,7 @@ extern "C" int ldsim_stat_fluctuations(ldsim_ctx* ctx, const float* light_sample
 extern "C" int ldsim_light_triggers(ldsim_ctx* ctx, const float* signal, int32_t n_det, int32_t n_ticks,
                                     const double* group_threshold, int32_t n_grp, const int32_t* row_module, int32_t n_mod,
                                     int64_t* trigger_idx, int32_t* trigger_module, int64_t capacity, int64_t* n_trig) {
+  LDSIM_ENTER(ctx);
   LW_NEED(ctx && group_threshold && row_module && n_trig && n_det >= 0 && n_ticks >= 0 && n_grp >= 0 && n_mod >= 0 &&
               capacity >= 0 && (capacity == 0 || (trigger_idx && trigger_module)), "bad argument");
   HIPCHK(hipSetDevice(ctx->device));
@@ -720,6 +722,7 @@ extern "C" int ldsim_light_triggers(ldsim_ctx* ctx, const float* signal, int32_t
 
 extern "C" int ldsim_light_detector_noise(ldsim_ctx* ctx, int32_t n_rows, int32_t n_samples, const double* spectrum,
                                           int32_t nbins, const double* phases, double* noise) {
+  LDSIM_ENTER(ctx);
   LW_NEED(ctx && spectrum && noise && n_rows >= 0 && n_samples >= 0 && nbins >= 0, "bad argument");
   HIPCHK(hipSetDevice(ctx->device));
   if (n_rows == 0 || n_samples == 0) return 0;
@@ -745,6 +748,7 @@ extern "C" int ldsim_sim_triggers(ldsim_ctx* ctx, const float* signal, const int
                                   const double* light_det_noise, int32_t n_noise_channels, int32_t n_noise_bins,
                                   const double* phases_signal, const double* phases_missing, double* digit_signal,
                                   int64_t* digit_true_track_id, double* digit_true_photons) {
+  LDSIM_ENTER(ctx);
   LW_NEED(ctx && n_det >= 0 && n_ticks >= 0 && max_truth >= 0 && n_trig >= 0 && n_det_trig >= 0 && digit_samples >= 0,
           "bad argument");
   LW_NEED(n_det == 0 || signal_op_channel_idx, "signal_op_channel_idx missing");
