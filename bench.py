@@ -5,7 +5,11 @@ bench.py -- throughput of the charge hot path (quench -> drift -> pixels -> indu
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; the launcher only
-   starts the processes -- the collective layer is RCCL through the C-ABI, larndsim_amd/comm.py, no torch in this file)
+   starts the processes -- the collective layer is RCCL through the C-ABI, larndsim_amd/comm.py, no torch in this file.
+   Started WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` starts its N ranks itself: the parent, which never
+   touches the GPU, spawns N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and
+   exits non-zero if any child does.  A line is never printed for a run whose RCCL communicator holds another number of ranks
+   than --gpus.)
 
 A step = one pass of the whole path over this rank's resident synthetic segment set (BASELINE.json configs[1]: module0,
 100k segments; the example edep-sim file is absent so the SURVEY 8d synthetic straight tracks are used).  Segments are
@@ -107,6 +111,34 @@ def profiled_traffic(config, kernel):
         return None, f"no PMC pass for {config}/{kernel} in profiles/{os.path.basename(TRAFFIC_FILE)} (tools/pmc_traffic.py writes it)"
 
 
+def self_launch(n):
+    """--gpus N without a launcher: N fresh child processes, one rank each (never an exec of a process that has touched the
+    GPU: this parent imports nothing that does).  Rank 0's stdout is relayed; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:          # a free port for the ranks' rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"bench.py --gpus {n}: ranks failed (rank, exit code): {bad}; no result line\n")
+        raise SystemExit(max(1, max(abs(c) for _, c in bad) & 0xFF))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,13 +169,28 @@ def main():
                     help="response ticks below exp(-v) of the table's largest entry are not read (library default 23; 0 = exact zeros only)")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)                      # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
 
     from larndsim_amd import batching, comm as lcomm, consts, dist as ldist, lib, synth
+    if os.environ.get("LDSIM_BENCH_REHEARSAL"):
+        # CPU rehearsal of the launch path (tests/test_cpu_dist.py): the ranks meet over the ncclUniqueId hand-out and stop
+        # before anything touches a GPU
+        got = lcomm.exchange_id(bytes(range(128)) if rank == 0 else b"", rank, world, timeout=60.0)
+        if os.environ.get("LDSIM_BENCH_REHEARSAL_FAIL_RANK") == str(rank):
+            raise SystemExit(f"rank {rank}: asked to fail (test of the launcher's error path)")
+        if got != bytes(range(128)):
+            raise SystemExit(f"rank {rank}: rendezvous payload differs")
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": a.gpus, "world": world, "steps": a.steps, "warmup": a.warmup}))
+        return
     from larndsim_amd.chain import ChargeChain
 
     use_dist = world > 1 or a.force_dist
@@ -301,6 +348,8 @@ def main():
         elapsed = cm.allreduce(elapsed, "max")
         n_job = cm.allreduce(n_job, "sum")
         n_ranks_rccl = cm.count()[0]                 # ncclCommCount: the ranks that really joined
+        if n_ranks_rccl != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the RCCL communicator holds {n_ranks_rccl} ranks: no result line")
 
     # ---- side measurements (one GPU only; never part of `value`) ------------------------------------------------------------
     extras = {}

@@ -144,7 +144,11 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * gtables_wave_kernel, one wave per pair, for the pairs that fit it and gtables_kernel, one workgroup per pair, for the rest
  * (default); 0 = gtables_kernel for all: same tables entry for entry), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
- * "quad_accuracy_log10" (qweights_kernel: node count for a quadrature error of 1e-10 (default) or 1e-12 of the peak weight),
+ * "quad_accuracy_log10" (tables / weights stage: Gauss-Legendre nodes along the segment for a quadrature error of 1e-v of the peak
+ * weight, v = 7 (default since round 4: N = ceil(3.4 + 1.38 r) nodes for a clipped segment r Gaussian widths long; per tick the
+ * result stays at 0.012 of the parity tolerance 1e-5 |ref| + 1e-7 peak against the reference's goldens, where the f4 rounding of
+ * the stored currents already is -- tools/quad_sweep.py, profiles/r04_acc_sweep_module0.log), 8, 9, 10 (4.8 + 1.6 r, the default
+ * of rounds 2-3) or 12 (6 + 1.9 r)),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows
  * staged in LDS; bit-identical results), "light_incidence_scalar" (1 = calculate_light_incidence with one channel per lane
  * instead of four (the form used when n_out or the LUT's detector count is not a multiple of 4); identical bits; default 0),
@@ -208,9 +212,14 @@ int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const Ld
 /* detsim.tracks_current[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response)
  *                                                     -- larndsim/detsim.py:351-453
  * Runs the kernels the options select, exactly like ldsim_charge_chain does for its sorted pair list ("split_kernels",
- * "weights_mode", "mac_mode": by default the quadrature weights stage + the shifted-window correlation, pairs beyond their
- * capacities recomputed by the monolithic closed-form kernel), on the dense [S][P] pixel array; pixel id -1 is evaluated
- * as the reference evaluates it (Python index wrap). */
+ * "weights_mode", "mac_mode", "gform_max_support").  Default: the node-separable form (weights_mode 2) -- pair_setup_kernel,
+ * gtables_wave_kernel (Gauss-Legendre tables X, Y, Z per pair) and gcorr_kernel (the two products on v_mfma_f64_16x16x4) -- for
+ * response tables whose staged support is at most gform_max_support (768) ticks; wider tables are handed to round 2's
+ * qweights_kernel + mac_shift kernels (weights_mode 1); pairs beyond a kernel's capacities (rules of more than quad_max_nodes
+ * nodes ...) are recomputed by the monolithic closed-form kernel.  Response ticks below exp(-trim_response_log) (default 23:
+ * 1e-10) of the table's largest entry are not read: an approximation relative to the reference of < 1e-10 of a waveform's peak
+ * that the headline throughput on the SURVEY table relies on (bench.py reports `exact_zero_trim` beside it).  All on the dense
+ * [S][P] pixel array; pixel id -1 is evaluated as the reference evaluates it (Python index wrap). */
 int ldsim_tracks_current(ldsim_ctx* ctx, const void* tracks, int64_t n, const LdsimTrackLayout* layout,
                          const int32_t* pixels, int32_t max_neigh, float* signals, int32_t n_ticks);
 /* detsim.tracks_current_mc[(S,P,T/64),(1,1,64)](signals, pixels, tracks, response, rng_states) -- larndsim/detsim.py:258-348,

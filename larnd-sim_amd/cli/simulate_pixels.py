@@ -191,13 +191,35 @@ def _as_list(v):
     return v
 
 
+NUMBA_F32_FIELDS = ("x_start", "x_end", "y_start", "y_end", "z_start", "z_end", "tran_diff", "long_diff", "t_start")
+
+
+def numba_f32_mode(flag, dtype):
+    """--numba_f32 {auto,0,1} -> 0 / 1.  auto: 1 when the fields whose f4 storage makes Numba type sub-expressions of
+    tracks_current as f32 are all f4 in the input records (the edep-sim schema), 0 when they are f8 (what the reference's own
+    tests and the golden vectors use).  A mixed record keeps the all-f64 arithmetic and says so."""
+    v = str(flag).strip().lower()
+    if v in ("0", "false", "off"):
+        return 0
+    if v in ("1", "true", "on"):
+        return 1
+    if v != "auto":
+        raise ValueError(f"--numba_f32 must be auto, 0 or 1, not {flag!r}")
+    kinds = {np.dtype(dtype[f]).itemsize for f in NUMBA_F32_FIELDS if f in dtype.names and np.dtype(dtype[f]).kind == "f"}
+    if kinds == {4}:
+        return 1
+    if kinds - {8}:
+        print("[simulate_pixels] the segment records mix f4 and f8 hot-path fields: all-f64 arithmetic is used (--numba_f32 0)")
+    return 0
+
+
 def run_simulation(input_filename, output_filename, config="module0", mod2mod_variation=None, pixel_layout=None,
                    detector_properties=None, simulation_properties=None, response_file=None, light_simulated=None,
                    light_lut_filename=None, light_det_noise_filename=None, bad_channels=None, n_events=None,
                    pixel_thresholds_file=None, pixel_gains_file=None, rand_seed=None, config_root=None,
                    tracks_current_mc=False, chunk_segments=50000, raw_arrays=False, overlap_downloads=None,
                    pixel_layout_id=None, response_id=None, light_lut_id=None, pixel_thresholds_id=None, pixel_gains_id=None,
-                   **ignored):
+                   numba_f32="auto", **ignored):
     if not os.path.exists(input_filename):
         raise Exception(f"Input file {input_filename} does not exist.")
     if os.path.exists(output_filename):
@@ -314,6 +336,13 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
     kept_tracks, light_dat = [], {}
     rng_seeded = False
     lib.set_option("mc_current", 1 if tracks_current_mc else 0)
+    # Numba types f32 (op) f32 as f32: with the real 152-byte schema (f4 coordinates, widths, times) a few sub-expressions of
+    # tracks_current run in single precision in the reference (detsim.py:74-79,116-118,141,387); with f8 fields everything is f64.
+    # "auto" follows the record's dtype.  The restatement of Numba's typing is UNPINNED (no Numba here to check it against:
+    # INTEGRATION.md); it differs from all-f64 by up to 5e-5 of a waveform's peak.
+    f32_mode = numba_f32_mode(numba_f32, all_tracks.dtype)
+    print("Numba f32 typing mode:", "on" if f32_mode else "off", f"(--numba_f32 {numba_f32})")
+    lib.set_option("numba_f32", f32_mode)
     try:
         for i_mod in mod_ids:                                       # convention: module ids count from 1 (:676-715)
             if m2m:
@@ -377,6 +406,7 @@ def run_simulation(input_filename, output_filename, config="module0", mod2mod_va
         out.close(pixel_layout if isinstance(pixel_layout, str) else None if pixel_layout is None else list(pixel_layout))
     finally:
         lib.set_option("mc_current", 0)
+        lib.set_option("numba_f32", 0)
     print(f"simulated {totals['n_segments']} segments in {totals['n_batches']} batches -> {totals['n_hits']} hits, "
           f"{totals['n_packets']} packets" + (f", {totals['n_light_triggers']} light triggers" if light_simulated else ""))
     print("Output saved in:", output_filename)
@@ -655,6 +685,9 @@ def main(argv=None):
     ap.add_argument("--tracks_current_mc", action="store_true",
                     help="induced currents from tracks_current_mc like the reference driver (default: tracks_current)")
     ap.add_argument("--raw_arrays", action="store_true", help="also store the per-pixel arrays (raw/...) and light_sample_inc")
+    ap.add_argument("--numba_f32", default="auto", choices=["auto", "0", "1"],
+                    help="evaluate the sub-expressions Numba types as float32 for f4 record fields in single precision like the "
+                         "reference (1), all in double (0), or by the input records' dtype (auto, default); unpinned restatement")
     a = vars(ap.parse_args(argv))
     run_simulation(**a)
 

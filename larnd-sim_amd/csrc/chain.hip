@@ -2,6 +2,7 @@
 // Mirrors the body of the reference's batch loop (cli/simulate_pixels.py:917-1105) for MANY batches at
 // once: every (event, TPC-group, sub-batch) batch keeps its own unique-pixel set, max_length and
 // segment numbering because the batch id is the leading key of the pair sort.
+#include <stdio.h>
 #include <math.h>
 
 #include <vector>
@@ -429,6 +430,9 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   HIPCHK(hipStreamSynchronize(st));
   stat_sum(h_raw, h_cnt);
+  if (ctx->debug_gform & 128)       // timing tools: cycle stamps of gcorr_kernel's waves (kernels_gcorr.hip)
+    fprintf(stderr, "gcorr stamps (shader cycles, summed over waves): info %llu stage %llu G %llu P %llu edges %llu tail %llu life %llu\n",
+            h_cnt[9], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];
   stats_from_counters(ctx->stats, h_cnt);

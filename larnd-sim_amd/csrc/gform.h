@@ -20,7 +20,7 @@
 #define G_CELLCAP 2048      // cells of a batch held in LDS as 16-bit (col, j) codes: every pair fits (40 columns x 48 rows)
 #define G_CELLPAD 32        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups)
 #define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
-#define G_CELL0 4           // ints in front of the cell words of a batch image (counts)
+#define G_CELL0 4           // ints before the first cell entry of a batch (counts; four, so that every table starts 16-byte aligned)
 
 // per pair, written by pair_setup_kernel next to PairParams: what sizes the record before any table exists
 struct GInfo {
@@ -34,46 +34,29 @@ struct GInfo {
   unsigned long long size;                                      // record size in doubles
 };
 
-// record layout in doubles from `off`, per node batch b:
-//   image     g_img(ncol, NJ).doubles      what gcorr_kernel's G products read, in the layout its LDS holds (one flat copy, no
-//                                          index arithmetic on the way in):
-//       2 doubles                          int count of listed cells padded to a multiple of G_CELLPAD with weightless dummies,
-//                                          int count of real cells, two unused
-//       info[cap]                          u64 per listed cell: response row offset (doubles into the padded table) | byte offset of
-//                                          its X column << 32 | byte offset of its Y row entry << 48; cap = ncol * NJ rounded up
-//       X[16][xs]                          X[n][col]; xs = (ncol + 1) | 1 (odd: the 16 node rows fall on distinct banks); column
-//                                          `ncol` holds zeros (the dummies point at it); rows past the batch's nodes: zeros
-//       Y[16][ys]                          Y[n][j]; ys = NJ | 1
-//   Z         rows * NUr                   Z[n][u]; NUr = NU rounded up to 16; rows = the batch's nodes rounded up to 4 (16 for all
-//                                          batches but the last: 59 % of the survey workload's pairs end in a batch of 1 .. 4 nodes)
-//   Zi        popcount(edge_bound) * rows * NUr   per possible window edge: Z over the slices that are invalid at that edge only
-//                                          (gcorr_kernel takes their share of the one tick the edge maps to back: one more
-//                                          16-node product against the column G_n[edge_k] it holds anyway)
+// record layout in doubles from `off`:
+//   per node batch b:
+//     cells     2 + padded / 2              int count padded to a multiple of G_CELLPAD with dummies, int count of real cells,
+//                                           two unused, then u32 row | col << 16 | j << 24 per cell
+//     X         rows * ncol                 X[n][col]; rows = the batch's nodes rounded up to 4 (16 for all batches but the last:
+//                                           59 % of the survey workload's pairs end in a batch of 1 .. 4 nodes)
+//     Y         rows * NJ                   Y[n][j]
+//     Z         rows * NUr                  Z[n][u]; NUr = NU rounded up to 16
+//     Zi        popcount(edge_bound) * rows * NUr   per possible window edge: Z over the slices that are invalid at that edge only
+//                                           (gcorr_kernel takes their share of the one tick the edge maps to back: one more
+//                                           16-node product against the column G_n[edge_k] it holds anyway)
 __host__ __device__ __forceinline__ int g_nur(int NU) { return (NU + 15) & ~15; }
 __host__ __device__ __forceinline__ int g_popc3(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1); }
-struct GImg {
-  int cap, xs, ys, x_d, y_d, doubles;      // info capacity; row strides; offsets of X and Y and the image's size in doubles
-};
-__host__ __device__ __forceinline__ GImg g_img(int ncol, int NJ) {
-  GImg I;
-  I.cap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-  I.xs = (ncol + 1) | 1;
-  I.ys = NJ | 1;
-  I.x_d = G_CELL0 / 2 + I.cap;
-  I.y_d = I.x_d + G_NODES * I.xs;
-  I.doubles = (I.y_d + G_NODES * I.ys + 1) & ~1;      // (every table after it starts 16-byte aligned)
-  return I;
+__host__ __device__ __forceinline__ unsigned long long g_cells_doubles(int ncol, int NJ) {
+  return G_CELL0 / 2 + (unsigned long long)((ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1)) / 2;
 }
-__host__ __device__ __forceinline__ unsigned long long g_info_word(unsigned row_off, unsigned col, unsigned j) {
-  return (unsigned long long)row_off | ((unsigned long long)(col * 8u) << 32) | ((unsigned long long)(j * 8u) << 48);
-}
-// node rows batch b of a rule of NQ nodes stores in its Z tables
+// node rows batch b of a rule of NQ nodes stores
 __host__ __device__ __forceinline__ int g_rows(int NQ, int b) {
   const int nb = NQ - G_NODES * b;
   return nb >= G_NODES ? G_NODES : ((nb + 3) & ~3);
 }
 __host__ __device__ __forceinline__ unsigned long long g_batch_doubles(int ncol, int NJ, int NU, int edge_bound, int rows = G_NODES) {
-  return (unsigned long long)g_img(ncol, NJ).doubles + (unsigned long long)rows * ((1 + g_popc3(edge_bound)) * g_nur(NU));
+  return g_cells_doubles(ncol, NJ) + (unsigned long long)rows * (ncol + NJ + (1 + g_popc3(edge_bound)) * g_nur(NU));
 }
 // (batch b starts b full batches into the record: only the last one is short)
 __host__ __device__ __forceinline__ unsigned long long g_record_doubles(int NB, int NQ, int ncol, int NJ, int NU, int edge_bound) {

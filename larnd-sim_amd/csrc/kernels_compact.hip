@@ -4,7 +4,10 @@
 // track_pixel_map [U][50], current_fractions [U][30][50] f64 = 13 KB per unique pixel, 2.5 GB per 50k-segment launch -- of
 // which the exporter (fee.export_to_hdf5, fee.py:143-344) reads the pixels that hold a hit, the slots up to the first ADC at
 // the pedestal, and the fractions of the track slots the pixel really has.  Here exactly that is gathered in HBM first:
-//   per hit pixel   row index in the dense arrays, pixel id, batch, number of hits, number of track slots
+//   per hit pixel   row index in the dense arrays, pixel id, batch, number of hits, number of track slots -- and the same row
+//                   (0 hits, 0 slots) for the first unique pixel of every batch even when it holds no hit: the driver counts
+//                   batches per export (sim.WRITE_BATCH_SIZE) from what it is handed, like the reference, which appends every
+//                   simulated batch (cli/simulate_pixels.py:1207-1214), and the exporter keeps its clock state in a batch's row 0
 //   per track slot  the segment index (track_pixel_map entry)
 //   per hit         the 24-byte row of the multi-GPU exchange {batch, pixel, ADC code, slot, tick} + the integrated charge
 //   per hit x slot  the backtracking fraction
@@ -15,6 +18,7 @@
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 
 __global__ void __launch_bounds__(256) compact_count_kernel(const int32_t* __restrict__ hit_count, const int64_t* __restrict__ tpm,
+                                                            const int32_t* __restrict__ ubatch,
                                                             int M, int64_t U, int32_t* __restrict__ c_hp, int32_t* __restrict__ c_trk,
                                                             int32_t* __restrict__ c_frac) {
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -23,7 +27,7 @@ __global__ void __launch_bounds__(256) compact_count_kernel(const int32_t* __res
   int nt = 0;
   if (nh > 0)
     for (int m = 0; m < M; m++) nt += tpm[u * M + m] >= 0;       // (filled from slot 0 on, -1 behind)
-  c_hp[u] = nh > 0;
+  c_hp[u] = nh > 0 || u == 0 || ubatch[u - 1] != ubatch[u];      // (a batch's first row always travels)
   c_trk[u] = nt;
   c_frac[u] = nh * nt;
 }
@@ -38,13 +42,14 @@ __global__ void __launch_bounds__(256) compact_fill_kernel(const int32_t* __rest
                                                            double* __restrict__ hit_charge, double* __restrict__ frac_val) {
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (u >= U) return;
-  const int nh = hit_count[u];
-  if (nh <= 0) return;
+  const int nh = hit_count[u] > 0 ? hit_count[u] : 0;
+  const bool first = u == 0 || ubatch[u - 1] != ubatch[u];
+  if (nh <= 0 && !first) return;
   const int nt = c_trk[u];
   int32_t* r = hp_rows + (int64_t)o_hp[u] * 5;
   // (bit 8 of the last word: the pixel is the first row of its batch in the dense arrays -- the exporter's clock-rollover
   // bookkeeping treats row 0 of what it is handed specially, fee.py:164-183,267-277)
-  r[0] = (int32_t)u; r[1] = upix[u]; r[2] = ubatch[u]; r[3] = nh; r[4] = nt | ((u == 0 || ubatch[u - 1] != ubatch[u]) ? 256 : 0);
+  r[0] = (int32_t)u; r[1] = upix[u]; r[2] = ubatch[u]; r[3] = nh; r[4] = nt | (first ? 256 : 0);
   for (int m = 0; m < nt; m++) trk_seg[o_trk[u] + m] = tpm[u * M + m];
   for (int h = 0; h < nh; h++) {
     hit_charge[hit_off[u] + h] = adc_list[u * A + h];
@@ -71,8 +76,8 @@ extern "C" int ldsim_chain_compact_build(ldsim_ctx* ctx, int64_t* sizes) {
   const int32_t* d_hitcnt = (const int32_t*)ctx->scratch[SB_PAIRPIX].p;
   const int32_t* d_hitoff = d_hitcnt + U;
   const unsigned g0 = (unsigned)((U + 255) / 256);
-  hipLaunchKernelGGL(compact_count_kernel, dim3(g0), dim3(256), 0, st, d_hitcnt, (const int64_t*)ctx->scratch[SB_TPM].p, M, U, c_hp,
-                     c_trk, c_frac);
+  hipLaunchKernelGGL(compact_count_kernel, dim3(g0), dim3(256), 0, st, d_hitcnt, (const int64_t*)ctx->scratch[SB_TPM].p,
+                     (const int32_t*)ctx->scratch[SB_UBATCH].p, M, U, c_hp, c_trk, c_frac);
   HIPCHK(hipGetLastError());
   if ((rc = sort_exclusive_scan_i32(ctx, c_hp, o_hp, U))) return rc;
   if ((rc = sort_exclusive_scan_i32(ctx, c_trk, o_trk, U))) return rc;

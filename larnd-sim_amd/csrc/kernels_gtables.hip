@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
   const double uxr = s_par[PP_UXR], uyr = s_par[PP_UYR], uzr = s_par[PP_UZR], i2T = s_par[PP_I2T], i2L = s_par[PP_I2L];
   const double kappa = s_par[PP_KAPPA], s_lo = s_par[PP_S_LO], qlen = s_par[PP_QLEN], wscale = s_par[PP_WSCALE];
   const double thr = s_par[PP_THR];
-  const GImg I = g_img(ncol, NJ);
+  const unsigned long long cells_d = g_cells_doubles(ncol, NJ);
   const unsigned long long batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
   int emask_seen = 0;
 
@@ -234,12 +234,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
   for (int b = 0; b < NB; b++) {
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
-    int32_t* cells = (int32_t*)brec;                         // [0] padded count, [1] real count of the listed cells
-    unsigned long long* info = (unsigned long long*)(brec + G_CELL0 / 2);      // one word per listed cell (g_info_word)
-    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch's Z tables
-    double* gX = brec + I.x_d;                               // the image's X[16][xs], Y[16][ys]
-    double* gY = brec + I.y_d;
-    double* gZ = brec + I.doubles;
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
+    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch
+    double* gX = brec + cells_d;
+    double* gY = gX + rows * ncol;
+    double* gZ = gY + rows * NJ;
     __syncthreads();          // the previous batch's tables are no longer read
     // ---- X and Y tables of this node batch: one task per (bin, node), node fastest ---------------------------------------------
     {
@@ -323,12 +322,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
     ztable(-1, gZ);
     __syncthreads();
     // ---- tables to the record -----------------------------------------------------------------------------------------------------
-    if (!(GA.dbg & 16)) {         // (all 16 node rows, the zero column of X behind the last real one)
-      for (int i = tid; i < G_NODES * (ncol + 1); i += CUR_THREADS) {
-        const int n = i / (ncol + 1), cc = i % (ncol + 1);
-        gX[n * I.xs + cc] = cc < ncol ? s_X[n][cc] : 0.0;
-      }
-      for (int i = tid; i < G_NODES * NJ; i += CUR_THREADS) gY[(i / NJ) * I.ys + i % NJ] = s_Y[i / NJ][i % NJ];
+    if (!(GA.dbg & 16)) {
+      for (int i = tid; i < rows * ncol; i += CUR_THREADS) gX[i] = s_X[i / ncol][i % ncol];
+      for (int i = tid; i < rows * NJ; i += CUR_THREADS) gY[i] = s_Y[i / NJ][i % NJ];
     }
     // ---- cells that can carry weight: sum over the nodes and all shifts of X Y Z above the pruning threshold (every
     // (cell, shift) bin the weight kernels would keep lies in such a cell); list in (column, j) order ------------------------------------
@@ -353,7 +349,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
         for (int w = 0; w < wv; w++) before += s_wcnt[w];
         if (keep) {
           const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-          info[pos] = g_info_word((unsigned)(s_coli[col] * A.nj + (jmin + jj)) * (unsigned)GA.nkp, (unsigned)col, (unsigned)jj);
+          const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
+          cells[G_CELL0 + pos] = (int)ce;
           s_cells[pos] = (unsigned short)(col | (jj << 6));
         }
         base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
@@ -362,9 +359,9 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
       __syncthreads();           // (s_cells[0] of another wave)
       const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
       if (tid < padded - base && base > 0) {
-        // padding: the first cell's response row (valid memory) against the zero column of X
+        // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
         const unsigned c0 = s_cells[0] & 63u, j0 = (s_cells[0] >> 6) & 63u;
-        info[base + tid] = g_info_word((unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) * (unsigned)GA.nkp, (unsigned)ncol, j0);
+        cells[G_CELL0 + base + tid] = (int)(0x80000000u | (unsigned)(s_coli[c0] * A.nj + (jmin + (int)j0)) | (c0 << 16) | (j0 << 24));
       }
       if (tid == 0) { cells[0] = padded; cells[1] = base; }
     }
@@ -630,7 +627,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   const double uxr = uni(s_par[PP_UXR]), uyr = uni(s_par[PP_UYR]), uzr = uni(s_par[PP_UZR]), i2T = uni(s_par[PP_I2T]);
   const double i2L = uni(s_par[PP_I2L]), kappa = uni(s_par[PP_KAPPA]), s_lo = uni(s_par[PP_S_LO]), qlen = uni(s_par[PP_QLEN]);
   const double wscale = uni(s_par[PP_WSCALE]), thr = uni(s_par[PP_THR]);
-  const GImg I = g_img(ncol, NJ);
+  const unsigned long long cells_d = g_cells_doubles(ncol, NJ);
   const unsigned long long batch_d = g_batch_doubles(ncol, NJ, NU, ebound);
   const int emask = anyinv & ebound;
   const int nbins = ncol + NJ;
@@ -639,12 +636,11 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   for (int b = 0; b < NB; b++) {
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
-    int32_t* cells = (int32_t*)brec;                         // [0] padded count, [1] real count of the listed cells
-    unsigned long long* info = (unsigned long long*)(brec + G_CELL0 / 2);      // one word per listed cell (g_info_word)
-    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch's Z tables
-    double* gX = brec + I.x_d;                               // the image's X[16][xs], Y[16][ys]
-    double* gY = brec + I.y_d;
-    double* gZ = brec + I.doubles;
+    int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
+    const int rows = g_rows(NQ, b);                          // node rows the record keeps of this batch
+    double* gX = brec + cells_d;
+    double* gY = gX + rows * ncol;
+    double* gZ = gY + rows * NJ;
     // this lane's four nodes: position along the segment and weight (a node past the batch's last one: rows of zeros)
     double sn[4], wn[4];
 #pragma unroll
@@ -696,8 +692,8 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
             const int n = 4 * m + q;
             const double v = n < nb ? sum[m] : 0.0;
             s_XY[n][bi] = v;
-            if (!(GA.dbg & 16)) {          // (all 16 node rows: zeros past the batch's last node)
-              if (isx) gX[n * I.xs + bb] = v; else gY[n * I.ys + bb] = v;
+            if (!(GA.dbg & 16) && n < rows) {
+              if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
             }
           }
         }
@@ -777,7 +773,6 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         }
       }
     };
-    if (lane < G_NODES && !(GA.dbg & 16)) gX[lane * I.xs + ncol] = 0.0;      // the zero column the padding cells point at
     switch ((nb + 3) >> 2) {
       case 1: tables(std::integral_constant<int, 1>{}); break;
       case 2: tables(std::integral_constant<int, 2>{}); break;
@@ -799,7 +794,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     {
       const int ncand = ncol * NJ;
       int base = 0;
-      unsigned first_row = 0, first_j = 0;
+      unsigned first_code = 0;
       for (int c0 = 0; c0 < ncand && !(A.debug_phases & 0x8000000); c0 += 64) {
         const int cc = c0 + lane;
         bool keep = false;
@@ -811,18 +806,14 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
           keep = do_prune ? w > thr : w != 0.0;
         }
         const unsigned long long bal = __ballot(keep);
-        const unsigned row_off = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) * (unsigned)GA.nkp;
-        if (keep) info[base + __popcll(bal & ((1ull << lane) - 1ull))] = g_info_word(row_off, (unsigned)col, (unsigned)jj);
-        if (base == 0 && bal) {
-          const int fl = __ffsll((long long)bal) - 1;
-          first_row = (unsigned)__builtin_amdgcn_readlane((int)row_off, fl);
-          first_j = (unsigned)__builtin_amdgcn_readlane(jj, fl);
-        }
+        const unsigned ce = (unsigned)(s_coli[col] * A.nj + (jmin + jj)) | ((unsigned)col << 16) | ((unsigned)jj << 24);
+        if (keep) cells[G_CELL0 + base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)ce;
+        if (base == 0 && bal) first_code = (unsigned)__builtin_amdgcn_readlane((int)ce, __ffsll((long long)bal) - 1);
         base += __popcll(bal);
       }
       const int padded = (base + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-      // padding: the first cell's response row (valid memory) against the zero column of X
-      if (lane < padded - base && base > 0) info[base + lane] = g_info_word(first_row, (unsigned)ncol, first_j);
+      // padding: copies of the first cell with the weightless flag (gcorr_kernel loads that cell's row and multiplies by 0)
+      if (lane < padded - base && base > 0) cells[G_CELL0 + base + lane] = (int)(0x80000000u | first_code);
       if (lane == 0) { cells[0] = padded; cells[1] = base; }
     }
   }

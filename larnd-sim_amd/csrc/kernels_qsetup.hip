@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   }
   if (!(s_hi > s_lo) || iz_hi < iz_lo) { pp[pair] = P; return; }
   const double qlen = s_hi - s_lo;
-  // nodes for a relative quadrature error of exp(-quad_log) of the peak weight: tools/quad_nodes.py (default 1e-10: 4.8 + 1.6 r;
-  // 1e-12 needs 6 + 1.9 r), r = clipped length in Gaussian widths along the segment
+  // nodes for a relative quadrature error of 1e-v of the peak weight: tools/quad_nodes.py (v = 7, the default: 3.4 + 1.38 r;
+  // 1e-10: 4.8 + 1.6 r; 1e-12 needs 6 + 1.9 r), r = clipped length in Gaussian widths along the segment
   const double nq_f = ceil(qn0 + qslope * qlen * sqrt(2.0 * a));
   // response shifts of the slices -> the tick window in which any of them sees a staged response entry
   int sh_min = 1 << 30, sh_max = -(1 << 30);

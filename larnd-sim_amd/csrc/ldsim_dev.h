@@ -125,7 +125,7 @@ struct ldsim_ctx {
   int32_t n_light_ch = 0;
   DevBuf resp_pad;                           // zero-padded copy of the response rows for mac_shift_kernel
   int32_t resp_pad_lo = 0, resp_pad_hi = -2; // staged range it was built for (-2: not built)
-  double quad_n0 = 4.8, quad_slope = 1.6;    // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-10 of the peak weight
+  double quad_n0 = 3.4, quad_slope = 1.38;   // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-7 of the peak weight (option quad_accuracy_log10, tools/quad_sweep.py)
   // overlapped download of the chain's results (ldsim_chain_download_async): a second stream copies launch k's per-pixel
   // arrays to the host while launch k + 1 computes into the other set of output buffers
   DevBuf light_wtid, light_wtph, light_wtid2;            // slot-major working copies of a response stage's output truth rows
@@ -162,7 +162,6 @@ struct ldsim_ctx {
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2
   double* d_glw = nullptr;
   int gl_nmax = 0;
-  int n_cu = 0;                     // compute units of the device (persistent grids)
   double wbuf_learned = 0;          // high-water demand per pair seen so far (x1.25): later calls size the pool with it
   int64_t n_fallback = 0;   // bit0: weights phase, bit1: correlation phase (timing experiments only)
   // resident segments
@@ -236,7 +235,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN, SB_GWORK
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN
 };
 
 void ldsim_set_error(const char* fmt, ...);

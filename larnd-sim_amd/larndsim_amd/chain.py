@@ -16,6 +16,7 @@ from .layout import make_layout
 
 class ChargeChain:
     def __init__(self, response=None, device=None):
+        lib.claim_chain(self)
         self.ctx = lib.context(device=device, noise_zero=False)
         self._generation = lib.consts_generation()
         self.n = 0
@@ -344,13 +345,16 @@ def expand_compact(c, lead_rows=False):
     arrays hold there), ``track_pixel_map`` [n][M] (-1 pad) and ``current_fractions`` [n][A][M] (written slots only: the dense
     array's un-normalised residue in the slot after the last hit, fee.py:572-573, is not part of the result).
 
-    ``lead_rows``: a batch whose first unique pixel holds no hit gets that hit-less row back in front of its hit pixels (no charge,
-    no track, the pixel id of the row after it, ``row`` -1) -- the reference's exporter keeps its clock-rollover state in row 0 of
-    what it is handed (fee.py:164-183, 267-277), and inserting the row here costs nothing where padding every batch's slice of
-    the 12 KB-per-pixel fraction array afterwards copied it once more."""
+    ``lead_rows``: a batch whose first unique pixel holds no hit keeps that hit-less row in front of its hit pixels (no charge, no
+    track) -- the reference's exporter keeps its clock-rollover state in row 0 of what it is handed (fee.py:164-183, 267-277), and
+    the driver counts the batches of an export from what it is handed, so a batch without any hit still shows up as its first row.
+    The compact form carries the first row of every batch (0 hits) since round 4; for input without it the row is inserted here
+    (the pixel id of the row after it, ``row`` -1)."""
     from . import packets
     A, M = consts.sim.MAX_ADC_VALUES, consts.sim.MAX_TRACKS_PER_PIXEL
     hp = c["hit_pixels"]
+    if not lead_rows and len(hp) and (hp[:, 3] == 0).any():          # (hit-less first rows carry no hits, slots or fractions)
+        hp = hp[hp[:, 3] > 0]
     n0 = hp.shape[0]
     nh, nt = hp[:, 3].astype(np.int64), (hp[:, 4] & 255).astype(np.int64)
     first = (hp[:, 4] & 256) != 0

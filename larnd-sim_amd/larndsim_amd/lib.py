@@ -141,6 +141,26 @@ def context(device=None, refresh_consts=True, noise_zero=False):
     return _ctx
 
 
+_chain_owner = None           # (thread ident, weak reference) of the ChargeChain that claimed the process-wide ctx last
+
+
+def claim_chain(chain):
+    """The process-wide ctx is thread-compatible, not thread-safe (include/ldsim.h): two ChargeChain objects driven from two threads
+    would share its segment store and scratch buffers.  The library itself refuses a second thread INSIDE a call (LDSIM_ESTATE,
+    csrc/ldsim_dev.h CtxEnter); this refuses the set-up that leads there: a ChargeChain made on one thread while a ChargeChain made
+    on another, still running thread is alive.  One process per GPU, or one thread per ctx, is the supported shape."""
+    global _chain_owner
+    import threading
+    import weakref
+    me = threading.get_ident()
+    if _chain_owner is not None:
+        tid, ref = _chain_owner
+        if tid != me and ref() is not None and any(t.ident == tid for t in threading.enumerate()):
+            raise LdsimError(f"a ChargeChain created on thread {tid} is still alive: the process-wide GPU context serves one thread "
+                             "at a time (use one process per GPU, or drop the other chain first)")
+    _chain_owner = (me, weakref.ref(chain))
+
+
 def destroy_context():
     global _ctx, _resp_token, _lut_token
     if _ctx is not None:

@@ -148,3 +148,77 @@ def test_unique_id_rendezvous_skips_a_port_someone_else_owns():
         stop.set()
         th.join(timeout=5)
         foreign.close()
+
+
+def _id_worker_job(rank, world, base_port, job_port, fill, q):
+    """a rank of the job whose launcher sits on `job_port` (its token), looking for its id in the candidates from `base_port`"""
+    sys.path.insert(0, os.path.join(REPO, "larnd-sim_amd"))
+    from larndsim_amd import comm
+    payload = bytes([fill]) * 128 if rank == 0 else b""
+    got = comm.exchange_id(payload, rank, world, addr="127.0.0.1", port=base_port, timeout=60.0,
+                           token=comm.job_token(world, "127.0.0.1", job_port))
+    q.put((fill, rank, got))
+
+
+def test_unique_id_rendezvous_of_two_jobs_on_overlapping_ports():
+    """Two jobs on one node whose candidate port ranges overlap (MASTER_PORTs a few apart), and a port probe that connects and
+    says nothing: every rank ends with ITS job's id, no serve slot is used up by a stranger (the frame carried only
+    a constant, and rank 0 counted every accepted connection)."""
+    import multiprocessing as mp
+    import threading
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    base = _free_port()
+    # job A owns candidates base .. base + 15, job B base + 2 .. base + 17; B's workers start first and meet A's listener
+    jobs = [(r, 3, base, 1000, 0xA1) for r in (0,)] + [(r, 3, base + 2, 2000, 0xB2) for r in (2, 1)]
+    procs = [ctx.Process(target=_id_worker_job, args=j + (q,)) for j in jobs]
+    for p in procs:
+        p.start()
+    time.sleep(1.0)
+
+    def probe():                          # a scanner: connects to the first candidates and hangs up
+        for k in range(4):
+            try:
+                socket.create_connection(("127.0.0.1", base + k), timeout=1.0).close()
+            except OSError:
+                pass
+    th = threading.Thread(target=probe)
+    th.start()
+    rest = [(r, 3, base, 1000, 0xA1) for r in (1, 2)] + [(0, 3, base + 2, 2000, 0xB2)]
+    procs2 = [ctx.Process(target=_id_worker_job, args=j + (q,)) for j in rest]
+    for p in procs2:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs + procs2]
+    th.join(timeout=10)
+    for p in procs + procs2:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == 6
+    for fill, rank, got in res:
+        assert got == bytes([fill]) * 128, f"job {fill:#x} rank {rank} got another job's id"
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two fresh ranks (RANK / WORLD_SIZE / MASTER_* set), they meet
+    over the id hand-out, rank 0's line is relayed and the exit code is 0; a WORLD_SIZE that contradicts --gpus is refused and a
+    failing rank makes the whole command fail without a result line.  LDSIM_BENCH_REHEARSAL stops the ranks
+    before anything touches a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LDSIM_BENCH_REHEARSAL"] = "1"
+    bench = os.path.join(REPO, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, timeout=180)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"rehearsal": True, "n_gpus": 2, "world": 2, "steps": 3, "warmup": 1}
+    # a launcher's WORLD_SIZE that contradicts --gpus: refused (the line would describe another job)
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, timeout=60)
+    assert r.returncode != 0 and not r.stdout.strip() and b"WORLD_SIZE=1" in r.stderr
+    # one rank dies (here: all of them, an unknown option value inside the children only): non-zero, no line
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--config", "module0"], env=dict(env, LDSIM_BENCH_REHEARSAL_FAIL_RANK="1"),
+                       capture_output=True, timeout=180)
+    assert r.returncode != 0 and not r.stdout.strip()

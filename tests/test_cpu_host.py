@@ -600,3 +600,39 @@ def test_expand_compact_lead_rows_equal_padding_each_batch():
     assert len(new["batch"]) == n + int((starts & ~first).sum())
     assert new["first_of_batch"][np.r_[True, new["batch"][1:] != new["batch"][:-1]]].all()
     assert (new["row"][new["row"] >= 0] == hp[:, 0]).all() and (new["row"] == -1).sum() == len(new["batch"]) - n
+
+
+def test_a_second_thread_cannot_claim_the_process_ctx_while_a_chain_lives():
+    """lib.claim_chain (what ChargeChain.__init__ calls first): the process-wide ctx serves one thread at a time.  A chain object
+    made on another thread while the first thread's chain is alive is refused; after the first is dropped, or its thread has ended,
+    the claim passes (VERDICT r03 item 5 -- the C-level guard, LDSIM_ESTATE on concurrent entry, has its test on the GPU)."""
+    import gc
+    import threading
+    from larndsim_amd import lib
+
+    class Chain:
+        pass
+    lib._chain_owner = None
+    a = Chain()
+    lib.claim_chain(a)
+    lib.claim_chain(Chain())                  # same thread: chains follow each other as before
+    lib.claim_chain(a)
+    seen = []
+
+    def other(expect_refusal):
+        try:
+            lib.claim_chain(Chain())
+            seen.append("claimed")
+        except lib.LdsimError as e:
+            seen.append(str(e))
+        assert ("still alive" in seen[-1]) == expect_refusal
+
+    t = threading.Thread(target=other, args=(True,)); t.start(); t.join()
+    assert "still alive" in seen[-1]
+    del a
+    gc.collect()
+    t = threading.Thread(target=other, args=(False,)); t.start(); t.join()
+    assert seen[-1] == "claimed"
+    # the thread that claimed last has ended: its claim does not outlive it
+    lib.claim_chain(Chain())
+    lib._chain_owner = None

@@ -28,9 +28,10 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
                    (0xe000000, 0, 0), (0xe000000, 0, 16), (0, 0, 16), (0, 0, 32), (0, 0, 0)),
         "adc": ((0, 0, 0), (0x10000, 0, 0), (0x20000, 0, 0), (0x40000, 0, 0), (0x60000, 0, 0), (0x70000, 0, 0), (0, 0, 0)),
         "occ": ((0, 0, 0), (0, -1, 0), (0, -2, 0), (0, -3, 0), (0, 1, 0), (0, 2, 0), (0, 0, 0)),
-        # (round 4, persistent correlation kernel: dbg 4 = the next pair's image is not requested ahead; lds pad n > 0 = at most n waves per CU)
+        # in-kernel cycle stamps of gcorr_kernel's waves (debug_gform 128; printed to stderr by the library)
+        "stamps": ((0, 0, 128), (0, 0, 0)),
         "corr": ((0, 0, 0), (0x100000, 0, 0), (0x200000, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0x100000, 0, 4), (0x100000, 0, 12),
-                 (0, 4, 0), (0, 8, 0), (0, 12, 0), (0, 0, 0))}
+                 (0x100000, 0, 14), (0, -12, 0), (0, 6, 0), (0, 0, 0))}
 for mask, pad, dbg in RUNS[WHICH]:
     lib.set_option("debug_phases", 15 | mask)
     lib.set_option("debug_lds_pad_kb", pad)

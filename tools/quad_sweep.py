@@ -22,12 +22,22 @@ from qweights_check import prepared                              # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "module0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
-ACCS = (12, 10, 9, 8, 7)
+# (quad_accuracy_log10, prune_log, trim_response_log); the first is the reference of the "vs tightest" comparisons
+ACCS = ((12, 0.0, 0.0), (10, 23.0, 23.0), (9, 23.0, 23.0), (8, 23.0, 23.0), (7, 23.0, 23.0), (8, 21.0, 21.0), (8, 19.0, 19.0), (7, 19.0, 19.0),
+        (7, 17.0, 17.0), (7, 16.0, 16.0))
+if os.environ.get("SWEEP"):
+    ACCS = tuple(tuple(float(v) for v in a.split(",")) for a in os.environ["SWEEP"].split(";"))
+
+
+def set_acc(acc):
+    lib.set_option("quad_accuracy_log10", acc[0])
+    lib.set_option("prune_log", acc[1])
+    lib.set_option("trim_response_log", acc[2])
 
 
 def stage(neigh, r, resp, T, acc):
     sig = np.zeros(neigh.shape + (T,), dtype=np.float32)
-    lib.set_option("quad_accuracy_log10", acc)
+    set_acc(acc)
     lib.set_option("gform_max_support", 1e9)
     detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, np.ascontiguousarray(neigh), r, resp)
     lib.set_option("gform_max_support", 768)
@@ -50,7 +60,7 @@ ch = ChargeChain(H.response_for(resp_kind))
 ch.upload(seg, bid)
 ch.quench_drift()
 for acc in ACCS:
-    lib.set_option("quad_accuracy_log10", acc)
+    set_acc(acc)
     ch.run(0, len(seg), want_fractions=True)
     st = ch.run(0, len(seg), want_fractions=True)
     ms = ch.kernel_ms()
@@ -97,11 +107,11 @@ for c in (cfg,):
         _, neigh, _, _ = O.get_pixels(r, nmax, P, rad)
         _, T = O.time_intervals(r)
         resp = H.response_for("survey" if c != "ndlar" else "golden")
-        ref = stage(neigh, r, resp, T, 12).astype(np.float64)
+        ref = stage(neigh, r, resp, T, ACCS[0]).astype(np.float64)
         peak = np.abs(ref).max(axis=-1, keepdims=True)
         for acc in ACCS[1:]:
             sig = stage(neigh, r, resp, T, acc).astype(np.float64)
             e, rel = excess(sig, ref, peak)
             print(f"vs acc 12, {c} {label} ({neigh.size} pairs x {T} ticks) acc {acc}: worst |diff| / tol {e:.3f}   worst |diff| / peak {rel:.2e}",
                   flush=True)
-lib.set_option("quad_accuracy_log10", 10)
+set_acc((10, 23.0, 23.0))
