@@ -18,7 +18,7 @@
 #define G_NUCAP 128         // response shifts of a pair whose Z table the kernels hold in LDS at once (more: in parts / from L2)
 #define G_ZS (G_NUCAP + 16) // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
 #define G_CELLCAP 2048      // cells of a batch held in LDS as 16-bit (col, j) codes: every pair fits (40 columns x 48 rows)
-#define G_CELLPAD 32        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups)
+#define G_CELLPAD 16        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups; 32 until round 4: 11 % of the G products were padding)
 #define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
 #define G_CELL0 4           // ints before the first cell entry of a batch (counts; four, so that every table starts 16-byte aligned)
 
@@ -75,4 +75,7 @@ struct GArgs {
   const double* glx;
   const double* glw;
   int32_t dbg;                   // timing tools (option debug_gform)
+  // edge_ks() of the launch's constants, computed on the host: a kernel that reads them from the constants block in HBM puts one
+  // more memory round trip in front of every pair (gcorr_kernel, gtables_wave_kernel)
+  int32_t edge_k[NEDGE], k_stage_lo, k_stage_hi;
 };

@@ -16,6 +16,7 @@
 // Zi table at the one response index it concerns.  No DPP shifts, no 512-tick tile padding, no weight pool: the matrix pipe
 // carries 16 x cells x ticks FMAs per pair where the shifted-window kernels issue (cells x shifts) x 512.
 #include "gform.h"
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -64,7 +65,6 @@ template <int M>
 __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
                                                       int cls) {
   const CurArgs& A = GA.c;
-  const LdsimConsts* c = A.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x;
@@ -74,9 +74,29 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
   const bool stamps = (GA.dbg & 128) != 0;
   unsigned long long ts0 = 0, ts_stage = 0, ts_g = 0, ts_p = 0, ts_e = 0, ts_mark = 0;
   if (stamps) ts0 = __builtin_amdgcn_s_memtime();
-  // (the flag and the whole GInfo record are requested before the first branch: one round trip to memory instead of two)
-  const int flagged = GA.flags[pair];
-  const GInfo gi = GA.gi[pair];
+  // The flag and the GInfo record in ONE round trip to memory: sixteen words requested back to back, and an empty asm statement
+  // that consumes them all -- left to itself the compiler sinks each field's load behind the branch that first needs it (flag,
+  // status, dimensions, window: four dependent trips in the round-3 ISA).  Wave-uniform: kept in scalar registers.
+  int flagged;
+  GInfo gi;
+  {
+    const int4* q = (const int4*)(GA.gi + pair);
+    const int4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+    int fl = GA.flags[pair];
+    int a0 = w0.x, a1 = w0.y, a2 = w0.z, a3 = w0.w, a4 = w1.x, a5 = w1.y, a6 = w1.z, a7 = w1.w, a8 = w2.x, a9 = w2.y, a10 = w2.z,
+        a11 = w2.w, a12 = w3.x, a13 = w3.y, a14 = w3.z, a15 = w4.x, a16 = w4.y;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10),
+                 "+v"(a11), "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15), "+v"(a16), "+v"(fl));
+    auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    flagged = sc(fl);
+    gi.ncol = sc(a0); gi.NJ = sc(a1); gi.jmin = sc(a2); gi.u_min = sc(a3);
+    gi.NU = sc(a4); gi.edge_bound = sc(a5); gi.NB = sc(a6); gi.status = sc(a7);
+    gi.NQ = sc(a8); gi.it0 = sc(a9); gi.T = sc(a10); gi.it_w0 = sc(a11);
+    gi.it_w1 = sc(a12); gi.emask = sc(a13); gi.wave_ok = sc(a14); gi.pad = 0;
+    gi.off = ((unsigned long long)(unsigned)sc(a16) << 32) | (unsigned)sc(a15);
+    gi.size = 0;
+  }
+  static_assert(sizeof(GInfo) == 80 && offsetof(GInfo, off) == 64, "GInfo layout");
   float* out = A.out + pair * (int64_t)A.T;
   if (flagged) {                                    // the monolithic kernel writes this pair, in full
     if (A.win && !big_list && tid == 0) { A.win[2 * pair] = 0; A.win[2 * pair + 1] = A.T; }
@@ -112,11 +132,10 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
   double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
   // per listed cell: response row offset (doubles into the padded table) | byte offsets of its X column and Y row << 32, << 48
   unsigned long long* s_info = (unsigned long long*)(s_Z + G_NODES * L.zs);
-  __shared__ int s_ncell;
+  __shared__ int s_ncell, s_nreal;
   const int xs = L.xs, ys = L.ys, zs = L.zs;
   double* ow = s_out + wv * TT;
-  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
-  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};
   const int kk = lane >> 4, jj = lane & 15;
   const int nkp = GA.nkp;
   unsigned long long n_mfma = 0, n_useful = 0;
@@ -138,30 +157,79 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
       if (loaded != b) {                           // (one batch: the tables stay for every tick tile)
         __syncthreads();
-        // tables: thread (row n = tid / 8, lane of 8) copies its row's columns -- no index division; Z two doubles at a time
-        const int ncell_l = cells[0];
+        // tables: thread (row n = tid / 8, lane of 8) copies its row's columns -- no index division; Z two doubles at a time.
+        // EVERY load of the batch is in flight before the first store: the first columns of each table into registers (what a
+        // typical pair has: X and Y up to 16 columns, Z up to 64 shifts, 256 cells), one wait, the stores; the rest by the plain
+        // loops.  [Round 3 staged table after table, each `load, wait, store` -- and the cell list only after its count had
+        // arrived: three to five dependent trips to HBM per batch, a quarter of a wave's life by the cycle stamps.]  The cell
+        // loop runs over the list's capacity (known from the dimensions), not over the count in the record.
+        const int cell_cap = L.cellcap;
         {
-          const int n = tid >> 3, c8 = tid & 7;
-          if (!(GA.dbg & 4)) {
-            for (int cc = c8; cc < ncol; cc += 8) s_X[n * xs + cc] = n < rows ? gX[n * ncol + cc] : 0.0;
-            for (int cc = c8; cc < NJ; cc += 8) s_Y[n * ys + cc] = n < rows ? gY[n * NJ + cc] : 0.0;
+          // (the thread index through an opaque asm: the addresses below are then computed here, per batch, instead of being
+          // hoisted out of the loops and spilled -- their reloads from scratch had put a wait in front of every load)
+          int tid_l = tid;
+          asm volatile("" : "+v"(tid_l));
+          const int n = tid_l >> 3, c8 = tid_l & 7;
+          const bool row = n < rows;
+          double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+          double2 z0 = {0, 0}, z1 = {0, 0}, z2 = {0, 0}, z3 = {0, 0};
+          unsigned ce0 = 0, ce1 = 0;
+          const bool stage = !(GA.dbg & 4);
+          if (stage) {
+            // (unconditional loads from clamped, always valid addresses: a load under a per-lane condition is waited for at the
+            // end of its branch, which serialises them again; the conditions are applied at the stores)
+            const int nn = min(n, rows - 1);
+            const double* xr = gX + nn * ncol;
+            const double* yr = gY + nn * NJ;
+            x0 = xr[min(c8, ncol - 1)];
+            x1 = xr[min(c8 + 8, ncol - 1)];
+            y0 = yr[min(c8, NJ - 1)];
+            y1 = yr[min(c8 + 8, NJ - 1)];
+            if (z_lds) {
+              const double* zr = gZ + nn * NUr + 2 * c8;                 // (NUr is a multiple of 16)
+              z0 = *(const double2*)zr;
+              z1 = *(const double2*)(zr + min(16, NUr - 16));
+              z2 = *(const double2*)(zr + min(32, NUr - 16));
+              z3 = *(const double2*)(zr + min(48, NUr - 16));
+            }
+          }
+          ce0 = (unsigned)cells[G_CELL0 + min(tid_l, cell_cap - 1)];
+          ce1 = (unsigned)cells[G_CELL0 + min(tid_l + GT, cell_cap - 1)];
+          const int ncell_l = cells[0], nreal_l = cells[1];
+          auto info_word = [&](unsigned ce) {
+            const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
+            return (unsigned long long)((ce & 0xFFFFu) * (unsigned)nkp) | ((unsigned long long)(col * 8u) << 32) |
+                   ((unsigned long long)(jc * 8u) << 48);                // (row word | column word: offsets in doubles / bytes)
+          };
+          if (stage) {
+            if (c8 < ncol) s_X[n * xs + c8] = row ? x0 : 0.0;
+            if (c8 + 8 < ncol) s_X[n * xs + c8 + 8] = row ? x1 : 0.0;
+            if (c8 < NJ) s_Y[n * ys + c8] = row ? y0 : 0.0;
+            if (c8 + 8 < NJ) s_Y[n * ys + c8 + 8] = row ? y1 : 0.0;
+            if (z_lds) {
+              double* zd = s_Z + n * zs + 2 * c8;
+              zd[0] = row ? z0.x : 0.0; zd[1] = row ? z0.y : 0.0;
+              if (NUr > 16) { zd[16] = row ? z1.x : 0.0; zd[17] = row ? z1.y : 0.0; }
+              if (NUr > 32) { zd[32] = row ? z2.x : 0.0; zd[33] = row ? z2.y : 0.0; }
+              if (NUr > 48) { zd[48] = row ? z3.x : 0.0; zd[49] = row ? z3.y : 0.0; }
+            }
+            for (int cc = c8 + 16; cc < ncol; cc += 8) s_X[n * xs + cc] = row ? gX[n * ncol + cc] : 0.0;
+            for (int cc = c8 + 16; cc < NJ; cc += 8) s_Y[n * ys + cc] = row ? gY[n * NJ + cc] : 0.0;
             if (z_lds)
-              for (int cc = 2 * c8; cc < NUr; cc += 16) {
+              for (int cc = 2 * c8 + 64; cc < NUr; cc += 16) {
                 double2 v = {0.0, 0.0};
-                if (n < rows) v = *(const double2*)(gZ + n * NUr + cc);
+                if (row) v = *(const double2*)(gZ + n * NUr + cc);
                 s_Z[n * zs + cc] = v.x;
                 s_Z[n * zs + cc + 1] = v.y;
               }
           }
           if (c8 == 0) s_X[n * xs + ncol] = 0.0;
+          // (entries past the list's padded count are never read: the loops below stop at the count)
+          if (tid_l < cell_cap) s_info[tid_l] = info_word(ce0);
+          if (tid_l + GT < cell_cap) s_info[tid_l + GT] = info_word(ce1);
+          for (int i = tid_l + 2 * GT; i < ncell_l; i += GT) s_info[i] = info_word((unsigned)cells[G_CELL0 + i]);
+          if (tid_l == 0) { s_ncell = ncell_l; s_nreal = nreal_l; }
         }
-        for (int i = tid; i < ncell_l; i += GT) {
-          const unsigned ce = (unsigned)cells[G_CELL0 + i];
-          const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
-          s_info[i] = (unsigned long long)((ce & 0xFFFFu) * (unsigned)nkp) | ((unsigned long long)(col * 8u) << 32) |
-                      ((unsigned long long)(jc * 8u) << 48);      // (row word | column word: offsets in doubles / bytes)
-        }
-        if (tid == 0) s_ncell = ncell_l;
         loaded = b;
       }
       __syncthreads();
@@ -170,7 +238,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       const int ngrp = ncell >> 2;                 // a multiple of GPF (gtables_kernel pads the list with weightless cells)
       if (tid == 0)
         n_useful += (unsigned long long)min(G_NODES, NQ - b * G_NODES) *
-                    ((unsigned long long)cells[1] * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
+                    ((unsigned long long)s_nreal * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
       // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k] -- for both tiles of the wave at once: one A
       // operand (Z of the lane's shift and node) feeds two independent accumulation chains.
       auto pstep2 = [&](const d4& g0acc, const d4& g1acc, int k0) {
@@ -254,7 +322,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       // group t + 2 (past the last group the indices wrap: valid, unused).  Every load is issued one slot (LDS) or GPF (L2) before
       // its use, no branch, and sched_barrier keeps the compiler from sinking them back to their uses.  [Prefetching the next tile
       // pair's first groups across the P step changed nothing: the loop runs at the rate the L1 delivers the B operands.]
-      const bool run_tiles = wv < n32 && ngrp > 0 && !(A.debug_phases & 0x100000);
+      const bool run_tiles = n32 > 0 && ngrp > 0 && !(A.debug_phases & 0x100000);
       const unsigned* s_inf32 = (const unsigned*)s_info;
       const char* xl = (const char*)(s_X + jj * xs);
       const char* yl = (const char*)(s_Y + jj * ys);
@@ -264,7 +332,27 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       };
       auto row_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk)]; };
       auto col_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk) + 1]; };
-      for (int kt = wv; kt < n32 && run_tiles; kt += GW) {
+      // The tile pairs are dealt to the pair's two waves alternately; an odd one left over (the survey table's 82 staged ticks are
+      // three tile pairs) is shared: each wave multiplies it with half of the cell groups, and both run the P step and the edge
+      // column on their partial G -- every step after G is linear in it, and the two tick arrays are added anyway.  [Dealt whole,
+      // one wave ran two tile pairs while the other waited at the barrier with one: a sixth of a wave's life by the cycle stamps.]
+      const int n_whole = (GA.dbg & 256) ? n32 : (n32 & ~1);
+      const int rounds = ngrp / GPF;
+      for (int kt = wv; run_tiles; kt += GW) {
+        int g_lo = 0, g_hi = ngrp;
+        bool shared = false;
+        if (kt >= n_whole) {
+          if (n_whole == n32) break;
+          kt = n32 - 1;
+          shared = true;
+          if (rounds >= 2) {
+            const int h = (rounds >> 1) * GPF;
+            g_lo = wv == 0 ? 0 : h;
+            g_hi = wv == 0 ? h : ngrp;
+          } else if (wv != 0) {
+            break;
+          }
+        }
         const int k0 = kA + 32 * kt;
         // (M = 2: tile 0 holds the even, tile 1 the odd indices of the 32 -- lane jj loads k0 + 2 jj and k0 + 2 jj + 1, adjacent)
         const double* rpl = GA.resp_pad + RESP_PAD + k0 + (M == 2 ? 2 * jj : jj);
@@ -274,19 +362,19 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         unsigned lo[2], hi[2];
 #pragma unroll
         for (int u = 0; u < GPF; u++) {
-          const double* q = rpl + row_word(u);
+          const double* q = rpl + row_word(g_lo + u);
           b0[u] = q[0];
           b1[u] = q[B1];
         }
-        lo[0] = row_word(GPF);
-        hi[0] = col_word(0);
-        hi[1] = col_word(1);
+        lo[0] = row_word(g_lo + GPF);
+        hi[0] = col_word(g_lo);
+        hi[1] = col_word(g_lo + 1);
         xv[0] = *(const double*)(xl + (hi[0] & 0xFFFFu));
         yv[0] = *(const double*)(yl + (hi[0] >> 16));
         if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-        for (int g0 = 0; g0 < ngrp; g0 += GPF) {
+        for (int g0 = g_lo; g0 < g_hi; g0 += GPF) {
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
             const double a = xv[u & 1] * yv[u & 1];
@@ -302,7 +390,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        n_mfma += 2 * ngrp;
+        n_mfma += 2 * (g_hi - g_lo);
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_g += t - ts_mark; ts_mark = t; }
         if (!(A.debug_phases & 0x200000)) {
           pstep2(acc0, acc1, k0);
@@ -343,6 +431,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             if (stamps) ts_e += __builtin_amdgcn_s_memtime() - ts_mark;
           }
         }
+        if (shared) break;
       }
     }
     if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
@@ -462,6 +551,13 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   HIPCHK(hipGetLastError());
   GArgs GA{};
   if ((rc = resp_pad_ensure(ctx, a, &GA.k_lo, &GA.k_hi, &GA.nkp))) return rc;
+  {
+    int ek[NEDGE], klo, khi;
+    edge_ks(&ctx->h_consts, a, ek, klo, khi);
+    for (int e = 0; e < NEDGE; e++) GA.edge_k[e] = ek[e];
+    GA.k_stage_lo = klo;
+    GA.k_stage_hi = khi;
+  }
   // ticks per tile of the correlation: the pairs' windows are as long as the staged response support (over M) plus their
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;

@@ -124,7 +124,7 @@ __device__ __forceinline__ int slice_shift_of(const LdsimConsts* c, double z_sta
   return (int)kr - M * it_ref;
 }
 
-__device__ __forceinline__ void edge_ks(const LdsimConsts* c, const CurArgs& A, int* edge_k, int& k_stage_lo, int& k_stage_hi) {
+__host__ __device__ __forceinline__ void edge_ks(const LdsimConsts* c, const CurArgs& A, int* edge_k, int& k_stage_lo, int& k_stage_hi) {
   const double V = c->time_window / c->response_sampling;
   edge_k[0] = 0; edge_k[1] = -1; edge_k[2] = -1;
   int ka = (int)floor(V - 0.5 - 1e-6);

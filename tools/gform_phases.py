@@ -30,6 +30,8 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
         "occ": ((0, 0, 0), (0, -1, 0), (0, -2, 0), (0, -3, 0), (0, 1, 0), (0, 2, 0), (0, 0, 0)),
         # in-kernel cycle stamps of gcorr_kernel's waves (debug_gform 128; printed to stderr by the library)
         "stamps": ((0, 0, 128), (0, 0, 0)),
+        # an odd tile pair shared by the pair's two waves (default) against dealt whole (debug_gform 256)
+        "share": ((0, 0, 0), (0, 0, 256), (0, 0, 128), (0, 0, 384), (0, 0, 0), (0, 0, 256)),
         "corr": ((0, 0, 0), (0x100000, 0, 0), (0x200000, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0x100000, 0, 4), (0x100000, 0, 12),
                  (0x100000, 0, 14), (0, -12, 0), (0, 6, 0), (0, 0, 0))}
 for mask, pad, dbg in RUNS[WHICH]:
@@ -38,6 +40,6 @@ for mask, pad, dbg in RUNS[WHICH]:
     lib.set_option("debug_gform", dbg)
     st = ch.run(0, len(seg), want_fractions=True)
     ms = ch.kernel_ms()
-    print(f"{cfg} {resp} debug_phases {mask:#10x} lds pad {pad:2d} KB dbg {dbg:2d}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  fallback {ms['fallback_ms']:.2f}  adc {ms['adc_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf}", flush=True)
+    print(f"{cfg} {resp} debug_phases {mask:#10x} lds pad {pad:2d} KB dbg {dbg:2d}: tables {ms['weights_ms']:.2f} ms  corr {ms['mac_ms']:.2f}  fallback {ms['fallback_ms']:.2f}  adc {ms['adc_ms']:.2f}  pairs {st.n_pairs} pool {st.n_wbuf} mfma {st.n_dfma // 1024}", flush=True)
 lib.set_option("debug_phases", 15)
 lib.set_option("debug_gform", 0)
