@@ -585,11 +585,15 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   if (getenv("LDSIM_DEBUG_GFORM")) {      // class sizes of the launch, and why pairs miss the wave kernel
     std::vector<GInfo> h((size_t)n);
     HIPCHK(hipMemcpy(h.data(), gi, (size_t)n * sizeof(GInfo), hipMemcpyDeviceToHost));
-    long n1 = 0, nu = 0, xy = 0, sl = 0, nb2 = 0;
+    long n1 = 0, nu = 0, xy = 0, sl = 0, nb2 = 0, small = 0, mid = 0;
+    double s_ncol = 0, s_nj = 0, s_nu = 0, s_nq = 0;
     for (const GInfo& g : h) {
       if (g.status != 1) continue;
       n1++;
       nb2 += g.NB > 1;
+      small += g.ncol <= 16 && g.NJ <= 16;
+      mid += g.ncol <= 32 && g.NJ <= 32;
+      s_ncol += g.ncol; s_nj += g.NJ; s_nu += g.NU; s_nq += g.NQ;
       if (g.wave_ok) continue;
       if (g.NU > 2 * G_NUCAP) nu++;
       else if (g.ncol + g.NJ > 80) xy++;
@@ -598,6 +602,8 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
     fprintf(stderr, "gform: %ld pairs, %ld with tables (%ld in 2+ node batches), workgroup tables kernel %llu (NU > 256: %ld, X | Y bins > 80: %ld, "
             "slices > 64: %ld), wide wave tables kernel %llu, correlation launches at %d KB / %d KB of LDS: %llu / %llu pairs, pool %.2f GB\n", (long)n, n1, nb2, n_wg, nu, xy, sl,
             n_w2, b1 >> 10, b2 >> 10, n_cls[1], n_cls[2], total * 8e-9);
+    fprintf(stderr, "gform: mean columns %.1f rows %.1f shifts %.1f nodes %.1f; pairs with <= 16 columns and rows %ld, <= 32 %ld\n", s_ncol / n1, s_nj / n1,
+            s_nu / n1, s_nq / n1, small, mid);
   }
   if ((rc = ldsim_ensure(ctx, SB_WBUF, (size_t)(total + 16) * 8))) return rc;
   HIPCHK(hipMemsetAsync(&counters[7], 0, 8, st));

@@ -58,8 +58,8 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
   __syncthreads();
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
-  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
-  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};      // (edge_ks of the launch's constants, from the host)
+  const int k_stage_lo = GA.k_stage_lo, k_stage_hi = GA.k_stage_hi;
 
   // ---- one chunk's slices (<= 64 slices, <= 64 distinct shifts): response shift, edge flags, member lists ordered by shift.
   // Run by one wave; results in s_dz / s_dzs / s_invs / s_inval / s_zord / s_ustart and s_misc[3..5], [20].
@@ -441,8 +441,8 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   wsync();
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
-  int edge_k[NEDGE], k_stage_lo, k_stage_hi;
-  edge_ks(c, A, edge_k, k_stage_lo, k_stage_hi);
+  const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};      // (edge_ks of the launch's constants, from the host)
+  const int k_stage_lo = GA.k_stage_lo, k_stage_hi = GA.k_stage_hi;
   bool bad = false;          // (wave-uniform) inconsistent with the set-up pass: monolithic kernel
 
   // ---- sample -> response cell maps, member lists ordered by response index ----------------------------------------------------------
