@@ -93,10 +93,25 @@ def cpu_baseline(response, n_seg=400):
     adc, _, _ = O.get_adc_values(ps, pts, tt, np.full(len(upix), consts.detector.DISCRIMINATION_THRESHOLD))
     O.digitize(adc)
     dt = time.perf_counter() - t0
+    # quench + drift alone on the whole workload size ("quench+drift for all sizes"): the two HBM-bound stages of
+    # the path on one host thread, median of five passes after a warm-up
+    full = synth.make_segments(SEGS_PER_GPU, seed=synth.SEED_BASE + 2, segs_per_event=5000)
+    batching.swap_coordinates(full)
+    qd = []
+    for i in range(6):
+        work = full.copy()
+        t1 = time.perf_counter()
+        O.quench(work, consts.physics.BIRKS)
+        O.drift(work)
+        qd.append(time.perf_counter() - t1)
+    qd_t = sorted(qd[1:])[2]
     return {"value": n_seg / dt, "unit": "segments/s", "cores": cores, "kind": "port",
             "physical_cores": phys, "usable_cpus": usable, "cpu_model": model,
             "sample": f"{n_seg} segments of the same synthetic set (charge chain), {dt:.1f} s; OpenMP ({cores} threads) over "
-                      f"(segment,pixel) pairs in tracks_current, the other stages single-threaded"}
+                      f"(segment,pixel) pairs in tracks_current, the other stages single-threaded",
+            "quench_drift_only": {"value": SEGS_PER_GPU / qd_t, "unit": "segments/s", "cores": 1, "segments": SEGS_PER_GPU,
+                                  "ms": 1e3 * qd_t, "note": "oracle quench + drift on all 100000 segments of the workload, one "
+                                                            "thread, median of 5"}}
 
 
 def profiled_traffic(config, kernel):

@@ -71,9 +71,10 @@ __device__ __forceinline__ double exp_neg_sel(double x) {
 }
 
 // exp(x) for x <= 0 with a 64-entry table: x = (64 e + j) ln2 / 64 + r, |r| <= ln2 / 128, exp(x) = 2^e * 2^(j/64) * exp(r), exp(r) by its
-// Taylor polynomial to r^5 (truncation 3.5e-17).  Five multiply-adds fewer than exp_neg's 13-term polynomial, for one read of an LDS
-// table that 64 lanes hit without a bank conflict (entry j lies in banks 2j, 2j + 1); ~1.5 ulp.  gtables_wave_kernel spends 58 % of
-// its VALU instructions in Gaussians.  `tab` = g_exp2_64 staged in LDS.
+// Taylor polynomial to r^4 (truncation |r|^5 / 120 <= 3.9e-14 relative: the tables it fills carry a quadrature error of 1e-7 of
+// their peak, and 1e-13 is what round 3's degree-5 form was held to; one multiply-add fewer per Gaussian).  Against exp_neg's
+// 13-term polynomial: nine multiply-adds fewer for one read of an LDS table that 64 lanes hit without a bank conflict (entry j
+// lies in banks 2j, 2j + 1).  gtables_wave_kernel spends 58 % of its VALU instructions in Gaussians.  `tab` = g_exp2_64 staged in LDS.
 __device__ const double g_exp2_64[64] = {
   0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
   0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
@@ -98,8 +99,7 @@ __device__ __forceinline__ double exp_neg_tab(double x, const double* __restrict
   double r = fma(-k, 0x1.62e4200000000p-7, xc);                 // ln2 / 64: high part (k times it is exact), low part
   r = fma(-k, 0x1.fdf473de6af28p-28, r);
   const int ki = (int)k;
-  double p = 1.0 / 120.0;
-  p = fma(p, r, 1.0 / 24.0);
+  double p = 1.0 / 24.0;
   p = fma(p, r, 1.0 / 6.0);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
