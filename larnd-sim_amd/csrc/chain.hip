@@ -380,6 +380,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   int32_t* d_hitoff = d_hitcnt + U;
   FeeArgs F{};
   F.c = ctx->d_consts;
+  F.k = FEEK_FROM(h);
   F.U = U;
   F.upix = d_upix; F.ubatch = d_ubatch; F.uoff = d_uoff;
   F.pair_val = d_vals2; F.pair_key = d_keys2;

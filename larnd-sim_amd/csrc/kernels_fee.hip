@@ -7,9 +7,11 @@
 // segment index), so the pixel's waveform is a register-owned sum over <= 50 compact f32 waveforms
 // (no atomics, no [U][N_t][50] slab), the trigger scan is a wave-64 prefix scan + ballot over
 // 64-tick chunks, and the per-hit backtracking fractions are wave reductions over the hit spans.
+#include <algorithm>
 #include "ldsim_args.h"
 
 #define FEE_THREADS 256
+#define FEE_SPAN 512     // ticks of LDS of the one-wave instantiation of pixel_adc_kernel
 #define NT_MAX 4096   // max len(TIME_TICKS) held in LDS
 #define A_MAX 64      // max MAX_ADC_VALUES
 #define M_MAX 64      // max MAX_TRACKS_PER_PIXEL handled by the chain kernel
@@ -39,22 +41,26 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
 }
 __device__ __forceinline__ double wave_sum(double v) { return lane_bcast(wave_incl_scan(v, 0), 63); }
 
-// q(ic): buffer-convolved charge of tick ic (fee.py:566-579), taps limited by last_reset and N_t
+// q(ic): buffer-convolved charge of tick ic (fee.py:566-579), taps limited by last_reset and N_t.  S holds the ticks
+// [s_lo, s_hi) of the pixel's waveform (element 0 = tick s_lo); it is zero outside them.
 __device__ __forceinline__ double conv_q(const double* S, int NT, int ic, int last_reset, int ntap, const double* wtap,
-                                         double dt, bool has_rt) {
+                                         double dt, bool has_rt, int s_lo, int s_hi) {
   double q = 0;
   if (has_rt) {
     int cs = ic - ntap;
     if (cs < last_reset) cs = last_reset;
+    if (cs < s_lo) cs = s_lo;
     int ce = ic + 1 < NT ? ic + 1 : NT;
-    for (int jc = cs; jc < ce; jc++) q += S[jc] * dt * wtap[ic - jc];
-  } else if (ic < NT) {
-    q = S[ic] * dt;
+    if (ce > s_hi) ce = s_hi;
+    for (int jc = cs; jc < ce; jc++) q += S[jc - s_lo] * dt * wtap[ic - jc];
+  } else if (ic < NT && ic >= s_lo && ic < s_hi) {
+    q = S[ic - s_lo] * dt;
   }
   return q;
 }
 
-__device__ __forceinline__ double digitize_one(const LdsimConsts* c, double q, double gain) {
+template <class K>
+__device__ __forceinline__ double digitize_one(const K* c, double q, double gain) {
   const double mV = 1e-3 * (1e-6 * 1.0);
   double v = q * gain + c->v_pedestal * mV - c->v_cm * mV;
   v = v > 0 ? v : 0;
@@ -79,9 +85,10 @@ struct HitRec {
 // [t_first, t_end): the ticks where S can be non-zero.  Without noise and with a positive threshold the scan's state does not
 // change on ticks whose charge is zero while the ADC is idle and the sum below threshold, so it starts at t_first and stops
 // once past t_end + ntap with the ADC idle (with noise every tick draws its normals and may trigger: all ticks are walked).
-__device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_stop, double thr, double time_padding,
+template <class K>
+__device__ int adc_scan(const K* c, const double* S, int NT, double t_stop, double thr, double time_padding,
                         int lane, HitRec* hits /* LDS, [A] */, const double* wtap, int ntap, const float* __restrict__ z,
-                        int* n_draws, int t_first = 0, int t_end = 1 << 30) {
+                        int* n_draws, int t_first = 0, int t_end = 1 << 30, int s_lo = 0, int s_hi = 1 << 30) {
   const double dt = c->time_sampling;
   const bool has_rt = c->buffer_risetime > 0;
   const int A = c->max_adc_values;
@@ -105,7 +112,7 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
     // liveness must be contiguous from lane 0: once a lane is dead the loop has ended
     unsigned long long live_mask = __ballot(live);
     int n_live = (live_mask == ~0ull) ? 64 : __ffsll((long long)~live_mask) - 1;
-    double q = (lane < n_live) ? conv_q(S, NT, my_ic, last_reset, ntap, wtap, dt, has_rt) : 0.0;
+    double q = (lane < n_live) ? conv_q(S, NT, my_ic, last_reset, ntap, wtap, dt, has_rt, s_lo, s_hi) : 0.0;
     const double incl = wave_incl_scan(q, lane);
     double qs = q_sum + incl;
     double q_noise = 0.0, disc_noise = 0.0;
@@ -136,7 +143,7 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
     double qi = 0;
     for (int base = ict + 1; base <= integrate_end; base += 64) {
       int t = base + lane;
-      double v = (t <= integrate_end) ? conv_q(S, NT, t, last_reset, ntap, wtap, dt, has_rt) : 0.0;
+      double v = (t <= integrate_end) ? conv_q(S, NT, t, last_reset, ntap, wtap, dt, has_rt, s_lo, s_hi) : 0.0;
       qi += wave_sum(v);
     }
     q_sum += qi;
@@ -178,10 +185,15 @@ __device__ int adc_scan(const LdsimConsts* c, const double* S, int NT, double t_
 }
 
 // ---- chain kernel ----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
-  const LdsimConsts* c = F.c;
-  const int64_t u = blockIdx.x;
-  if (u >= F.U) return;
+// Two instantiations.  THREADS = 256, the whole tick axis in LDS (16-26 KB: eight pixels per CU), for every pixel when noise is on
+// (the scan then walks every tick) and for pixels whose slots' windows span more than FEE_SPAN ticks.  THREADS = 64 -- a wave per
+// pixel, FEE_SPAN ticks of LDS starting at the pixel's first written tick -- for the others, over a list (fee_span_kernel): the
+// kernel is a chain of dependent trips to memory per pixel (pair range -> keys -> slots' starts and windows -> rows), so what
+// counts is pixels in flight, and a CU holds 2048 threads: 8 pixels of 256 threads, 19 of 64 at 8.4 KB each.
+template <int THREADS>
+__device__ __forceinline__ void pixel_adc_body(const FeeArgs& F, const int64_t u, const int32_t* __restrict__ span /* [U][2] or NULL */,
+                                               const int s_cap) {
+  const FeeK* c = &F.k;          // (kernel arguments: scalar registers, no loads)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NT = c->n_time_ticks;
   const int A = c->max_adc_values, M = c->max_tracks_per_pixel;
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   __syncthreads();
   {
     int cnt = 0;
-    for (int64_t p = p0 + tid; p < p1; p += FEE_THREADS) cnt += (F.pair_key[p] & 15ull) != 15ull;
+    for (int64_t p = p0 + tid; p < p1; p += THREADS) cnt += (F.pair_key[p] & 15ull) != 15ull;
     if (cnt) atomicAdd(&s_nvalid, cnt);
   }
   __syncthreads();
@@ -239,7 +251,10 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   }
   // ---- summed waveform: each thread owns ticks tid, tid+256, ... and adds the slots' rows in slot order, each over the ticks
   // its window puts on the pixel's time axis (detsim.py:516-520) ------------------------------------------------------------
-  for (int t = tid; t < NT; t += FEE_THREADS) S[t] = 0;
+  // the ticks S holds: all of them, or the pixel's window from the set-up pass (every slot's ticks lie inside it)
+  const int s_lo = span ? span[2 * u] : 0;
+  const int s_hi = span ? min(s_lo + s_cap, NT) : NT;
+  for (int t = tid; t < s_hi - s_lo; t += THREADS) S[t] = 0;
   if (tid == 0) {          // the ticks the slots' windows cover
     int t_lo = NT, t_hi = 0;
     for (int k = 0; k < n_slots; k++) {
@@ -253,15 +268,15 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
     const int st = s_start[k];
     const int lo = max(st + s_w0[k], 0), hi = min(st + s_w1[k], NT);
     const float* wf = F.waves + s_row[k] * (int64_t)F.T - st;
-    for (int t = lo + ((tid - lo) & (FEE_THREADS - 1)); t < hi; t += FEE_THREADS) S[t] += (double)wf[t];
+    for (int t = lo + ((tid - lo) & (THREADS - 1)); t < hi; t += THREADS) S[t - s_lo] += (double)wf[t];
   }
   __syncthreads();
   // ---- trigger scan on wave 0 ----------------------------------------------------------------------------------------
   if (wv == 0) {
     const double thr = F.thr_table ? F.thr_table[F.upix[u]] : F.threshold;
     int nd = 0;
-    int nh = (F.debug & 0x20000) ? 0 : adc_scan(c, S, NT, 1 * c->time_interval[1], thr, F.time_padding, lane, hits, wtap, ntap,
-                      F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd, s_trange[0], s_trange[1]);
+    int nh = (F.debug & 0x20000) ? 0 : adc_scan(c, S, NT, 1 * c->time_interval1, thr, F.time_padding, lane, hits, wtap, ntap,
+                      F.noise_z ? F.noise_z + u * (int64_t)F.noise_nd : nullptr, &nd, s_trange[0], s_trange[1], s_lo, s_hi);
     if (lane == 0) {
       s_nh = nh;
       if (F.n_draws) F.n_draws[u] = nd;
@@ -270,7 +285,7 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   __syncthreads();
   const int nh = s_nh;
   const double gain = F.gain_table ? F.gain_table[F.upix[u]] : c->gain * (1e-3 * (1e-6 * 1.0)) / 1.0;   // GAIN * mV / e
-  for (int h = tid; h < A; h += FEE_THREADS) {
+  for (int h = tid; h < A; h += THREADS) {
     double q = h < nh ? hits[h].q : 0.0;
     F.adc_list[u * A + h] = q;
     F.adc_ticks[u * A + h] = h < nh ? hits[h].tick : 0.0;
@@ -284,24 +299,42 @@ __global__ void __launch_bounds__(FEE_THREADS) pixel_adc_kernel(FeeArgs F) {
   // ---- backtracking fractions (fee.py:572-573, 633-635): sum_jc sig_k[jc]*G[min(ntap, b-jc)] / true_q ------------
   if (F.fractions && !(F.debug & 0x40000)) {
     double* fr = F.fractions + u * (int64_t)A * M;       // zero on entry (one memset of the whole array by the launcher)
-    for (int k = wv; k < n_slots; k += FEE_THREADS / 64) {
+    for (int k = wv; k < n_slots; k += THREADS / 64) {      // (a wave per slot)
       const float* wf = F.waves + s_row[k] * (int64_t)F.T;
       const int st = s_start[k];
       for (int h = 0; h < nh; h++) {
         int lr = hits[h].lr, b = hits[h].b;
         int hi = b < NT - 1 ? b : NT - 1;
+        // (the ticks of the hit span the slot's window covers: a first hit's span starts at tick 0, a thousand ticks before
+        // any window; same terms in the same lane-strided order)
+        const int j0 = max(lr, st + s_w0[k]), j1 = min(hi, st + s_w1[k] - 1);
         double acc = 0;
-        for (int jc = lr + lane; jc <= hi; jc += 64) {
+        for (int jc = j0 + ((lr + lane - j0) & 63); jc <= j1; jc += 64) {
           int it = jc - st;
-          if (it >= s_w0[k] && it < s_w1[k]) {
-            int d = b - jc;
-            acc += (double)wf[it] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
-          }
+          int d = b - jc;
+          acc += (double)wf[it] * (rt > 0 ? G[d < ntap ? d : ntap] : dt);
         }
         acc = wave_sum(acc);
         if (lane == 0) fr[h * M + k] = hits[h].tq > 0 ? acc / hits[h].tq : acc;
       }
     }
+  }
+}
+
+// one workgroup per unique pixel
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) pixel_adc_kernel(FeeArgs F) {
+  if ((int64_t)blockIdx.x < F.U) pixel_adc_body<THREADS>(F, (int64_t)blockIdx.x, nullptr, 0);
+}
+// a fixed grid walks a device-built list of pixels (its length stays on the device: no host round trip to size the launch)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) pixel_adc_list_kernel(FeeArgs F, const int32_t* __restrict__ list,
+                                                                const unsigned long long* __restrict__ count,
+                                                                const int32_t* __restrict__ span, int s_cap) {
+  const int64_t n = (int64_t)*count;
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    pixel_adc_body<THREADS>(F, (int64_t)list[i], span, s_cap);
+    __syncthreads();          // (the next pixel reuses the workgroup's LDS)
   }
 }
 
@@ -331,6 +364,44 @@ extern "C++" int fee_clear_unwritten_fractions(ldsim_ctx* ctx, int64_t U, const 
   return 0;
 }
 
+// The ticks a pixel's slots write, [t_lo, t_hi), from the same expressions as pixel_adc_kernel; the pixels whose window fits
+// FEE_SPAN ticks go to list 0, the others to list 1 (one atomic per wave and list).
+__global__ void __launch_bounds__(256) fee_span_kernel(FeeArgs F, int32_t* __restrict__ span, int32_t* __restrict__ lists /* [2][U] */,
+                                                       unsigned long long* __restrict__ counts /* [2] */) {
+  const FeeK* c = &F.k;
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int cls = -1;
+  if (u < F.U) {
+    const int NT = c->n_time_ticks, M = c->max_tracks_per_pixel;
+    const double dt = c->time_sampling;
+    const int64_t p0 = F.uoff[u], p1 = F.uoff[u + 1];
+    int n_slots = 0;
+    for (int64_t p = p0; p < p1 && n_slots < M; p++) n_slots += (F.pair_key[p] & 15ull) != 15ull;      // (valid ones come first)
+    int t_lo = NT, t_hi = 0;
+    for (int k = 0; k < n_slots; k++) {
+      const int r = F.pair_val[p0 + k] / F.P;
+      const int st = (int)py_round(F.track_starts[r] / dt);
+      const int w0 = F.win ? F.win[2 * (p0 + k)] : 0, w1 = F.win ? F.win[2 * (p0 + k) + 1] : F.T;
+      const int lo = max(st + w0, 0), hi = min(st + w1, NT);
+      if (hi > lo) { t_lo = min(t_lo, lo); t_hi = max(t_hi, hi); }
+    }
+    if (t_hi <= t_lo) { t_lo = 0; t_hi = 0; }
+    span[2 * u] = t_lo;
+    span[2 * u + 1] = t_hi;
+    cls = (t_hi - t_lo <= FEE_SPAN) ? 0 : 1;
+  }
+  for (int cc = 0; cc < 2; cc++) {
+    const unsigned long long m = __ballot(cls == cc);
+    if (!m) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&counts[cc], (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (cls == cc) lists[(int64_t)cc * F.U + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)u;
+  }
+}
+
 extern "C++" int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F) {
   if (F.U == 0) return 0;
   const LdsimConsts& h = ctx->h_consts;
@@ -342,7 +413,31 @@ extern "C++" int fee_launch_chain(ldsim_ctx* ctx, const FeeArgs& F) {
   // (the kernel writes the (hit, slot) entries that exist; everything else of `fractions` reads 0 like the reference's array once
   // fee_clear_unwritten_fractions has run: the dense downloads call it -- clearing 12 KB per pixel in every launch cost 0.45 ms per
   // 100 k segments, and the compact download reads the written entries only)
-  hipLaunchKernelGGL(pixel_adc_kernel, dim3((unsigned)F.U), dim3(FEE_THREADS), (size_t)((h.n_time_ticks + 1) & ~1) * 8, ctx->stream, F);
+  const size_t full = (size_t)((h.n_time_ticks + 1) & ~1) * 8;
+  const bool skip_idle = !F.noise_z && ((F.thr_table != nullptr) || F.threshold > 0);
+  if (!skip_idle || !F.win || ctx->fee_one_class || h.n_time_ticks <= FEE_SPAN) {
+    // (noise: every tick is walked; a threshold table may hold non-positive entries -- the scan decides per pixel, so the table
+    // case keeps the windows only when the constant path would; complete rows: no windows to go by)
+    hipLaunchKernelGGL(pixel_adc_kernel<FEE_THREADS>, dim3((unsigned)F.U), dim3(FEE_THREADS), full, ctx->stream, F);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int rc;
+  if ((rc = ldsim_ensure(ctx, SB_SPAN, (size_t)F.U * 16 + 64))) return rc;      // span [U][2] | lists [2][U] | counts [2]
+  int32_t* d_span = (int32_t*)ctx->scratch[SB_SPAN].p;
+  int32_t* d_lists = d_span + 2 * F.U;
+  unsigned long long* d_counts = (unsigned long long*)((char*)ctx->scratch[SB_SPAN].p + (((size_t)F.U * 16 + 15) & ~(size_t)15));
+  HIPCHK(hipMemsetAsync(d_counts, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(fee_span_kernel, dim3((unsigned)((F.U + 255) / 256)), dim3(256), 0, ctx->stream, F, d_span, d_lists, d_counts);
+  HIPCHK(hipGetLastError());
+  // both launches over the whole grid: a workgroup past its list's count leaves at once (the counts stay on the device: no
+  // host round trip); the one-wave launch first
+  const unsigned g_small = (unsigned)std::min<int64_t>(F.U, 256 * 24), g_big = (unsigned)std::min<int64_t>(F.U, 256 * 8);
+  hipLaunchKernelGGL(pixel_adc_list_kernel<64>, dim3(g_small), dim3(64), (size_t)FEE_SPAN * 8, ctx->stream, F, d_lists,
+                     d_counts, d_span, FEE_SPAN);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(pixel_adc_list_kernel<FEE_THREADS>, dim3(g_big), dim3(FEE_THREADS), full, ctx->stream, F,
+                     d_lists + F.U, d_counts + 1, (const int32_t*)nullptr, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }

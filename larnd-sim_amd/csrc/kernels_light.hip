@@ -10,11 +10,14 @@
 //      the photons that actually arrive:
 //      * without truth slots (MAX_MC_TRUTH_IDS = 0): sum_light_scatter_kernel -- a workgroup per (detector, tick tile)
 //        keeps the tile in LDS as f64 and its threads deposit the batch's contributions;
-//      * with truth slots: every (segment, detector) emits its contributions as records keyed by
-//        (detector, tick, position of the segment in the detector's descending-photons order, profile bin); one stable
-//        radix sort puts each (detector, tick) cell's records in the order the reference's loop visits them
-//        (light_sim.py:86,99) and one thread per cell replays them: same f4 accumulation order, same first-come
-//        truth slots (light_sim.py:103-110,119-127).
+//      * with truth slots: the (detector, segment) pairs are walked in the reference's visiting order -- detector after detector,
+//        inside one its segments by descending photons (light_sim.py:86, cli/simulate_pixels.py:1141-1144) -- and each emits
+//        its contributions, profile bin after profile bin, as records {32-bit key (detector, tick) | 64-bit payload (segment,
+//        the f4 product of light_sim.py:100)}; a STABLE radix sort over the key's 20-odd bits (three passes) puts each
+//        (detector, tick) cell's records together without disturbing the order they were emitted in, and a wave per block of
+//        records replays them: same f4 accumulation order, same first-come truth slots (light_sim.py:103-110,119-127).
+//        [Rounds 2-3 keyed the records (detector, tick, rank, bin) in 64 bits -- eight passes over 12-byte pairs -- and fetched
+//        photons and segment of a sorted record through its index: 5.2 ms per 2x2 batch of 2.4e7 records.]
 #include "ldsim_dev.h"
 
 __device__ __forceinline__ void get_voxel(const LdsimConsts* c, double x, double y, double z, int itpc, int nx, int ny,
@@ -265,6 +268,22 @@ __device__ __forceinline__ void light_deposits_ph(const LightSum& L, int64_t r, 
     at(track_time + (double)L.t0_avg[lb] * ns / mus, 0, (double)ph / tick);
   }
 }
+// the same deposits with the f4 product `n_photons_det * time_profile[ip]` (or n_photons_det alone without LUT smearing) instead
+// of photons = (double)product / LIGHT_TICK_SIZE: what a record carries in 32 bits
+template <class F>
+__device__ __forceinline__ void light_deposits_f4(const LightSum& L, int64_t r, int idet, F f) {
+  const LdsimConsts* c = L.c;
+  const int opch = L.op_channel[idet];
+  const float ph = L.nph[r * L.n_inc + opch];
+  if (c->enable_lut_smearing) {
+    const int32_t* vx = L.voxel + r * 3;
+    const int64_t lb = ((((int64_t)vx[0] * L.ny + vx[1]) * L.nz + vx[2]) * L.ndet_lut + (opch % L.ndet_lut));
+    const float* prof = L.time_dist + lb * L.nprof;
+    light_deposits_ph(L, r, opch, ph, [&](int64_t it, int ip, double) { f(it, ip, ph * prof[ip]); });
+  } else {
+    light_deposits_ph(L, r, opch, ph, [&](int64_t it, int ip, double) { f(it, ip, ph); });
+  }
+}
 template <class F>
 __device__ __forceinline__ void light_deposits(const LightSum& L, int64_t r, int idet, F f) {
   const int opch = L.op_channel[idet];
@@ -381,18 +400,7 @@ __global__ void __launch_bounds__(256) light_clear_list_kernel(LightAct A, float
 }
 
 // ---- with truth slots: records sorted into the reference's visiting order --------------------------------------------------------
-#define LK_TICK_BITS 16
 #define LK_RANK_BITS 20
-#define LK_IP_BITS 7
-// rank[idet][r] = position of segment r in sorted_indices[idet] (stage call: the caller's order)
-__global__ void light_rank_from_sorted_kernel(const int32_t* __restrict__ sorted_idx, int n_det, int64_t n,
-                                              int32_t* __restrict__ rank) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (int64_t)n_det * n) return;
-  const int64_t idet = p / n, q = p - idet * n;
-  const int32_t r = sorted_idx[p];
-  if (r >= 0 && r < n) rank[idet * n + r] = (int32_t)q;
-}
 // resident path: order of cli/simulate_pixels.py:1141-1144, np.argsort(n_photons_det)[::-1] per detector: descending
 // photons; equal photons (the reference's sort is not stable, their order is unpinned) by descending segment index
 __global__ void light_order_keys_kernel(LightSum L, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
@@ -405,61 +413,51 @@ __global__ void light_order_keys_kernel(LightSum L, unsigned long long* __restri
             (unsigned long long)((~(unsigned int)r) & ((1u << LK_RANK_BITS) - 1));
   vals[p] = (int32_t)r;
 }
-__global__ void light_rank_from_order_kernel(const int32_t* __restrict__ vals, int n_det, int64_t n,
-                                             int32_t* __restrict__ rank) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (int64_t)n_det * n) return;
-  const int64_t idet = p / n;
-  rank[idet * n + vals[p]] = (int32_t)(p - idet * n);
-}
-// one thread per (segment, detector): number of deposits
-__global__ void light_count_kernel(LightSum L, int32_t* __restrict__ count) {
+// ---- round 4: records emitted in visiting order, 32-bit keys, the payload travelling with the key ---------------------------------
+// order[idet][q] = the segment visited q-th for detector idet (the first sort's values, or the caller's sorted_indices); p runs
+// over (idet, q), so the scan of the counts lays the records out detector after detector, segment after segment in visiting order
+__global__ void light_count_ordered_kernel(LightSum L, const int32_t* __restrict__ order, int32_t* __restrict__ count) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= L.n * L.n_det) return;
-  const int64_t r = p / L.n_det;
-  const int idet = (int)(p - r * L.n_det);
+  const int idet = (int)(p / L.n);
+  const int64_t r = order[p];
   int cnt = 0;
-  light_deposits(L, r, idet, [&](int64_t, int, double) { cnt++; });
+  if (r >= 0 && r < L.n) light_deposits(L, r, idet, [&](int64_t, int, double) { cnt++; });
   count[p] = cnt;
 }
-__global__ void light_fill_kernel(LightSum L, const int32_t* __restrict__ offs, const int32_t* __restrict__ rank,
-                                  unsigned long long* __restrict__ keys, int32_t* __restrict__ vals,
-                                  int32_t* __restrict__ rec_seg, double* __restrict__ rec_ph) {
+__global__ void light_fill_ordered_kernel(LightSum L, const int32_t* __restrict__ order, const int32_t* __restrict__ offs, int tick_bits,
+                                          unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= L.n * L.n_det) return;
-  const int64_t r = p / L.n_det;
-  const int idet = (int)(p - r * L.n_det);
+  const int idet = (int)(p / L.n);
+  const int64_t r = order[p];
+  if (r < 0 || r >= L.n) return;
   int64_t w = offs[p];
-  const unsigned long long rk = (unsigned long long)(unsigned int)rank[(int64_t)idet * L.n + r];
-  light_deposits(L, r, idet, [&](int64_t it, int ip, double photons) {
-    keys[w] = ((unsigned long long)idet << (LK_TICK_BITS + LK_RANK_BITS + LK_IP_BITS)) |
-              ((unsigned long long)it << (LK_RANK_BITS + LK_IP_BITS)) | (rk << LK_IP_BITS) | (unsigned long long)ip;
-    vals[w] = (int32_t)w;
-    rec_seg[w] = (int32_t)r;
-    rec_ph[w] = photons;
+  light_deposits_f4(L, r, idet, [&](int64_t it, int, float pp) {
+    keys[w] = ((unsigned)idet << tick_bits) | (unsigned)it;
+    vals[w] = ((unsigned long long)(unsigned)r << 32) | (unsigned long long)(unsigned)__float_as_int(pp);
     w++;
   });
 }
+
 // one thread per (detector, tick) cell that received something: replay its records in order (light_sim.py:101-110,118-127)
-__global__ void light_replay_kernel(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
-                                    const int32_t* __restrict__ rec_seg, const double* __restrict__ rec_ph, int64_t n_rec,
-                                    const int64_t* __restrict__ track_id, int64_t n_ticks, double truth_threshold,
-                                    float* __restrict__ out, int64_t* __restrict__ true_id, double* __restrict__ true_ph,
-                                    int max_truth) {
+__global__ void light_replay_kernel(const unsigned* __restrict__ keys, const unsigned long long* __restrict__ vals, int64_t n_rec,
+                                    int tick_bits, double tick_size, const int64_t* __restrict__ track_id, int64_t n_ticks,
+                                    double truth_threshold, float* __restrict__ out, int64_t* __restrict__ true_id,
+                                    double* __restrict__ true_ph, int max_truth) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
-  const int SH = LK_RANK_BITS + LK_IP_BITS;
-  const unsigned long long cell = keys[i] >> SH;
-  if (i > 0 && (keys[i - 1] >> SH) == cell) return;
-  const int64_t idet = (int64_t)(cell >> LK_TICK_BITS), it = (int64_t)(cell & ((1u << LK_TICK_BITS) - 1));
+  const unsigned cell = keys[i];
+  if (i > 0 && keys[i - 1] == cell) return;
+  const int64_t idet = (int64_t)(cell >> tick_bits), it = (int64_t)(cell & ((1u << tick_bits) - 1));
   const int64_t o = idet * n_ticks + it;
   float acc = out[o];
-  for (int64_t j = i; j < n_rec && (keys[j] >> SH) == cell; j++) {
-    const int32_t w = vals[j];
-    const double photons = rec_ph[w];
+  for (int64_t j = i; j < n_rec && keys[j] == cell; j++) {
+    const unsigned long long v = vals[j];
+    const double photons = (double)__int_as_float((int)(unsigned)v) / tick_size;
     acc = (float)((double)acc + photons);
     if (photons > truth_threshold) {
-      const int64_t id = track_id[rec_seg[w]];
+      const int64_t id = track_id[(int64_t)(v >> 32)];
       for (int k = 0; k < max_truth; k++) {
         int64_t* tid = &true_id[o * max_truth + k];
         if (*tid == -1 || *tid == id) {
@@ -477,7 +475,7 @@ __global__ void light_replay_kernel(const unsigned long long* __restrict__ keys,
 // The cells the last truth-slot photon sum wrote (the heads of its sorted records, still in light_tmp[4]) back to their initial
 // values: the next sum on the same buffers starts from arrays that are clean everywhere else (ldsim_dev_sum_light) -- at 50 truth
 // slots and 50 000 ticks clearing 15 GB per batch was half the photon sum's time, the cells written are 3 % of them.
-__global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned long long* __restrict__ keys, int64_t n_rec,
+__global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned* __restrict__ keys, int64_t n_rec, int tick_bits,
                                                                int64_t n_ticks, int max_truth, float* __restrict__ out,
                                                                int64_t* __restrict__ true_id, double* __restrict__ true_ph) {
   // a workgroup per 256 records: the heads among them (first record of a cell) are collected, then each wave clears whole cells,
@@ -486,14 +484,13 @@ __global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned l
   __shared__ int s_n;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  const int SH = LK_RANK_BITS + LK_IP_BITS;
   if (tid == 0) s_n = 0;
   __syncthreads();
   unsigned cell = 0;
   bool head = false;
   if (i < n_rec) {
-    cell = (unsigned)(keys[i] >> SH);
-    head = i == 0 || (unsigned)(keys[i - 1] >> SH) != cell;
+    cell = keys[i];
+    head = i == 0 || keys[i - 1] != cell;
   }
   const unsigned long long m = __ballot(head);
   int base = 0;
@@ -504,7 +501,7 @@ __global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned l
   const int nh = s_n;
   for (int h = wv; h < nh; h += 4) {
     const unsigned c = s_cell[h];
-    const int64_t o = (int64_t)(c >> LK_TICK_BITS) * n_ticks + (int64_t)(c & ((1u << LK_TICK_BITS) - 1));
+    const int64_t o = (int64_t)(c >> tick_bits) * n_ticks + (int64_t)(c & ((1u << tick_bits) - 1));
     if (lane == 0) out[o] = 0.f;
     for (int k = lane; k < max_truth; k += 64) {
       true_id[o * max_truth + k] = -1;
@@ -514,21 +511,20 @@ __global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned l
 }
 
 // The same replay with a wave per block of RW_BLOCK sorted records (max_truth <= 64): the wave owns the (detector, tick) cells
-// whose first record lies in its block and walks each to its end.  The records are fetched 64 at a time, one per lane (key,
-// photons and track id: three dependent loads, but 64 in flight), and replayed in order from registers; lane k keeps truth
+// whose first record lies in its block and walks each to its end.  The records are fetched 64 at a time, one per lane (key and
+// payload side by side, then the track id of the payload's segment), and replayed in order from registers; lane k keeps truth
 // slot k of the cell, so "the first slot that is empty or holds this id" (light_sim.py:120-126) is one ballot and the row is
 // read and written once, coalesced.  One thread per cell walked its run alone with a global-memory slot search per record:
 // a busy tick of a busy detector (thousands of records) set the kernel's time.
 #define RW_BLOCK 256
-__global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned long long* __restrict__ keys,
-                                                               const int32_t* __restrict__ vals, const int32_t* __restrict__ rec_seg,
-                                                               const double* __restrict__ rec_ph, int64_t n_rec,
+__global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned* __restrict__ keys,
+                                                               const unsigned long long* __restrict__ vals, int64_t n_rec,
+                                                               int tick_bits, double tick_size,
                                                                const int64_t* __restrict__ track_id, int64_t n_ticks,
                                                                double truth_threshold, float* __restrict__ out,
                                                                int64_t* __restrict__ true_id, double* __restrict__ true_ph,
                                                                int max_truth) {
   const int lane = threadIdx.x;
-  const int SH = LK_RANK_BITS + LK_IP_BITS;
   const int64_t b0 = (int64_t)blockIdx.x * RW_BLOCK, b1 = min(b0 + RW_BLOCK, n_rec);
   auto rl64 = [](unsigned long long v, int l) {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
@@ -546,7 +542,7 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
       true_ph[o * max_truth + lane] = slot_ph;
     }
   };
-  unsigned prev_cell = b0 > 0 ? (unsigned)(keys[b0 - 1] >> SH) : 0xFFFFFFFFu;       // (cells use 28 bits)
+  unsigned prev_cell = b0 > 0 ? keys[b0 - 1] : 0xFFFFFFFFu;       // (cells use at most 28 bits)
   for (int64_t c0 = b0; c0 < n_rec; c0 += 64) {
     if (c0 >= b1 && !open) break;                 // past the block and nothing left to finish
     const int64_t j = c0 + lane;
@@ -554,10 +550,10 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
     double ph = 0.0;
     int64_t id = -1;
     if (j < n_rec) {
-      cell = (unsigned)(keys[j] >> SH);
-      const int32_t w = vals[j];
-      ph = rec_ph[w];
-      id = track_id[rec_seg[w]];
+      cell = keys[j];
+      const unsigned long long v = vals[j];
+      ph = (double)__int_as_float((int)(unsigned)v) / tick_size;        // photons of light_sim.py:100
+      id = track_id[(int64_t)(v >> 32)];
     }
     const int nv = (int)min((int64_t)64, n_rec - c0);
     bool done = false;
@@ -569,7 +565,7 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned lo
         if (open) { close_cell(); open = false; }
         if (c0 + t >= b1) { done = true; break; }          // the next block's cell
         open = true;
-        o = (int64_t)(ct >> LK_TICK_BITS) * n_ticks + (int64_t)(ct & ((1u << LK_TICK_BITS) - 1));
+        o = (int64_t)(ct >> tick_bits) * n_ticks + (int64_t)(ct & ((1u << tick_bits) - 1));
         acc = out[o];
         slot_id = lane < max_truth ? true_id[o * max_truth + lane] : -2;
         slot_ph = lane < max_truth ? true_ph[o * max_truth + lane] : 0.0;
@@ -596,7 +592,7 @@ int light_launch_reset_cells(ldsim_ctx* ctx, int64_t n_rec, int64_t n_ticks, int
                               double* true_ph) {
   if (n_rec <= 0) return 0;
   hipLaunchKernelGGL(light_reset_cells_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const unsigned long long*)ctx->light_tmp[4].p, n_rec, n_ticks, max_truth, out, true_id, true_ph);
+                     (const unsigned*)ctx->light_tmp[4].p, n_rec, ctx->light_lazy_tick_bits, n_ticks, max_truth, out, true_id, true_ph);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -608,6 +604,8 @@ int light_launch_clear_list(ldsim_ctx* ctx, const LightAct* act, float* out) {
 }
 
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
+int sort_pairs_bits(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t, int, int);
+int sort_pairs_u32_u64(ldsim_ctx*, unsigned*, unsigned*, unsigned long long*, unsigned long long*, int64_t, int);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 static inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
@@ -678,40 +676,37 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if (n_det > (1 << 12) || n_ticks > (1 << LK_TICK_BITS) || n > (1 << LK_RANK_BITS) || ctx->lut_nprof > (1 << LK_IP_BITS) ||
-      (int64_t)n_det * n >= 0x7fffffffLL) {
-    ldsim_set_error("photon sum with truth slots: at most 4096 detectors, 65536 ticks, 2^20 segments per call and a "
-                    "128-bin time profile (got %d, %lld, %lld, %d)", n_det, (long long)n_ticks, (long long)n, ctx->lut_nprof);
+  auto bits_for = [](int64_t v) { int b = 1; while ((1ll << b) < v) b++; return b; };
+  const int tick_bits = bits_for(n_ticks), det_bits = bits_for(n_det);
+  if (tick_bits + det_bits > 32 || n > (1 << LK_RANK_BITS) || (int64_t)n_det * n >= 0x7fffffffLL) {
+    ldsim_set_error("photon sum with truth slots: (detector, tick) must fit 32 bits and a call 2^20 segments (got %d detectors, "
+                    "%lld ticks, %lld segments)", n_det, (long long)n_ticks, (long long)n);
     return LDSIM_EINVAL;
   }
   const int64_t np = (int64_t)n_det * n;
   DevBuf* T = ctx->light_tmp;
   int rc;
-  if ((rc = ldsim_ensure_buf(ctx, &T[0], (size_t)np * 4))) return rc;          // rank
   if ((rc = ldsim_ensure_buf(ctx, &T[1], (size_t)np * 4 + 16))) return rc;     // count, then offsets in T[2]
   if ((rc = ldsim_ensure_buf(ctx, &T[2], (size_t)np * 4 + 16))) return rc;
-  int32_t* d_rank = (int32_t*)T[0].p;
   int32_t* d_count = (int32_t*)T[1].p;
   int32_t* d_offs = (int32_t*)T[2].p;
-  if (sorted_idx) {
-    HIPCHK(hipMemsetAsync(d_rank, 0, (size_t)np * 4, st));
-    hipLaunchKernelGGL(light_rank_from_sorted_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, sorted_idx, n_det, n, d_rank);
-  } else {
+  const int32_t* d_order = sorted_idx;            // [n_det][n]: the segment visited q-th for detector idet
+  if (!sorted_idx) {
+    // descending photons per detector (cli/simulate_pixels.py:1141-1144): one sort of the (detector, segment) pairs over the key bits
+    // that are used -- detector | inverted photon bits | inverted segment index
     if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)np * 8))) return rc;
-    if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)np * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[0], (size_t)np * 8))) return rc;
     if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)np * 4))) return rc;
     if ((rc = ldsim_ensure_buf(ctx, &T[6], (size_t)np * 4))) return rc;
     hipLaunchKernelGGL(light_order_keys_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, (unsigned long long*)T[3].p,
                        (int32_t*)T[5].p);
     HIPCHK(hipGetLastError());
-    if ((rc = sort_pairs(ctx, (unsigned long long*)T[3].p, (unsigned long long*)T[4].p, (int32_t*)T[5].p, (int32_t*)T[6].p,
-                         np)))
+    if ((rc = sort_pairs_bits(ctx, (unsigned long long*)T[3].p, (unsigned long long*)T[0].p, (int32_t*)T[5].p, (int32_t*)T[6].p, np, 0,
+                              52 + det_bits)))
       return rc;
-    hipLaunchKernelGGL(light_rank_from_order_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, (const int32_t*)T[6].p, n_det,
-                       n, d_rank);
+    d_order = (const int32_t*)T[6].p;
   }
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(light_count_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_count);
+  hipLaunchKernelGGL(light_count_ordered_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_order, d_count);
   HIPCHK(hipGetLastError());
   if ((rc = sort_exclusive_scan_i32(ctx, d_count, d_offs, np))) return rc;
   int32_t last_off = 0, last_cnt = 0;
@@ -721,23 +716,23 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   const int64_t n_rec = (int64_t)last_off + last_cnt;
   if (n_rec == 0) return 0;
   if (n_rec_out) *n_rec_out = n_rec;
-  if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)n_rec * 8))) return rc;
-  if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)n_rec * 8))) return rc;
-  if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)n_rec * 4))) return rc;
-  if ((rc = ldsim_ensure_buf(ctx, &T[6], (size_t)n_rec * 4))) return rc;
-  if ((rc = ldsim_ensure_buf(ctx, &T[7], (size_t)n_rec * 4))) return rc;
+  // records: T[3] keys in, T[4] keys sorted (kept for the next sum's lazy reset), T[7] / T[8] payloads in / sorted
+  if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)n_rec * 4))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)n_rec * 4))) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &T[7], (size_t)n_rec * 8))) return rc;
   if ((rc = ldsim_ensure_buf(ctx, &T[8], (size_t)n_rec * 8))) return rc;
-  unsigned long long *k0 = (unsigned long long*)T[3].p, *k1 = (unsigned long long*)T[4].p;
-  int32_t *v0 = (int32_t*)T[5].p, *v1 = (int32_t*)T[6].p, *rseg = (int32_t*)T[7].p;
-  double* rph = (double*)T[8].p;
-  hipLaunchKernelGGL(light_fill_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_offs, d_rank, k0, v0, rseg, rph);
+  unsigned *k0 = (unsigned*)T[3].p, *k1 = (unsigned*)T[4].p;
+  unsigned long long *v0 = (unsigned long long*)T[7].p, *v1 = (unsigned long long*)T[8].p;
+  hipLaunchKernelGGL(light_fill_ordered_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, d_order, d_offs, tick_bits, k0, v0);
   HIPCHK(hipGetLastError());
-  if ((rc = sort_pairs(ctx, k0, k1, v0, v1, n_rec))) return rc;
+  if ((rc = sort_pairs_u32_u64(ctx, k0, k1, v0, v1, n_rec, tick_bits + det_bits))) return rc;
+  ctx->light_lazy_tick_bits = tick_bits;
+  const double tick_size = ctx->h_consts.light_tick_size;
   if (max_truth <= 64)
-    hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_rec, RW_BLOCK)), dim3(64), 0, st, k1, v1, rseg, rph, n_rec, track_id,
-                       n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
+    hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_rec, RW_BLOCK)), dim3(64), 0, st, k1, v1, n_rec, tick_bits, tick_size,
+                       track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
   else
-    hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, rseg, rph, n_rec, track_id,
+    hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, n_rec, tick_bits, tick_size, track_id,
                        n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
   HIPCHK(hipGetLastError());
   return 0;

@@ -301,6 +301,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "debug_lds_pad_kb")) ctx->debug_lds_pad_kb = value >= -40 && value <= 16 ? (int)value : 0;
   else if (!strcmp(name, "debug_gform")) ctx->debug_gform = (int)value;
   else if (!strcmp(name, "gform_wave_tables")) ctx->gform_wave_tables = value != 0;
+  else if (!strcmp(name, "fee_one_class")) ctx->fee_one_class = value != 0;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }
   else if (!strcmp(name, "split_max_items")) ctx->split_max_items = (int)value;

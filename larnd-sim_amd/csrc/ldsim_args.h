@@ -53,8 +53,23 @@ struct CurArgs {
   const unsigned long long* flag_count;   //   that only finds its flag unset)
 };
 
+// The constants the FEE kernels use, by value (kernel arguments live in scalar registers): read through the pointer to the
+// constants block in HBM every field costs a trip to L2, taken one after the other where the code first needs them -- a dozen
+// dependent round trips per pixel in a kernel that is nothing but such chains.
+struct FeeK {
+  int32_t n_time_ticks, max_adc_values, max_tracks_per_pixel, pad;
+  double time_sampling, buffer_risetime, clock_cycle, adc_hold_delay, reset_cycles, adc_busy_delay;
+  double reset_noise_charge, uncorrelated_noise_charge, discriminator_noise;
+  double v_pedestal, v_cm, v_ref, adc_counts, gain, time_interval1;
+};
+#define FEEK_FROM(h) FeeK{(h).n_time_ticks, (h).max_adc_values, (h).max_tracks_per_pixel, 0, (h).time_sampling, (h).buffer_risetime, \
+                          (h).clock_cycle, (double)(h).adc_hold_delay, (double)(h).reset_cycles, (double)(h).adc_busy_delay,         \
+                          (h).reset_noise_charge, (h).uncorrelated_noise_charge, (h).discriminator_noise, (h).v_pedestal, (h).v_cm, \
+                          (h).v_ref, (double)(h).adc_counts, (h).gain, (h).time_interval[1]}
+
 struct FeeArgs {
   const LdsimConsts* c;
+  FeeK k;
   // unique pixels
   int64_t U;
   const int32_t* upix;

@@ -150,6 +150,7 @@ struct ldsim_ctx {
   int debug_lds_b1_kb = 0;                   // timing tools: LDS budget of gcorr_kernel's second class in KB (0 = 32)
   int debug_lds_pad_kb = 0;                  // timing tools: KB taken off the LDS budget of gcorr_kernel's small class
   long long frac_clean_gen = -1;             // out_gen of the output set whose dense fractions array has been completed with zeros
+  int fee_one_class = 0;                     // option: 1 = pixel_adc_kernel with 256 threads and the whole tick axis for every pixel (A/B checks)
   int gform_wave_tables = 1;                 // 1: gtables_wave_kernel (a wave per pair) for the pairs that fit it, 0: gtables_kernel for all
   int debug_gform = 0;                       // timing tools: parts of gtables_kernel / gcorr_kernel switched off (tools/gform_phases.py)
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel
@@ -181,7 +182,7 @@ struct ldsim_ctx {
   DevBuf light_tmp[9];
   // lazy clear of the resident photon-sum arrays (ldsim_dev_sum_light): valid = the arrays are clean over `light_clean_cells`
   // (detector, tick) cells except where the records still sorted in light_tmp[4] fell
-  int light_lazy_valid = 0, light_lazy_mt = 0;
+  int light_lazy_valid = 0, light_lazy_mt = 0, light_lazy_tick_bits = 16;
   long long light_lazy_nrec = 0, light_lazy_nticks = 0;
   size_t light_clean_cells = 0, light_lazy_cap[3] = {0, 0, 0};
   void *light_lazy_out = nullptr, *light_lazy_tid = nullptr, *light_lazy_tph = nullptr;
@@ -235,7 +236,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN, SB_SPAN
 };
 
 void ldsim_set_error(const char* fmt, ...);

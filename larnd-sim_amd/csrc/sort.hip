@@ -155,6 +155,34 @@ int sort_pairs(ldsim_ctx* ctx, unsigned long long* keys_in, unsigned long long* 
   return 0;
 }
 
+// the same over the key bits [begin_bit, end_bit) only (a pass per 8 bits)
+int sort_pairs_bits(ldsim_ctx* ctx, unsigned long long* keys_in, unsigned long long* keys_out, int32_t* vals_in, int32_t* vals_out,
+                    int64_t n, int begin_bit, int end_bit) {
+  if (n == 0) return 0;
+  if (end_bit > 64) end_bit = 64;
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, begin_bit, end_bit, ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, tmp);
+  if (rc) return rc;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->scratch[SB_SORTTMP].p, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, begin_bit,
+                                   end_bit, ctx->stream));
+  return 0;
+}
+
+// stable sort of 32-bit keys (their low `bits` bits) with 64-bit payloads: the photon-sum records (kernels_light.hip)
+int sort_pairs_u32_u64(ldsim_ctx* ctx, unsigned* keys_in, unsigned* keys_out, unsigned long long* vals_in, unsigned long long* vals_out,
+                       int64_t n, int bits) {
+  if (n == 0) return 0;
+  if (bits > 32) bits = 32;
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, tmp);
+  if (rc) return rc;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->scratch[SB_SORTTMP].p, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits,
+                                   ctx->stream));
+  return 0;
+}
+
 int sort_exclusive_scan_i32(ldsim_ctx* ctx, const int32_t* in, int32_t* out, int64_t n) {
   if (n == 0) return 0;
   size_t tmp = 0;
