@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 6
+#define LDSIM_ABI_VERSION 7
 
 /* error codes */
 #define LDSIM_OK 0
@@ -454,6 +454,55 @@ int ldsim_hits_accumulate(ldsim_ctx* ctx, int32_t reset);
  * counts[world] (may be NULL) = rows per rank */
 int ldsim_comm_allgather_hits(ldsim_ctx* ctx, void** gathered, int64_t* total_rows, int64_t* counts);
 int ldsim_comm_gathered_download(ldsim_ctx* ctx, void* rows, int64_t n);
+
+/* ---- fee.export_to_hdf5's hit loop on compact rows (larndsim/fee.py:143-344) -- host code, no ctx, no GPU ---------------------------
+ * The LArPix `packets` rows (larpix-control's HDF5 format 2.4: 36-byte packed rows, ldsim_packets_row_bytes) and the
+ * `mc_packets_assn` rows (event_ids (1,) i8 | segment_ids (n,) i8 | fraction (n,) f8 | file_traj_ids (n,) i8 | fraction_traj (n,) f8,
+ * n = ASSOCIATION_COUNT_TO_STORE: ldsim_packets_assn_row_bytes) of one export, from the rows the reference's loop would enter --
+ * the pixels whose first ADC lies above the pedestal code, in export order (batch after batch, pixel after pixel) -- with what is
+ * per row precomputed by the caller (larndsim_amd/packets.py: pixel -> io_group / io_channel / chip / channel through tile map,
+ * tile orientation and pixel layout, fee.py:150-157,238-255; event start times).  Per hit: clock rollover (:164-183), the packets
+ * of a new event (timestamp + sync per io group, the event's light triggers, :187-230), the timestamp packet of a changed tick
+ * (:267-277), the data packet with its parity, and the association row (:284-344; equal fractions keep descending slot order --
+ * numpy's argsort leaves their order to its build).  Returns the number of rows written, or a negative status. */
+typedef struct {
+  int64_t n_rows;               /* rows entering the hit loop */
+  const int64_t* row_event;     /* [n_rows] event id */
+  const int64_t* row_base;      /* [n_rows] int(event_start_time / CLOCK_CYCLE) */
+  const int64_t* row_ts_s;      /* [n_rows] int(event_start_time * mus / s): value of the per-event timestamp packets */
+  const uint8_t* row_ok;        /* [n_rows] the pixel has a readout address and its channel is not disabled */
+  const int32_t* row_io_group;  /* [n_rows] */
+  const int32_t* row_io_channel;
+  const int32_t* row_chip;
+  const int32_t* row_channel;
+  const int64_t* row_hit0;      /* [n_rows + 1] offsets into hit_*: the row's slots up to the first ADC <= pedestal */
+  const int64_t* row_trk0;      /* [n_rows + 1] offsets into trk_*: the row's filled track slots */
+  const int64_t* row_frac0;     /* [n_rows] offset into hit_frac of the row's first hit: [slot][track slot] from there */
+  const int32_t* hit_adc;       /* ADC code */
+  const double* hit_tick;       /* adc_ticks_list value */
+  const double* hit_frac;       /* backtracking fractions */
+  const int64_t* trk_segment;   /* segment id of a track slot (track_ids) */
+  const int64_t* trk_traj;      /* trajectory id of a track slot (traj_ids) */
+  int64_t base0;                /* int(event_start_time / CLOCK_CYCLE) of row 0 of the export's arrays (a row without hits included) */
+  int32_t first_row_is_row0;    /* rows[0] is that row 0 */
+  int32_t light_trig_mode;      /* light.LIGHT_TRIG_MODE */
+  int64_t n_trig;               /* light triggers of the export (fee.py:209-221) */
+  const double* trig_time;
+  const int64_t* trig_event;
+  const int64_t* trig_module;
+  int32_t n_io_groups;          /* io groups that get the per-event timestamp / sync packets */
+  const int32_t* io_groups;
+  int32_t n_modules;            /* MODULE_TO_IO_GROUPS: module ids, and per module its groups module_groups[module_group0[m] .. [m + 1]) */
+  const int64_t* module_ids;
+  const int32_t* module_group0;
+  const int32_t* module_groups;
+  int64_t clock_reset_period;   /* detector.CLOCK_RESET_PERIOD */
+  double clock_cycle, mus, s;   /* detector.CLOCK_CYCLE, units.mus, units.s */
+  int32_t n_keep, max_tracks;   /* sim.ASSOCIATION_COUNT_TO_STORE, sim.MAX_TRACKS_PER_PIXEL */
+} LdsimPacketsIn;
+int32_t ldsim_packets_row_bytes(void);
+int32_t ldsim_packets_assn_row_bytes(int32_t n_keep);
+int64_t ldsim_packets_build(const LdsimPacketsIn* in, void* packets_out, void* assn_out, int64_t capacity);
 
 /* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
 int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);

@@ -561,9 +561,39 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
     write_batch = max(int(getattr(sim, "WRITE_BATCH_SIZE", 1)), 1)
     pending = []            # (event, arrays of the batch, its light triggers or None)
 
+    event_of_batch = np.array([t[0] for t in table], dtype=np.int64)
+    first_seg_of_batch = np.searchsorted(bid[:nsim], np.arange(len(table)), side="left").astype(np.int64)
+
+    def export_triggers(events_in_order):
+        """light triggers embedded in the charge stream of an export (:206-222)"""
+        uniq = np.unique(np.asarray(events_in_order))
+        ev_time = np.array([event_times[int(e) % sim.MAX_EVENTS_PER_FILE] for e in uniq])
+        if all(p[2] is None for p in pending):
+            # each event triggers once at perfect t0 (:218-222)
+            return ev_time, (np.zeros(len(uniq)), uniq, np.ones(len(uniq)))
+        # the simulated triggers of the export's batches (:209-216); a batch without any keeps the perfect one
+        trip = [p[2] if p[2] is not None else (np.zeros(1), np.array([p[0]]), np.ones(1)) for p in pending]
+        return ev_time, tuple(np.concatenate([np.atleast_1d(t[k]) for t in trip]) for k in range(3))
+
+    def flush_pending_compact():
+        """the same export from the compact rows of the chain, through the native hit loop (ldsim_packets_build): no dense
+        [pixel][30][50] fraction rows are rebuilt to feed an array-shaped exporter"""
+        pieces = [packets.compact_to_rows(p[1][1], event_of_batch, first_seg_of_batch, seg_ids_all, trj_ids_all, rows=p[1][2:4])
+                  for p in pending]
+        rows = pieces[0] if len(pieces) == 1 else {k: np.concatenate([q[k] for q in pieces]) for k in pieces[0]}
+        ev_time, (lt_times, lt_events, lt_mods) = export_triggers([p[0] for p in pending])
+        pk, assn = packets.build_packets_compact(**rows, event_start_times=ev_time, light_trigger_times=lt_times,
+                                                 light_trigger_event_id=lt_events, light_trigger_modules=lt_mods,
+                                                 bad_channels=bad_list, i_mod=i_mod)
+        out.append_packets(pk, assn)
+        res["n_packets"] += len(pk)
+        pending.clear()
+
     def flush_pending():
         if not pending:
             return
+        if isinstance(pending[0][1][0], str):           # ("compact", download, first row, row after the last)
+            return flush_pending_compact()
         events = [p[0] for p in pending]
         cat = [np.concatenate([p[1][k] for p in pending]) if len(pending) > 1 else pending[0][1][k] for k in range(7) if k != 4]
         # (the fraction rows, 12 KB per pixel: batches that follow each other in one launch's array are one slice of it)
@@ -586,6 +616,22 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         out.append_packets(pk, assn)
         res["n_packets"] += len(pk)
         pending.clear()
+
+    def export_chunk_compact(c):
+        """packets and association rows of one chain launch from its compact download: a batch is a run of hit-pixel rows (its
+        first unique pixel always among them, hits or not: kernels_compact.hip)"""
+        hp = c["hit_pixels"]
+        rb = hp[:, 2]
+        starts = np.flatnonzero(np.r_[True, rb[1:] != rb[:-1]]) if len(rb) else np.zeros(0, dtype=np.int64)
+        ends = np.r_[starts[1:], len(rb)]
+        for a, b in zip(starts, ends):
+            bb = int(rb[a])
+            event = table[bb][0]
+            announce_until(event)
+            pending.append((event, ("compact", c, int(a), int(b)), light_trig_of.get((int(event), int(table[bb][1]))), None))
+            if len(pending) >= write_batch:
+                flush_pending()
+        res["n_hits"] += len(c["hit_rows"])
 
     def export_chunk(r):
         """packets and association rows of one chain launch (`r`: the launch's per-pixel arrays)"""
@@ -638,7 +684,7 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
             continue
         chain.run(int(b), int(e), want_fractions=True)
         if not raw_arrays:
-            export_chunk(expand_compact(chain.download_compact(), lead_rows=True))
+            export_chunk_compact(chain.download_compact())
             b = e
             continue
         if not overlapped:

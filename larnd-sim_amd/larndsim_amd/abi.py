@@ -56,7 +56,7 @@ class LdsimChainStats(C.Structure):
                 ("n_dfma_useful", C.c_int64)]
 
 
-ABI_VERSION = 6      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
+ABI_VERSION = 7      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):
@@ -105,3 +105,16 @@ def pack_consts(noise_zero=False):
     c.light_det_noise_sample_spacing = float(l.LIGHT_DET_NOISE_SAMPLE_SPACING)
     c.light_nbit, c.op_channel_per_trig = int(l.LIGHT_NBIT), int(l.OP_CHANNEL_PER_TRIG)
     return c
+
+
+class LdsimPacketsIn(C.Structure):
+    """include/ldsim.h LdsimPacketsIn (ldsim_packets_build)"""
+    _fields_ = [("n_rows", C.c_int64), ("row_event", C.c_void_p), ("row_base", C.c_void_p), ("row_ts_s", C.c_void_p),
+                ("row_ok", C.c_void_p), ("row_io_group", C.c_void_p), ("row_io_channel", C.c_void_p), ("row_chip", C.c_void_p),
+                ("row_channel", C.c_void_p), ("row_hit0", C.c_void_p), ("row_trk0", C.c_void_p), ("row_frac0", C.c_void_p),
+                ("hit_adc", C.c_void_p), ("hit_tick", C.c_void_p), ("hit_frac", C.c_void_p), ("trk_segment", C.c_void_p),
+                ("trk_traj", C.c_void_p), ("base0", C.c_int64), ("first_row_is_row0", C.c_int32), ("light_trig_mode", C.c_int32),
+                ("n_trig", C.c_int64), ("trig_time", C.c_void_p), ("trig_event", C.c_void_p), ("trig_module", C.c_void_p),
+                ("n_io_groups", C.c_int32), ("io_groups", C.c_void_p), ("n_modules", C.c_int32), ("module_ids", C.c_void_p),
+                ("module_group0", C.c_void_p), ("module_groups", C.c_void_p), ("clock_reset_period", C.c_int64),
+                ("clock_cycle", C.c_double), ("mus", C.c_double), ("s", C.c_double), ("n_keep", C.c_int32), ("max_tracks", C.c_int32)]

@@ -42,6 +42,7 @@ EXPORTS = [
     "ldsim_dev_light_response", "ldsim_dev_light_response_download", "ldsim_light_response_ms",
     "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_count", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
     "ldsim_comm_allgather_hits", "ldsim_comm_gathered_download",
+    "ldsim_packets_build", "ldsim_packets_row_bytes", "ldsim_packets_assn_row_bytes",
 ]
 
 
@@ -54,6 +55,7 @@ def load():
                              "(make -C larnd-sim_amd/csrc). There is no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
         _lib.ldsim_last_error.restype = C.c_char_p
+        _lib.ldsim_packets_build.restype = C.c_int64
         for name in EXPORTS:
             getattr(_lib, name)   # fail loudly on a missing symbol
         if int(_lib.ldsim_abi_version()) != ABI_VERSION:

@@ -299,7 +299,10 @@ def build_packets(event_id_list, adc_list, adc_ticks_list, unique_pix, current_f
     if n_data == 0:
         return packets, ds
     F = current_fractions[hit_row[ph], hit_slot[ph]].astype(np.float64, copy=False)
-    frac_order = np.flip(np.argsort(F, axis=1), axis=1)          # on the same rows the reference sorts: ties fall the same way
+    # (stable: equal fractions -- the exact zeros of track slots whose current missed the hit, beside the unused slots' zeros --
+    # keep descending slot order like the native hit loop, csrc/packets.hip; the reference's default argsort leaves their order to
+    # numpy's build)
+    frac_order = np.flip(np.argsort(F, axis=1, kind="stable"), axis=1)
     head = frac_order[:, :n_keep]
     w = head.shape[1]
     hr = hit_row[ph][:, None]
@@ -341,6 +344,185 @@ def build_packets(event_id_list, adc_list, adc_ticks_list, unique_pix, current_f
     ds['fraction_traj'][pos] = out_tfr
     ds['event_ids'][pos, 0] = event[ph]
     return packets, ds
+
+
+def _row_addresses(pid, L, bad_channels):
+    """pixel id -> (ok, io_group, io_channel, chip, channel, module id) as the hit loop finds them (fee.py:150-157,238-255):
+    the same expressions as build_packets, on any array of pixel ids."""
+    d = consts.detector
+    nx, ny = int(d.N_PIXELS[0]), int(d.N_PIXELS[1])
+    pix_x, pix_y, plane_id = pid % nx, (pid // nx) % ny, pid // (nx * ny)
+    module_id = plane_id // 2 + 1
+    ntx, nty = L["chip"].shape
+    tile_x, tile_y = pix_x // ntx, pix_y // nty
+    anode = plane_id % 2
+    tm = L["tile_map"]
+    in_map = (anode < tm.shape[0]) & (tile_x < tm.shape[1]) & (tile_y < tm.shape[2])
+    if not in_map.all():
+        raise IndexError("pixel outside the tile map")
+    tile_id = tm[anode, tile_x, tile_y]
+    px, py = pix_x % ntx, pix_y % nty
+    px = np.where(L["flip_x"][tile_id], ntx - px - 1, px)
+    py = np.where(L["flip_y"][tile_id], nty - py - 1, py)
+    chip, channel = L["chip"][px, py], L["chan"][px, py]
+    ok = (chip >= 0) & L["has_orient"][tile_id]
+    io = np.where(ok & (chip < L["io"].shape[1]), L["io"][np.minimum(tile_id, L["io"].shape[0] - 1),
+                                                        np.clip(chip, 0, L["io"].shape[1] - 1)], -1)
+    ok &= io >= 0
+    io_group_idx, io_channel = io // 1000, io % 1000
+    io_group = np.zeros(len(pid), dtype=np.int64)
+    for m, g in d.MODULE_TO_IO_GROUPS.items():
+        sel = ok & (module_id == int(m))
+        if sel.any():
+            io_group[sel] = np.asarray(list(g), dtype=np.int64)[io_group_idx[sel] - 1]
+    if bad_channels:
+        bad = set()
+        for chip_key, chans in bad_channels.items():
+            for ch in chans:
+                bad.add("%s:%i" % (chip_key, int(ch)))
+        if bad:
+            for i in np.flatnonzero(ok):
+                if "%i-%i-%i:%i" % (io_group[i], io_channel[i], chip[i], channel[i]) in bad:
+                    ok[i] = False
+    return ok, io_group, io_channel, chip, channel, module_id
+
+
+def build_packets_compact(row_event, row_pixel, row_nh, row_nt, hit_adc, hit_tick, hit_frac, trk_segment, trk_traj,
+                          event_start_times, light_trigger_times=None, light_trigger_event_id=None, light_trigger_modules=None,
+                          bad_channels=None, i_mod=-1):
+    """``build_packets`` on the compact rows of the chain (``ChargeChain.download_compact``) through the native hit loop
+    (``ldsim_packets_build``, csrc/packets.hip) -- no dense [pixel][30][50] fraction array is ever formed.
+
+    Rows in export order: ``row_event`` (event id), ``row_pixel`` (pixel id), ``row_nh`` hits, ``row_nt`` filled track slots per
+    row -- row 0 of the export included even when it holds no hit (the exporter's clock state starts from it).  Hits pixel after
+    pixel, slot 0 up: ``hit_adc`` (ADC code), ``hit_tick`` (adc_ticks_list), ``hit_frac`` (per hit one fraction per track slot of
+    its row).  Track slots pixel after pixel: ``trk_segment`` / ``trk_traj`` (the exporter's track_ids / traj_ids values).
+    ``event_start_times``: one per unique event id of the rows, ascending, like build_packets.  Same bytes as build_packets on the
+    dense form of the same rows (tests/test_cpu_host.py; equal fractions of real track slots fall in descending slot order)."""
+    import ctypes as C
+    from . import lib
+    from .abi import LdsimPacketsIn
+    d, light, sim, units = consts.detector, consts.light, consts.sim, consts.units
+    if not d.PIXEL_CONNECTION_DICT:
+        raise RuntimeError("the pixel layout (chip / channel map) is not loaded: packets need consts.load_properties(...) on "
+                           "the detector / pixel-layout YAML files or a snapshot that carries the readout map")
+    L = _readout_luts()
+    row_event = np.ascontiguousarray(row_event, dtype=np.int64)
+    row_pixel = np.asarray(row_pixel, dtype=np.int64)
+    row_nh = np.asarray(row_nh, dtype=np.int64)
+    row_nt = np.asarray(row_nt, dtype=np.int64)
+    hit_adc = np.ascontiguousarray(hit_adc, dtype=np.int32)
+    hit_tick = np.ascontiguousarray(hit_tick, dtype=np.float64)
+    hit_frac = np.ascontiguousarray(hit_frac, dtype=np.float64)
+    trk_segment = np.ascontiguousarray(trk_segment, dtype=np.int64)
+    trk_traj = np.ascontiguousarray(trk_traj, dtype=np.int64)
+    n_keep = int(sim.ASSOCIATION_COUNT_TO_STORE)
+    empty = (np.zeros(0, dtype=packets_dtype), np.zeros(0, dtype=assn_dtype()))
+    R = len(row_event)
+    if R == 0:
+        return empty
+    io_groups = np.unique(np.array(list(d.MODULE_TO_IO_GROUPS.values())))
+    io_groups = io_groups if i_mod < 0 else io_groups[(i_mod - 1) * 2: i_mod * 2]
+    unique_events, inv = np.unique(row_event, return_inverse=True)
+    event_start_times = np.asarray(event_start_times, dtype=np.float64)
+    base = (event_start_times[inv] / d.CLOCK_CYCLE).astype(int).astype(np.int64)
+    ts_s = (event_start_times[inv] * units.mus / units.s).astype(np.int64)
+    ped = _digitize0()
+    hit0 = np.r_[0, np.cumsum(row_nh)]
+    trk0 = np.r_[0, np.cumsum(row_nt)]
+    frac0 = np.r_[0, np.cumsum(row_nh * row_nt)]
+    # slots up to the first ADC <= pedestal (fee.py:159-162,281-282)
+    n_valid = np.zeros(R, dtype=np.int64)
+    if len(hit_adc):
+        row_of_hit = np.repeat(np.arange(R), row_nh)
+        slot = np.arange(len(hit_adc)) - hit0[row_of_hit]
+        stop = np.where(hit_adc <= ped, slot, np.int64(1 << 40))
+        first_stop = np.full(R, np.int64(1 << 40))
+        np.minimum.at(first_stop, row_of_hit, stop)
+        n_valid = np.minimum(row_nh, first_stop)
+    module_known = np.isin(row_pixel // (int(d.N_PIXELS[0]) * int(d.N_PIXELS[1])) // 2 + 1,
+                           np.array(list(d.MODULE_TO_IO_GROUPS.keys()), dtype=np.int64))
+    rows_in = np.flatnonzero((n_valid > 0) & module_known)
+    if len(rows_in) == 0:
+        return empty
+    ok, io_group, io_channel, chip, channel, _ = _row_addresses(row_pixel[rows_in], L, bad_channels)
+    nv = n_valid[rows_in]
+    # the C side walks [row_hit0[i], row_hit0[i + 1]) of the hit arrays: the rows' leading slots, gathered
+    take = np.repeat(hit0[rows_in], nv) + (np.arange(int(nv.sum())) - np.repeat(np.cumsum(nv) - nv, nv))
+    a_adc = np.ascontiguousarray(hit_adc[take])
+    a_tick = np.ascontiguousarray(hit_tick[take])
+    r_hit0 = np.ascontiguousarray(np.r_[0, np.cumsum(nv)], dtype=np.int64)
+    r_trk0_lo = trk0[rows_in]
+    nt_in = row_nt[rows_in]
+    # track slots: contiguous per row already; pass offsets into the full arrays through a gathered copy of the offsets
+    # (row_trk0 must be one array of n + 1 ascending offsets: gather the slots of the rows that enter)
+    ttake = np.repeat(r_trk0_lo, nt_in) + (np.arange(int(nt_in.sum())) - np.repeat(np.cumsum(nt_in) - nt_in, nt_in))
+    a_seg = np.ascontiguousarray(trk_segment[ttake])
+    a_trj = np.ascontiguousarray(trk_traj[ttake])
+    r_trk0 = np.ascontiguousarray(np.r_[0, np.cumsum(nt_in)], dtype=np.int64)
+    r_frac0 = np.ascontiguousarray(frac0[rows_in], dtype=np.int64)
+    lt_t = np.ascontiguousarray(np.empty(0) if light_trigger_times is None else light_trigger_times, dtype=np.float64).ravel()
+    lt_e = np.ascontiguousarray(np.empty(0, dtype=np.int64) if light_trigger_event_id is None else light_trigger_event_id, dtype=np.int64).ravel()
+    lt_m = np.ascontiguousarray(np.empty(0) if light_trigger_modules is None else light_trigger_modules).ravel().astype(np.int64)
+    n_trig_rows = 0
+    if light.LIGHT_TRIG_MODE == 0 and len(lt_e):
+        per_mod = {int(m): len(g) for m, g in d.MODULE_TO_IO_GROUPS.items()}
+        n_trig_rows = int(sum(per_mod.get(int(m), 0) for m in lt_m))
+    mods = sorted(int(m) for m in d.MODULE_TO_IO_GROUPS)
+    mod_ids = np.array(mods, dtype=np.int64)
+    mg = [np.asarray(list(d.MODULE_TO_IO_GROUPS[m]), dtype=np.int32) for m in mods]
+    mod_g0 = np.ascontiguousarray(np.r_[0, np.cumsum([len(g) for g in mg])], dtype=np.int32)
+    mod_g = np.ascontiguousarray(np.concatenate(mg) if mg else np.zeros(0, dtype=np.int32), dtype=np.int32)
+    iog = np.ascontiguousarray(io_groups, dtype=np.int32)
+    cap = 2 * int(nv.sum()) + len(unique_events) * 2 * len(iog) + n_trig_rows + 16
+    pk = np.zeros(cap, dtype=packets_dtype)
+    ds = np.zeros(cap, dtype=assn_dtype())
+    Lb = lib.load()
+    assert pk.dtype.itemsize == Lb.ldsim_packets_row_bytes() and ds.dtype.itemsize == Lb.ldsim_packets_assn_row_bytes(C.c_int32(n_keep))
+    keep = dict(ev=np.ascontiguousarray(row_event[rows_in]), base=np.ascontiguousarray(base[rows_in]), ts=np.ascontiguousarray(ts_s[rows_in]),
+                ok=np.ascontiguousarray(ok, dtype=np.uint8), iog=np.ascontiguousarray(io_group, dtype=np.int32),
+                ioc=np.ascontiguousarray(io_channel, dtype=np.int32), chip=np.ascontiguousarray(chip, dtype=np.int32),
+                chan=np.ascontiguousarray(channel, dtype=np.int32))
+    P = LdsimPacketsIn()
+    P.n_rows = len(rows_in)
+    P.row_event, P.row_base, P.row_ts_s = (a.ctypes.data for a in (keep["ev"], keep["base"], keep["ts"]))
+    P.row_ok, P.row_io_group, P.row_io_channel = keep["ok"].ctypes.data, keep["iog"].ctypes.data, keep["ioc"].ctypes.data
+    P.row_chip, P.row_channel = keep["chip"].ctypes.data, keep["chan"].ctypes.data
+    P.row_hit0, P.row_trk0, P.row_frac0 = r_hit0.ctypes.data, r_trk0.ctypes.data, r_frac0.ctypes.data
+    P.hit_adc, P.hit_tick, P.hit_frac = a_adc.ctypes.data, a_tick.ctypes.data, hit_frac.ctypes.data
+    P.trk_segment, P.trk_traj = a_seg.ctypes.data, a_trj.ctypes.data
+    P.base0 = int(base[0])
+    P.first_row_is_row0 = int(rows_in[0] == 0)
+    P.light_trig_mode = int(light.LIGHT_TRIG_MODE)
+    P.n_trig = len(lt_e)
+    P.trig_time, P.trig_event, P.trig_module = lt_t.ctypes.data, lt_e.ctypes.data, lt_m.ctypes.data
+    P.n_io_groups, P.io_groups = len(iog), iog.ctypes.data
+    P.n_modules, P.module_ids, P.module_group0, P.module_groups = len(mods), mod_ids.ctypes.data, mod_g0.ctypes.data, mod_g.ctypes.data
+    P.clock_reset_period = int(d.CLOCK_RESET_PERIOD)
+    P.clock_cycle, P.mus, P.s = float(d.CLOCK_CYCLE), float(units.mus), float(units.s)
+    P.n_keep, P.max_tracks = n_keep, int(sim.MAX_TRACKS_PER_PIXEL)
+    n = int(Lb.ldsim_packets_build(C.byref(P), pk.ctypes.data_as(C.c_void_p), ds.ctypes.data_as(C.c_void_p), C.c_int64(cap)))
+    if n < 0:
+        raise lib.LdsimError(f"ldsim error {n}: {Lb.ldsim_last_error().decode()}")
+    return pk[:n], ds[:n]
+
+
+def compact_to_rows(c, event_of_batch, first_segment_of_batch, segment_ids, traj_ids, rows=None):
+    """The arguments of ``build_packets_compact`` from ``ChargeChain.download_compact()``'s arrays (rows ``rows`` = a slice of its hit
+    pixels, default all): events from the rows' batch ids, track slots mapped to segment / trajectory ids (a batch's track slots
+    count its segments from its first one, cli/simulate_pixels.py:1019-1026)."""
+    hp = c["hit_pixels"]
+    nh_all, nt_all = hp[:, 3].astype(np.int64), (hp[:, 4] & 255).astype(np.int64)
+    h0 = np.r_[0, np.cumsum(nh_all)]
+    t0 = np.r_[0, np.cumsum(nt_all)]
+    f0 = np.r_[0, np.cumsum(nh_all * nt_all)]
+    a, b = (0, len(hp)) if rows is None else rows
+    batch = hp[a:b, 2].astype(np.int64)
+    seg_idx = np.repeat(np.asarray(first_segment_of_batch, dtype=np.int64)[batch], nt_all[a:b]) + c["track_segments"][t0[a]:t0[b]]
+    return dict(row_event=np.asarray(event_of_batch, dtype=np.int64)[batch], row_pixel=hp[a:b, 1], row_nh=nh_all[a:b], row_nt=nt_all[a:b],
+                hit_adc=c["hit_rows"]["adc"][h0[a]:h0[b]], hit_tick=c["hit_rows"]["tick"][h0[a]:h0[b]],
+                hit_frac=c["fractions"][f0[a]:f0[b]], trk_segment=np.asarray(segment_ids, dtype=np.int64)[seg_idx],
+                trk_traj=np.asarray(traj_ids, dtype=np.int64)[seg_idx])
 
 
 def build_sync_packets(sync_times, i_mod=-1):

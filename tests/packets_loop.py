@@ -144,7 +144,10 @@ def build_packets_loop(event_id_list, adc_list, adc_ticks_list, unique_pix, curr
     packets_mc_trk = np.array(mc_trk)
     packets_mc_trj = np.array(mc_trj)
     packets_mc_evt = np.array(mc_evt)
-    frac_order = np.flip(np.argsort(packets_frac, axis=1), axis=1)
+    # (the reference: np.flip(np.argsort(...)); its order of EQUAL fractions -- exact zeros of real track slots beside the unused
+    # slots' zeros -- is left to numpy's build (its SIMD sort kernels are not stable): unpinned.  kind="stable" fixes it to descending
+    # slot order, the rule of larndsim_amd.packets and csrc/packets.hip; rows without equal real fractions are unaffected)
+    frac_order = np.flip(np.argsort(packets_frac, axis=1, kind="stable"), axis=1)
     ass_segment_ids = np.take_along_axis(packets_mc_trk, frac_order, axis=1)
     ass_trajectory_ids = np.take_along_axis(packets_mc_trj, frac_order, axis=1)
     ass_fractions = np.take_along_axis(packets_frac, frac_order, axis=1)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/ldsim.h but not exported"
     assert set(lib.EXPORTS) == declared
-    assert l.ldsim_abi_version() == abi.ABI_VERSION == 6
+    assert l.ldsim_abi_version() == abi.ABI_VERSION == 7
 
 
 def test_graft_entry_build_succeeds():
@@ -360,6 +360,66 @@ def test_packets_array_form_equals_the_hit_loop(cfg, spill):
         if spill:
             assert (inp["event_start_times"] / consts.detector.CLOCK_CYCLE > consts.detector.CLOCK_RESET_PERIOD).any()
     assert n_big > 0          # the pairwise-summation branch was reached
+
+
+def _dense_to_compact_rows(event_id_list, adc_list, adc_ticks_list, unique_pix, current_fractions, track_ids, traj_ids):
+    """the arguments of packets.build_packets_compact from the dense per-pixel arrays build_packets takes: every row, its hits = the
+    slots the chain's scan wrote (here: up to the last slot above 0 -- the exporter's own stop rule is the builder's job), its filled
+    track slots, the fractions of those slots"""
+    U, A = adc_list.shape
+    nh = np.where((adc_list != 0).any(axis=1), A - np.argmax((adc_list != 0)[:, ::-1], axis=1), 0).astype(np.int64)
+    filled = track_ids != -1
+    nt = filled.sum(axis=1).astype(np.int64)
+    assert all((filled[u, :nt[u]]).all() for u in range(U)), "track slots fill from slot 0"
+    hit_row = np.repeat(np.arange(U), nh)
+    hit_slot = np.arange(int(nh.sum())) - np.repeat(np.cumsum(nh) - nh, nh)
+    frac = [current_fractions[u, s, :nt[u]] for u, s in zip(hit_row, hit_slot)]
+    return dict(row_event=event_id_list[:, 0], row_pixel=unique_pix, row_nh=nh, row_nt=nt,
+                hit_adc=adc_list[hit_row, hit_slot].astype(np.int32), hit_tick=adc_ticks_list[hit_row, hit_slot],
+                hit_frac=np.concatenate(frac) if frac else np.zeros(0),
+                trk_segment=track_ids[filled], trk_traj=traj_ids[filled])
+
+
+@pytest.mark.parametrize("cfg,spill", [("module0", False), ("module0", True), ("2x2_no_modvar", True)])
+def test_native_packet_builder_equals_build_packets(cfg, spill):
+    """ldsim_packets_build (csrc/packets.hip: the reference's hit loop in C on the chain's compact rows -- hits, filled track slots
+    and per-hit fractions, no dense [pixel][30][50] array) against packets.build_packets on the dense form of the same rows: the
+    same bytes, on the golden inputs (pinned to fee.export_to_hdf5) and on random ones that walk every branch -- clock rollovers,
+    pixels without a chip, a disabled channel, light triggers, module selection, hit-less rows in front."""
+    from larndsim_amd import packets
+    H.load_cfg(cfg, noise_zero=False)
+    g = H.gold(f"packets_{cfg}.npz")
+    n_ev = len(g["event_times"])
+    bad = {str(g["bad_key"]): [int(g["bad_channel"])]} if str(g["bad_key"]) else None
+    args = (g["event_id_list"], g["adc"], g["ticks"], g["unique_pix"], g["fractions"], g["segment_ids"], g["traj_ids"])
+    kw = dict(light_trigger_times=g["trig_times"], light_trigger_event_id=np.arange(n_ev), light_trigger_modules=np.ones(n_ev),
+              bad_channels=bad)
+    a = packets.build_packets(*args, g["event_times"], **kw)
+    b = packets.build_packets_compact(**_dense_to_compact_rows(*args), event_start_times=g["event_times"], **kw)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and len(a[0]) > 40
+    rng = np.random.default_rng(78)
+    for trial in range(6):
+        inp = _random_packet_inputs(rng, 400, 12, spill)
+        if trial >= 3:                       # the export starts with rows that hold no hit (the exporter's row 0 all the same)
+            inp["adc_list"][:3] = 0
+        kw = {}
+        if trial % 2 == 0:
+            kw = dict(light_trigger_times=rng.uniform(0, 5, 12), light_trigger_event_id=rng.integers(0, 12, 12),
+                      light_trigger_modules=np.ones(12))
+        if trial % 3 == 1:
+            kw["i_mod"] = 1
+        a = packets.build_packets(**inp, **kw)
+        if trial == 2 and len(a[0]):
+            first = a[0][a[0]["packet_type"] == 0][0]
+            kw["bad_channels"] = {"%i-%i-%i" % (first["io_group"], first["io_channel"], first["chip_id"]): [int(first["channel_id"])]}
+            a = packets.build_packets(**inp, **kw)
+        est = inp.pop("event_start_times")
+        b = packets.build_packets_compact(**_dense_to_compact_rows(**inp), event_start_times=est, **kw)
+        assert len(a[0]) == len(b[0]) > 300, trial
+        for name in a[0].dtype.names:
+            assert np.array_equal(a[0][name], b[0][name]), (trial, name)
+        for name in a[1].dtype.names:
+            assert a[1][name].tobytes() == b[1][name].tobytes(), (trial, name)
 
 
 @pytest.mark.parametrize("cfg", ["module0", "2x2_no_modvar"])
