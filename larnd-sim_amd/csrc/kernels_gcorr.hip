@@ -36,7 +36,9 @@ struct GLds {
   int xs, ys, zs, cellcap, bytes;
   bool z_lds;
 };
-__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT, int budget, int M) {
+// (M | 16: Z is never staged -- the P step reads it from the record)
+__host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, int TT, int budget, int Mz) {
+  const int M = Mz & 15;
   GLds L;
   L.xs = (ncol + 1) | 1;                             // odd strides: the 16 node rows fall on distinct banks; column `ncol` of X
   L.ys = NJ | 1;                                     //   holds zeros (the weightless padding cells of the list point at it)
@@ -48,7 +50,7 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   // M = 1: == 16 mod 32, the four 16-shift runs of an A operand read conflict-free; M = 2 reads every other shift (one parity):
   // an odd stride puts the runs of neighbouring node rows on the other half of the bank pairs
   const int zs = M == 2 ? nur + 1 : ((nur & 31) == 16 ? nur : nur + 16);
-  L.z_lds = NU <= G_NUCAP && rest + 8 * G_NODES * zs <= budget;
+  L.z_lds = !(Mz & 16) && NU <= G_NUCAP && rest + 8 * G_NODES * zs <= budget;
   L.zs = L.z_lds ? zs : 0;
   L.bytes = rest + 8 * G_NODES * L.zs;
   return L;
@@ -114,10 +116,11 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
-  if (g_lds_class(ncol, NJ, NU, TT, b0, b1, M) != cls) return;      // another launch's pair
+  const int Mz = M | ((GA.dbg & 1024) ? 16 : 0);
+  if (g_lds_class(ncol, NJ, NU, TT, b0, b1, Mz) != cls) return;      // another launch's pair
   unsigned long long ts_info = 0;
   if (stamps) ts_info = __builtin_amdgcn_s_memtime();
-  const GLds L = g_lds_layout(ncol, NJ, NU, TT, cls == 0 ? b0 : (cls == 1 ? b1 : b2), M);
+  const GLds L = g_lds_layout(ncol, NJ, NU, TT, cls == 0 ? b0 : (cls == 1 ? b1 : b2), Mz);
   const double* __restrict__ rec = GA.rec + gip->off;
   const int emask = gip->emask, ebound = gip->edge_bound, it0 = gip->it0, T = gip->T, it_w0 = gip->it_w0, it_w1 = gip->it_w1;
   const int NUr = g_nur(NU), NU16 = NUr >> 4;
@@ -562,15 +565,18 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
   const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
+  // [round 4: 12 KB for M = 1 -- swept again on the kernel without spills: 12 KB 5.04, 13 KB 5.24-5.40, 11 KB 5.20, 14 KB 5.44 ms per
+  // 50 k segments (profiles/r04_gcorr_lds_budget.log); at 13312 + the static words a CU held eleven workgroups, not twelve]
   // Launches of the correlation by LDS need (g_lds_class): pairs that fit 13 KB (M = 1: 80 VGPRs, six waves per SIMD; M = 2, whose
   // kernel spills at 80: 16 KB, 96 VGPRs, five) run twelve (ten) to a CU in the launch over all pairs, the
   // rest -- listed here, counted on the host together with the pool size -- seven to a CU at 22 KB (every such pair of the ndlar
   // workload fits it; at 32 KB they ran five to a CU: 18.8 -> 17.6 ms per 50 k segments, tools/lds_b1_sweep.py) or two to three at the caps' size.
-  const int b0 = (M == 1 ? 13312 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, M).bytes;
+  const int Mz = M | ((ctx->debug_gform & 1024) ? 16 : 0);
+  const int b0 = (M == 1 ? 12288 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, Mz).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
-  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, b0, b1, M, d_big, d_total + 1);
+  hipLaunchKernelGGL(gbig_list_kernel, dim3(g0), dim3(256), 0, st, gi, n, TT, b0, b1, Mz, d_big, d_total + 1);
   HIPCHK(hipGetLastError());
   GA.gi = gi;
   GA.dbg = (ctx->debug_gform & ~64) | (ctx->gform_wave_tables ? 0 : 64);

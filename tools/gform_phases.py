@@ -31,6 +31,9 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
         # in-kernel cycle stamps of gcorr_kernel's waves (debug_gform 128; printed to stderr by the library)
         "stamps": ((0, 0, 128), (0, 0, 0)),
         # an odd tile pair shared by the pair's two waves (default) against dealt whole (debug_gform 256)
+        # Z staged in LDS where it fits (default) against read from the record in the P step for every pair (debug_gform 1024), at
+        # several LDS budgets of the first class (13 KB - pad)
+        "zlds": ((0, 0, 0), (0, 0, 1024), (0, 2, 1024), (0, 4, 1024), (0, 1, 0), (0, 1, 1024), (0, 0, 0)),
         "share": ((0, 0, 0), (0, 0, 256), (0, 0, 128), (0, 0, 384), (0, 0, 0), (0, 0, 256)),
         "corr": ((0, 0, 0), (0x100000, 0, 0), (0x200000, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0x100000, 0, 4), (0x100000, 0, 12),
                  (0x100000, 0, 14), (0, -12, 0), (0, 6, 0), (0, 0, 0))}
