@@ -37,7 +37,7 @@ SEGS_PER_GPU = 100_000
 CHUNK_SEGMENTS = int(os.environ.get("LDSIM_CHUNK_SEGMENTS", "100000"))
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector FP64 (spec)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (spec), /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "r03_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "r04_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
 def host_cpu():
@@ -430,6 +430,20 @@ def main():
             ch.synchronize()
             t_dense = (time.perf_counter() - t2) / nd
             extras["dense_response_value"] = len(seg) / t_dense
+            nl_d = max(acc["launches"], 1)
+            useful_d = acc["dfma_useful"] if acc["dfma_useful"] > 0 else acc["dfma"]
+            tr_d, tr_src = profiled_traffic(a.config + "_dense", "mac_shift_kernel" if round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING) == 1 else "mac_shift2_kernel")
+            # first-class roofline of the path a full-support response table takes (gform_max_support hands it to the round-2 kernels)
+            extras["roofline_dense"] = {
+                "bound": "valu_f64", "kernel": "mac_shift_kernel" if round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING) == 1 else "mac_shift2_kernel",
+                "launch_ms_avg": acc["m_ms"] / nl_d, "weights_kernel": "qweights_kernel", "weights_kernel_ms_avg": acc["w_ms"] / nl_d,
+                "achieved": (2.0 * useful_d / (acc["m_ms"] * 1e-3) / 1e12) if acc["m_ms"] > 0 else None, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (2.0 * useful_d / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if acc["m_ms"] > 0 else None,
+                "issued_frac": (2.0 * acc["dfma"] / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if acc["m_ms"] > 0 else None,
+                "traffic": tr_d, "traffic_source": tr_src,
+                "note": "algorithmic flops = 2 x (weights kept) x (window ticks) over the correlation kernel's time against the f64 DFMA peak; "
+                        "issued counts every FMA lane (8-shift block and 512-tick tile padding)"}
             extras["dense_response"] = {"value": len(seg) / t_dense, "unit": "segments/s", "ms_per_step": 1e3 * t_dense,
                                         "steps": nd, "mac_kernel_ms_avg": acc["m_ms"] / max(acc["launches"], 1),
                                         "dfma_per_segment": acc["dfma"] / max(acc["S"], 1),
@@ -478,6 +492,12 @@ def main():
                                    f"(seed {synth.SEED_BASE + seed_index}, {segs_per_event}/event), {what}, backtracking fractions "
                                    f"{'on' if a.fractions else 'off'}",
                        "response": f"synthetic '{a.response}' (45,45,1950) f64", "noise": "off",
+                       "trim_response_log": 23.0 if a.trim_response_log is None else a.trim_response_log,
+                       "quad_accuracy_log10": 7,
+                       "approximations": "response ticks below exp(-trim_response_log) = 1e-10 of the table's largest entry are not read "
+                                         "(a waveform moves by < 1e-10 of its peak; `exact_zero_trim` is the figure without it); quadrature "
+                                         "along the segment for 1e-7 of the peak weight (0.012 of the parity tolerance on the reference's "
+                                         "goldens: profiles/r04_acc_sweep_module0.log)",
                        "light": (f"synthetic LUT (14,26,8) x 48 ch/TPC x 100 bins, {int(consts.light.N_OP_CHANNEL)} channels, "
                                  f"{len(bedges) - 1} photon sums per step") if light_on else "off",
                        "segments_per_step": int(n_job), "pairs_per_segment": acc["pairs"] / max(acc["S"], 1),

@@ -11,7 +11,7 @@ echo 3 >> $O/progress; python3 bench.py --baseline-config 3 --steps 2 --warmup 1
 echo 5 >> $O/progress; python3 bench.py --baseline-config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_ndlar_1M.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 echo kt >> $O/progress; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --config ndlar --light on --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/kt.log 2>&1 || exit 1
-cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats_ndlar.csv
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/r04_kernel_stats_ndlar.csv
 rm -rf $O/kt
 echo done >> $O/progress
 for f in module0 2x2 2x2_light ndlar_light 2x2_1M ndlar_1M; do tail -1 $O/bench_$f.log | cut -c1-200; done

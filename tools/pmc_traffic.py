@@ -1,6 +1,6 @@
 """HBM bytes per launch of the chain's kernels from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, rocprofv3 PMC slots).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
-coalesced read (same guide, HBM), so it is doubled.  Writes profiles/r03_traffic.json (LDSIM_TRAFFIC_FILE names another), which bench.py reads for
+coalesced read (same guide, HBM), so it is doubled.  Writes profiles/r04_traffic.json (LDSIM_TRAFFIC_FILE names another), which bench.py reads for
 `roofline.traffic`, and copies the per-kernel averages next to it.
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
@@ -65,12 +65,13 @@ def main():
         return kernel_stats(sys.argv[2], sys.argv[3])
     config, d_fetch, d_write = sys.argv[1:4]
     fetch, write = per_kernel(d_fetch, "FETCH_SIZE"), per_kernel(d_write, "WRITE_SIZE")
-    path = os.path.join(REPO, "profiles", os.environ.get("LDSIM_TRAFFIC_FILE", "r03_traffic.json"))
+    path = os.path.join(REPO, "profiles", os.environ.get("LDSIM_TRAFFIC_FILE", "r04_traffic.json"))
     tab = json.load(open(path)) if os.path.exists(path) else {}
     entry = {}
     # a kernel launched several times per chain launch (gcorr_kernel: once per LDS class) is summed over them: "per launch" means
-    # per chain launch = per dispatch of pixel_adc_kernel, which runs once in each
-    chain_f, chain_w = fetch.get("pixel_adc_kernel", (0.0, 0))[1], write.get("pixel_adc_kernel", (0.0, 0))[1]
+    # per chain launch
+    # (make_keys_kernel runs once per chain launch; the FEE stage is two list launches since round 4)
+    chain_f, chain_w = fetch.get("make_keys_kernel", (0.0, 0))[1], write.get("make_keys_kernel", (0.0, 0))[1]
     for k in sorted(set(fetch) | set(write)):
         f_kib, nf = fetch.get(k, (0.0, 0))
         w_kib, nw = write.get(k, (0.0, 0))
@@ -80,7 +81,7 @@ def main():
                     "write_size_kib_avg": w_kib, "dispatches_per_chain_launch": per_f,
                     "launches_profiled": [nf, nw],
                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x 2 per the gfx950 correction"}
-    tab[config] = entry
+    tab[os.environ.get("LDSIM_TRAFFIC_KEY", config)] = entry
     with open(path, "w") as fh:
         json.dump(tab, fh, indent=1, sort_keys=True)
     for k, e in sorted(entry.items(), key=lambda kv: -kv[1]["bytes_per_launch"])[:8]:
