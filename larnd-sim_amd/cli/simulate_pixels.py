@@ -679,23 +679,30 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
     overlapped = raw_arrays and ((nsim >= 8 * chunk_segments) if overlap_downloads is None else bool(overlap_downloads))
     b = 0
     in_flight = None
-    for e in edges[1:]:
-        if not (e - b >= chunk_segments or e == nsim):
-            continue
+    launches = [(int(b0), int(e0)) for b0, e0 in _launch_ranges(edges, nsim, chunk_segments)]
+    if not raw_arrays:
+        # Default path.  Launch k runs on a worker thread (ChargeChain.run_async: the C call blocks on its size read-backs but
+        # releases the interpreter) while launch k - 1's packets are built here from its compact download -- host work that never
+        # enters the ctx.
+        prev = None
+        for b0, e0 in launches:
+            chain.run_async(b0, e0, want_fractions=True)
+            if prev is not None:
+                export_chunk_compact(prev)
+            chain.wait()
+            prev = chain.download_compact()
+        if prev is not None:
+            export_chunk_compact(prev)
+        launches = []
+    for b, e in launches:
         chain.run(int(b), int(e), want_fractions=True)
-        if not raw_arrays:
-            export_chunk_compact(chain.download_compact())
-            b = e
-            continue
         if not overlapped:
             export_chunk(chain.download())
-            b = e
             continue
         arriving = chain.download_async()
         if in_flight is not None:
             export_chunk(in_flight)
         in_flight = arriving
-        b = e
     if in_flight is not None:
         chain.wait_download()
         export_chunk(in_flight)
@@ -706,6 +713,15 @@ def _simulate_module(chain, out, i_mod, m2m, tracks, all_events, det_borders, ev
         for k in parts[0]:
             out.put(("raw/" if not m2m else f"raw_mod{i_mod - 1}/") + k, np.concatenate([p[k] for p in parts]))
     return res
+
+
+def _launch_ranges(edges, nsim, chunk_segments):
+    """segment ranges of the chain launches: whole batches, at least chunk_segments each (the last one: what is left)"""
+    b = 0
+    for e in edges[1:]:
+        if e - b >= chunk_segments or e == nsim:
+            yield b, e
+            b = e
 
 
 def main(argv=None):

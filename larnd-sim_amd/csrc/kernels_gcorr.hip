@@ -44,12 +44,16 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   L.ys = NJ | 1;                                     //   holds zeros (the weightless padding cells of the list point at it)
   const int nur = g_nur(NU);
   L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys) + L.cellcap) + 16;
+  // (one 32-bit word per listed cell since round 4: cell index | X column << 12 | Y row entry << 18 -- 64-bit words with the row's
+  // offset spelled out cost a KB per 256 cells, which is what kept the Z table of a typical pair out of LDS)
+  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys)) + 4 * L.cellcap + 16;
   // Z in LDS where the pair's budget has room for it; else (and for the steepest long segments, NU > G_NUCAP) the P step reads
   // it from the record: a pair never drops to the low-occupancy class because of its Z table
   // M = 1: == 16 mod 32, the four 16-shift runs of an A operand read conflict-free; M = 2 reads every other shift (one parity):
   // an odd stride puts the runs of neighbouring node rows on the other half of the bank pairs
-  const int zs = M == 2 ? nur + 1 : ((nur & 31) == 16 ? nur : nur + 16);
+  // (round 4, M = 1: the rows packed -- a two-way bank conflict on the P step's four reads per 16 shifts against a trip to the
+  // record for every pair whose padded table did not fit)
+  const int zs = M == 2 ? nur + 1 : nur;
   L.z_lds = !(Mz & 16) && NU <= G_NUCAP && rest + 8 * G_NODES * zs <= budget;
   L.zs = L.z_lds ? zs : 0;
   L.bytes = rest + 8 * G_NODES * L.zs;
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
   double* s_Y = s_X + G_NODES * L.xs;               // [16][ys]
   double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
   // per listed cell: response row offset (doubles into the padded table) | byte offsets of its X column and Y row << 32, << 48
-  unsigned long long* s_info = (unsigned long long*)(s_Z + G_NODES * L.zs);
+  unsigned* s_info = (unsigned*)(s_Z + G_NODES * L.zs);      // per listed cell: cell index | X column << 12 | Y row entry << 18
   __shared__ int s_ncell, s_nreal;
   const int xs = L.xs, ys = L.ys, zs = L.zs;
   double* ow = s_out + wv * TT;
@@ -201,8 +205,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
           const int ncell_l = cells[0], nreal_l = cells[1];
           auto info_word = [&](unsigned ce) {
             const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
-            return (unsigned long long)((ce & 0xFFFFu) * (unsigned)nkp) | ((unsigned long long)(col * 8u) << 32) |
-                   ((unsigned long long)(jc * 8u) << 48);                // (row word | column word: offsets in doubles / bytes)
+            return (ce & 0xFFFu) | (col << 12) | (jc << 18);
           };
           if (stage) {
             if (c8 < ncol) s_X[n * xs + c8] = row ? x0 : 0.0;
@@ -326,15 +329,19 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       // its use, no branch, and sched_barrier keeps the compiler from sinking them back to their uses.  [Prefetching the next tile
       // pair's first groups across the P step changed nothing: the loop runs at the rate the L1 delivers the B operands.]
       const bool run_tiles = n32 > 0 && ngrp > 0 && !(A.debug_phases & 0x100000);
-      const unsigned* s_inf32 = (const unsigned*)s_info;
+      const unsigned* s_inf32 = s_info;
       const char* xl = (const char*)(s_X + jj * xs);
       const char* yl = (const char*)(s_Y + jj * ys);
       auto wrap = [&](int g) {            // (g < 3 ngrp)
         g = g >= ngrp ? g - ngrp : g;
         return g >= ngrp ? g - ngrp : g;
       };
-      auto row_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk)]; };
-      auto col_word = [&](int g) { return s_inf32[2 * (4 * wrap(g) + kk) + 1]; };
+      // row word: the cell's offset into the padded response table (doubles); column word: byte offsets of its X column and Y row entry
+      auto row_word = [&](int g) { return (s_inf32[4 * wrap(g) + kk] & 0xFFFu) * (unsigned)nkp; };
+      auto col_word = [&](int g) {
+        const unsigned w = s_inf32[4 * wrap(g) + kk];
+        return ((w >> 9) & 0x1F8u) | (((w >> 15) & 0x1F8u) << 16);      // (col * 8) | (j * 8) << 16
+      };
       // The tile pairs are dealt to the pair's two waves alternately; an odd one left over (the survey table's 82 staged ticks are
       // three tile pairs) is shared: each wave multiplies it with half of the cell groups, and both run the P step and the edge
       // column on their partial G -- every step after G is linear in it, and the two tick arrays are added anyway.  [Dealt whole,
@@ -515,7 +522,7 @@ extern "C++" int gform_M(const ldsim_ctx* ctx, const CurArgs& args) {
   const double ratio = h.time_sampling / h.response_sampling;
   const int M = (int)llround(ratio);
   if (M < 1 || M > 2 || fabs(ratio - M) > 1e-9 || h.sampled_points > NS_MAX || args.nj > NJ_MAX || args.ni > 64 ||
-      args.ni * args.nj > 65535 || args.n_pairs > 0x7fffffffLL)
+      args.ni * args.nj > 4096 || args.n_pairs > 0x7fffffffLL)      // (12 bits of cell index in gcorr_kernel's LDS words)
     return 0;
   return M;
 }

@@ -87,6 +87,35 @@ class ChargeChain:
         self._want_fractions = bool(want_fractions)
         return st
 
+    def run_async(self, seg_begin=0, seg_end=None, want_fractions=False):
+        """``run`` on a worker thread: the C call blocks (a chain launch reads sizes back from the device five times) but releases
+        the interpreter, so the caller can do host work that does not enter the ctx meanwhile -- the bundled driver builds the
+        previous launch's packets (``ldsim_packets_build`` takes no ctx).  ``wait()`` joins and returns the launch's statistics.
+        Any other call into the ctx before ``wait()`` is refused by the library (LDSIM_ESTATE: a ctx serves one thread at a time)."""
+        import threading
+        if getattr(self, "_worker", None) is not None:
+            raise lib.LdsimError("a chain launch is already in flight: wait() first")
+        box = {}
+
+        def work():
+            try:
+                box["st"] = self.run(seg_begin, seg_end, want_fractions)
+            except BaseException as e:          # handed to wait()
+                box["err"] = e
+        self._worker = (threading.Thread(target=work, name="ldsim-chain-launch"), box)
+        self._worker[0].start()
+
+    def wait(self):
+        """Join the launch started by ``run_async`` and return its statistics (or raise what it raised)."""
+        w = getattr(self, "_worker", None)
+        if w is None:
+            raise lib.LdsimError("no chain launch in flight")
+        w[0].join()
+        self._worker = None
+        if "err" in w[1]:
+            raise w[1]["err"]
+        return w[1]["st"]
+
     def set_pixel_thresholds(self, keys, values, default):
         """Per-pixel discrimination thresholds of the fused chain: ``pixel_thresholds_lut[unique_pix]`` of the reference
         driver (cli/simulate_pixels.py:1079-1084).  Call after the constants are loaded."""

@@ -764,6 +764,34 @@ def test_second_thread_entering_a_busy_ctx_is_refused():
         assert np.array_equal(good[k], out[k]), f"{k}: the call in progress was disturbed"
 
 
+def test_chain_run_async_equals_run():
+    """ChargeChain.run_async / wait: the launch on a worker thread (the interpreter is free for host work meanwhile; the bundled
+    driver builds the previous launch's packets there) gives the same statistics and results as run(); a second launch before
+    wait() and a wait() without a launch are refused; a ctx call from the launching thread during the flight is refused by the
+    library's guard or runs after it -- never beside it."""
+    H.load_cfg("module0")
+    seg = synth.make_segments(6000, seed=6, segs_per_event=1500)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    ch = ChargeChain(synth.make_response("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    st0 = ch.run(0, len(seg), want_fractions=True)
+    good = ch.download()
+    ch.run_async(0, len(seg), want_fractions=True)
+    with pytest.raises(lib.LdsimError, match="already in flight"):
+        ch.run_async(0, len(seg))
+    host_work = sum(i * i for i in range(200000))          # (anything that does not enter the ctx)
+    st1 = ch.wait()
+    assert host_work > 0 and st1.n_pairs == st0.n_pairs and st1.n_unique == st0.n_unique
+    out = ch.download()
+    for k in good:
+        assert np.array_equal(good[k], out[k]), k
+    with pytest.raises(lib.LdsimError, match="no chain launch in flight"):
+        ch.wait()
+
+
 def test_chain_with_nothing_to_simulate():
     """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
     drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""
