@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDSIM_ABI_VERSION 7
+#define LDSIM_ABI_VERSION 8
 
 /* error codes */
 #define LDSIM_OK 0
@@ -503,6 +503,13 @@ typedef struct {
 int32_t ldsim_packets_row_bytes(void);
 int32_t ldsim_packets_assn_row_bytes(int32_t n_keep);
 int64_t ldsim_packets_build(const LdsimPacketsIn* in, void* packets_out, void* assn_out, int64_t capacity);
+
+/* ---- output writer helper (host only, no ctx) ----
+ * CRC-32 (reflected 0xEDB88320: what a ZIP member carries, = zlib.crc32) of the concatenation of n_parts byte ranges on
+ * n_threads host threads (<= 0: all hardware threads).  The driver's .npz writer (cli/simulate_pixels.py OutputFile, the stand-in
+ * for the h5py datasets of the reference's cli/simulate_pixels.py:1240-1301) checksums a dataset that exists as the .npy header
+ * plus one piece per chain launch without joining the pieces. */
+uint32_t ldsim_crc32_parts(const void* const* parts, const uint64_t* sizes, int64_t n_parts, int32_t n_threads);
 
 /* timing of the dominant kernel over the last chain call, measured with HIP events on the ctx stream */
 int ldsim_chain_kernel_ms(ldsim_ctx* ctx, double* current_ms, double* adc_ms, double* total_ms);

@@ -150,8 +150,13 @@ class _Output:
                 if "configs" in f.keys() and pixel_layout is not None:
                     f["configs"].attrs["pixel_layout"] = pixel_layout
         if self.h5py is None:
-            out = {k: (np.concatenate(v) if len(v) > 1 else v[0]) for k, v in self.parts.items() if len(v)}
-            np.savez(self.filename, **out)       # uncompressed like the HDF5 datasets it stands in for (zlib cost a quarter of a run)
+            # stored members like np.savez (uncompressed like the HDF5 datasets they stand in for), each written from its
+            # per-launch pieces as they are, checksummed on all host threads (larndsim_amd/npz_stream.py)
+            from larndsim_amd.npz_stream import NpzStream
+            with NpzStream(self.filename if self.filename.endswith(".npz") else self.filename + ".npz") as z:
+                for k, v in self.parts.items():
+                    if len(v):
+                        z.write(k, v)
 
 
 def _prepend_t_event(arr):

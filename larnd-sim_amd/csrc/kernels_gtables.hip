@@ -406,6 +406,9 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
   const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
+  const bool stamps = (GA.dbg & 2048) != 0;      // timing tools: cycle stamps into the statistics stripes 9..15 (chain.hip prints them)
+  unsigned long long ts0 = 0, ts_a = 0, ts_b = 0, ts_c = 0, ts_xy = 0, ts_z = 0, ts_cells = 0, ts_m = 0;
+  if (stamps) ts0 = __builtin_amdgcn_s_memtime();
   GInfo* __restrict__ gip = GA.gi + pair;
   // (everything the pair's two records hold is requested before the first branch: one round trip to memory instead of three)
   const GInfo gi0 = *gip;
@@ -439,6 +442,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   if (lane < PP_COUNT) s_par[lane] = par_l;
   s_e2[lane] = e2_l;
   wsync();
+  if (stamps) ts_a = __builtin_amdgcn_s_memtime();
   const int NS = c->sampled_points;
   const double bin = c->response_bin_size;
   const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};      // (edge_ks of the launch's constants, from the host)
@@ -517,6 +521,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     if (jmax >= jmin && lane <= NJ && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
   }
   if (ncol != ncol_g || NJ != NJ_g || jmin != gi0.jmin || ncol + NJ > XYS - 1) bad = true;
+  if (stamps) ts_b = __builtin_amdgcn_s_memtime();
 
   // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
   int NUc, anyinv = 0;
@@ -615,6 +620,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     return;
   }
   wsync();
+  if (stamps) ts_c = __builtin_amdgcn_s_memtime();
   if (A.debug_phases & 0x1000000) return;      // timing tools: stop after the maps
 
   const double* gx_tab = GA.glx + (int64_t)NQ * (NQ - 1) / 2;
@@ -660,6 +666,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     auto tables = [&](auto mc_tag) {
       constexpr int MC = decltype(mc_tag)::value;
       // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
+      if (stamps) ts_m = __builtin_amdgcn_s_memtime();
       for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
         const int bi = b0 + u16;
         const bool act = bi < nbins, isx = bi < ncol;
@@ -699,6 +706,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         }
       }
       // ---- Z and, from the same Gaussians, the tables over the slices that are invalid at a window edge -----------------------------------------
+      if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_xy += t - ts_m; ts_m = t; }
       {
         double cen[4];
   #pragma unroll
@@ -779,6 +787,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
       case 3: tables(std::integral_constant<int, 3>{}); break;
       default: tables(std::integral_constant<int, 4>{}); break;
     }
+    if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_z += t - ts_m; ts_m = t; }
     // per-node totals over the shifts (cell test): row sums over the 16 lanes of a node group
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -816,6 +825,16 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
       if (lane < padded - base && base > 0) cells[G_CELL0 + base + lane] = (int)(0x80000000u | first_code);
       if (lane == 0) { cells[0] = padded; cells[1] = base; }
     }
+    if (stamps) ts_cells += __builtin_amdgcn_s_memtime() - ts_m;
+  }
+  if (stamps && lane == 0) {
+    stat_add(A.counters, 9, ts_a - ts0);
+    stat_add(A.counters, 10, ts_b - ts_a);
+    stat_add(A.counters, 11, ts_c - ts_b);
+    stat_add(A.counters, 12, ts_xy);
+    stat_add(A.counters, 13, ts_z);
+    stat_add(A.counters, 14, ts_cells);
+    stat_add(A.counters, 15, __builtin_amdgcn_s_memtime() - ts0);
   }
   if (lane == 0) {
     gip->emask = emask;

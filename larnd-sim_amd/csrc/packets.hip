@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/ldsim.h"
+#include "hostpool.h"
 
 void ldsim_set_error(const char* fmt, ...);
 
@@ -61,6 +62,55 @@ inline void empty_assn(char* row, int n_keep) {
   ev[0] = -1;
   for (int k = 0; k < n_keep; k++) { seg[k] = -1; fr[k] = 0.0; tid[k] = -1; tfr[k] = 0.0; }
 }
+
+struct Ent { double f; int slot; };
+struct TEnt { int64_t id; double f; int pos; };
+struct Todo { int64_t out, i, h; };
+
+// association row of data hit h of row i (fee.py:284-344)
+void fill_assn(const LdsimPacketsIn* in, int64_t i, int64_t h, char* row, Ent* ent, TEnt* tent) {
+  const int n_keep = in->n_keep, MT = in->max_tracks;
+  const int64_t h0 = in->row_hit0[i], t0 = in->row_trk0[i];
+  const int nt = (int)(in->row_trk0[i + 1] - t0);
+  const int64_t event = in->row_event[i];
+  empty_assn(row, n_keep);
+  int64_t* ev = (int64_t*)row;
+  int64_t* seg = ev + 1;
+  double* fr = (double*)(seg + n_keep);
+  int64_t* tid = (int64_t*)(fr + n_keep);
+  double* tfr = (double*)(tid + n_keep);
+  ev[0] = event;
+  // all max_tracks slots in descending fraction order (equal fractions: descending slot); unused slots: fraction 0, id -1
+  const double* f = in->hit_frac + in->row_frac0[i] + (int64_t)(h - h0) * nt;
+  // Only the nt filled slots are sorted; the MT - nt unused ones (slots MT-1 .. nt, all 0) sit as one run behind the last
+  // positive fraction: a filled slot with fraction 0 has the lower slot number and follows them.
+  for (int k = 0; k < nt; k++) { ent[k].f = f[k]; ent[k].slot = k; }
+  std::sort(ent, ent + nt, [](const Ent& a, const Ent& b) { return a.f > b.f || (a.f == b.f && a.slot > b.slot); });
+  int n_pos = 0;
+  while (n_pos < nt && ent[n_pos].f > 0.0) n_pos++;
+  const int w = n_keep < MT ? n_keep : MT, n_unused = MT - nt;
+  for (int k = 0; k < w; k++) {
+    const int e = k < n_pos ? k : (k < n_pos + n_unused ? -1 : k - n_unused);
+    if (e >= 0) { seg[k] = in->trk_segment[t0 + ent[e].slot]; fr[k] = ent[e].f; }      // (else: -1 and 0 from empty_assn)
+  }
+  // trajectories: ids ascending, each with the sum of its slots' fractions taken in fraction order (left to right), stored f4
+  int ntr = 0;
+  for (int k = 0; k < nt; k++) {
+    const int64_t id = in->trk_traj[t0 + ent[k].slot];
+    if (id > -1) { tent[ntr].id = id; tent[ntr].f = ent[k].f; tent[ntr].pos = ntr; ntr++; }
+  }
+  std::sort(tent, tent + ntr, [](const TEnt& a, const TEnt& b) { return a.id < b.id || (a.id == b.id && a.pos < b.pos); });
+  int ng = 0;
+  for (int k = 0; k < ntr && ng < n_keep;) {
+    double sum = tent[k].f;
+    int e = k + 1;
+    while (e < ntr && tent[e].id == tent[k].id) { sum += tent[e].f; e++; }
+    tid[ng] = (int64_t)(int32_t)tent[k].id;            // (the reference's id array is int32)
+    tfr[ng] = (double)(float)sum;
+    ng++;
+    k = e;
+  }
+}
 }  // namespace
 
 extern "C" int64_t ldsim_packets_build(const LdsimPacketsIn* in, void* packets_out, void* assn_out, int64_t capacity) {
@@ -80,10 +130,7 @@ extern "C" int64_t ldsim_packets_build(const LdsimPacketsIn* in, void* packets_o
   int64_t off = 0, off_row0_final = 0;
   bool have_prev_event = false, have_prev_tick = false;
   int64_t prev_event = -1, prev_tick = -1;
-  struct Ent { double f; int slot; };
-  std::vector<Ent> ent((size_t)MT);
-  struct TEnt { int64_t id; double f; int pos; };
-  std::vector<TEnt> tent((size_t)MT);
+  std::vector<Todo> todo;
   for (int64_t i = 0; i < in->n_rows; i++) {
     const int64_t h0 = in->row_hit0[i], h1 = in->row_hit0[i + 1];
     const int64_t t0 = in->row_trk0[i];
@@ -177,45 +224,20 @@ extern "C" int64_t ldsim_packets_build(const LdsimPacketsIn* in, void* packets_o
         const uint64_t word = (((uint64_t)chip & 0xFFull) << 2) | (((uint64_t)channel & 0x3Full) << 10) |
                               (((uint64_t)tick_m & 0x7FFFFFFFull) << 16) | (1ull << 47) | (((uint64_t)dataword & 0xFFull) << 48);
         r->parity = (uint8_t)(1 - (__builtin_popcountll(word) & 1));
-        // ---- association row (fee.py:284-344) -------------------------------------------------------------------------------------------
-        char* row = as + (size_t)n_out * assn_bytes;
-        empty_assn(row, n_keep);
-        int64_t* ev = (int64_t*)row;
-        int64_t* seg = ev + 1;
-        double* fr = (double*)(seg + n_keep);
-        int64_t* tid = (int64_t*)(fr + n_keep);
-        double* tfr = (double*)(tid + n_keep);
-        ev[0] = event;
-        // all max_tracks slots in descending fraction order (equal fractions: descending slot); unused slots: fraction 0, id -1
-        const double* f = in->hit_frac + in->row_frac0[i] + (int64_t)(h - h0) * nt;
-        for (int k = 0; k < MT; k++) { ent[k].f = k < nt ? f[k] : 0.0; ent[k].slot = k; }
-        std::sort(ent.begin(), ent.begin() + MT, [](const Ent& a, const Ent& b) { return a.f > b.f || (a.f == b.f && a.slot > b.slot); });
-        const int w = n_keep < MT ? n_keep : MT;
-        for (int k = 0; k < w; k++) {
-          seg[k] = ent[k].slot < nt ? in->trk_segment[t0 + ent[k].slot] : -1;
-          fr[k] = ent[k].f;
-        }
-        // trajectories: ids ascending, each with the sum of its slots' fractions taken in fraction order (left to right), stored f4
-        int ntr = 0;
-        for (int k = 0; k < MT; k++) {
-          if (ent[k].slot >= nt) continue;
-          const int64_t id = in->trk_traj[t0 + ent[k].slot];
-          if (id > -1) { tent[ntr].id = id; tent[ntr].f = ent[k].f; tent[ntr].pos = ntr; ntr++; }
-        }
-        std::sort(tent.begin(), tent.begin() + ntr, [](const TEnt& a, const TEnt& b) { return a.id < b.id || (a.id == b.id && a.pos < b.pos); });
-        int ng = 0;
-        for (int k = 0; k < ntr && ng < n_keep;) {
-          double sum = tent[k].f;
-          int e = k + 1;
-          while (e < ntr && tent[e].id == tent[k].id) { sum += tent[e].f; e++; }
-          tid[ng] = (int64_t)(int32_t)tent[k].id;            // (the reference's id array is int32)
-          tfr[ng] = (double)(float)sum;
-          ng++;
-          k = e;
-        }
+        todo.push_back({n_out, i, h});         // the association row: second pass, on host threads
       }
       n_out++;
     }
+  }
+  {
+    // ---- association rows (fee.py:284-344): independent per data packet, on the parked host threads (hostpool.h) ------------------
+    const int n_parts = HostPool::parts_for(todo.size(), 1024);
+    HostPool::run(n_parts, [&](int t) {
+      std::vector<Ent> ent((size_t)MT);
+      std::vector<TEnt> tent((size_t)MT);
+      const size_t lo = todo.size() * (size_t)t / n_parts, hi = todo.size() * (size_t)(t + 1) / n_parts;
+      for (size_t q = lo; q < hi; q++) fill_assn(in, todo[q].i, todo[q].h, as + (size_t)todo[q].out * assn_bytes, ent.data(), tent.data());
+    });
   }
   return n_out;
 full:

@@ -56,7 +56,7 @@ class LdsimChainStats(C.Structure):
                 ("n_dfma_useful", C.c_int64)]
 
 
-ABI_VERSION = 7      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
+ABI_VERSION = 8      # include/ldsim.h LDSIM_ABI_VERSION: the struct layouts of this file
 
 
 def pack_consts(noise_zero=False):

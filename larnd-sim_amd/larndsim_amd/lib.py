@@ -42,7 +42,7 @@ EXPORTS = [
     "ldsim_dev_light_response", "ldsim_dev_light_response_download", "ldsim_light_response_ms",
     "ldsim_comm_unique_id", "ldsim_comm_init", "ldsim_comm_destroy", "ldsim_comm_count", "ldsim_comm_allreduce_f64", "ldsim_hits_accumulate",
     "ldsim_comm_allgather_hits", "ldsim_comm_gathered_download",
-    "ldsim_packets_build", "ldsim_packets_row_bytes", "ldsim_packets_assn_row_bytes",
+    "ldsim_packets_build", "ldsim_packets_row_bytes", "ldsim_packets_assn_row_bytes", "ldsim_crc32_parts",
 ]
 
 
@@ -56,6 +56,8 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.ldsim_last_error.restype = C.c_char_p
         _lib.ldsim_packets_build.restype = C.c_int64
+        _lib.ldsim_crc32_parts.restype = C.c_uint32
+        _lib.ldsim_crc32_parts.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int64, C.c_int32]
         for name in EXPORTS:
             getattr(_lib, name)   # fail loudly on a missing symbol
         if int(_lib.ldsim_abi_version()) != ABI_VERSION:
@@ -220,3 +222,18 @@ def set_light(lut=None, ctx=None):
         nx, ny, nz, nd = lut.shape
         check(lib.ldsim_set_light_lut(ctx, ptr(vis), ptr(t0), ptr(t0a), ptr(td), C.c_int32(nx), C.c_int32(ny),
                                       C.c_int32(nz), C.c_int32(nd), C.c_int32(td.shape[-1])))
+
+
+def crc32_parts(parts, n_threads=0):
+    """zlib.crc32 of the concatenation of ``parts`` (bytes objects or C-contiguous numpy arrays) on the host threads of
+    ``ldsim_crc32_parts`` -- the checksum of an .npz member written piece by piece."""
+    import numpy as np
+    views = [np.frombuffer(p, dtype=np.uint8) if isinstance(p, (bytes, bytearray, memoryview)) else p for p in parts]
+    views = [v for v in views if v.nbytes]
+    for v in views:
+        if not v.flags["C_CONTIGUOUS"]:
+            raise ValueError("crc32_parts needs C-contiguous pieces")
+    n = len(views)
+    ptrs = (C.c_void_p * max(n, 1))(*[v.ctypes.data for v in views])
+    sizes = (C.c_uint64 * max(n, 1))(*[v.nbytes for v in views])
+    return int(load().ldsim_crc32_parts(ptrs, sizes, C.c_int64(n), C.c_int32(n_threads)))

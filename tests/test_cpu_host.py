@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/ldsim.h but not exported"
     assert set(lib.EXPORTS) == declared
-    assert l.ldsim_abi_version() == abi.ABI_VERSION == 7
+    assert l.ldsim_abi_version() == abi.ABI_VERSION == 8
 
 
 def test_graft_entry_build_succeeds():
@@ -402,6 +402,9 @@ def test_native_packet_builder_equals_build_packets(cfg, spill):
         inp = _random_packet_inputs(rng, 400, 12, spill)
         if trial >= 3:                       # the export starts with rows that hold no hit (the exporter's row 0 all the same)
             inp["adc_list"][:3] = 0
+        if trial >= 4:                       # negative and exactly-zero fractions in filled slots: the unused slots (0) sort between
+            inp["current_fractions"][:, :, 0] *= -1.0
+            inp["current_fractions"][:, :, 1] = 0.0
         kw = {}
         if trial % 2 == 0:
             kw = dict(light_trigger_times=rng.uniform(0, 5, 12), light_trigger_event_id=rng.integers(0, 12, 12),
@@ -696,3 +699,50 @@ def test_a_second_thread_cannot_claim_the_process_ctx_while_a_chain_lives():
     # the thread that claimed last has ended: its claim does not outlive it
     lib.claim_chain(Chain())
     lib._chain_owner = None
+
+
+def test_crc32_parts_equals_zlib():
+    """ldsim_crc32_parts (csrc/crc32.hip: slicing-by-8 per 4 MiB piece on host threads, pieces joined with the GF(2) zero-append
+    operator) against zlib.crc32 over ragged part lists, on 1, 3 and all threads."""
+    import zlib
+    from larndsim_amd import lib
+    rng = np.random.default_rng(11)
+    for sizes in ([], [0], [1], [7, 0, 9], [5, 4 << 20, (4 << 20) + 3, 123457], [(9 << 20) + 1]):
+        parts = [rng.integers(0, 256, s, dtype=np.uint8) for s in sizes]
+        ref = zlib.crc32(b"".join(p.tobytes() for p in parts))
+        for nt in (1, 3, 0):
+            assert lib.crc32_parts(parts, nt) == ref, (sizes, nt)
+    assert lib.crc32_parts([b"123456789"]) == 0xCBF43926          # the check value of CRC-32/ISO-HDLC
+
+
+@pytest.mark.parametrize("zip64_at", [None, 64])
+def test_npz_stream_reads_back_like_savez(tmp_path, monkeypatch, zip64_at):
+    """The driver's output writer (larndsim_amd/npz_stream.py): members written from ragged pieces read back through numpy.load
+    as the joined arrays, zipfile's own CRC check passes, and with the ZIP64 threshold lowered every ZIP64 record is exercised."""
+    import zipfile
+    from larndsim_amd import npz_stream
+    from larndsim_amd.packets import packets_dtype
+    if zip64_at is not None:
+        monkeypatch.setattr(npz_stream, "_ZIP64_AT", zip64_at)
+    rng = np.random.default_rng(0)
+    fn = str(tmp_path / "a.npz")
+    pk = [np.frombuffer(rng.bytes(36 * n), dtype=packets_dtype) for n in (5, 0, 17)]
+    al = np.zeros(7, dtype=np.dtype([("a", "u1"), ("b", "f8"), ("c", "i4", (3,))], align=True))
+    al["b"] = rng.random(7)
+    wv = [rng.random((3, 4, 5)), rng.random((0, 4, 5)), rng.random((2, 4, 5))]
+    with npz_stream.NpzStream(fn) as z:
+        z.write("packets", pk)
+        z.write("light_wvfm/light_wvfm_mod0", wv)
+        z.write("scalar", [np.float64(3.5)])
+        z.write("al", [al, al[:0], al[::2]])
+        z.write("empty", [np.zeros((0, 3), dtype="i2")])
+        with pytest.raises(ValueError, match="differ"):
+            z.write("bad", [np.zeros(3), np.zeros(3, dtype="f4")])
+    assert zipfile.ZipFile(fn).testzip() is None
+    with np.load(fn) as f:
+        assert f.files == ["packets", "light_wvfm/light_wvfm_mod0", "scalar", "al", "empty"]
+        assert np.array_equal(f["packets"], np.concatenate(pk)) and f["packets"].dtype == packets_dtype
+        assert np.array_equal(f["light_wvfm/light_wvfm_mod0"], np.concatenate(wv))
+        assert f["scalar"] == 3.5 and f["scalar"].shape == ()
+        assert np.array_equal(f["al"], np.concatenate([al, al[::2]])) and f["al"].dtype == al.dtype
+        assert f["empty"].shape == (0, 3) and f["empty"].dtype == np.dtype("i2")

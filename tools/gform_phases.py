@@ -30,6 +30,8 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
         "occ": ((0, 0, 0), (0, -1, 0), (0, -2, 0), (0, -3, 0), (0, 1, 0), (0, 2, 0), (0, 0, 0)),
         # in-kernel cycle stamps of gcorr_kernel's waves (debug_gform 128; printed to stderr by the library)
         "stamps": ((0, 0, 128), (0, 0, 0)),
+        # the same for gtables_wave_kernel (debug_gform 2048)
+        "tstamps": ((0, 0, 2048), (0, 0, 0)),
         # an odd tile pair shared by the pair's two waves (default) against dealt whole (debug_gform 256)
         # Z staged in LDS where it fits (default) against read from the record in the P step for every pair (debug_gform 1024), at
         # several LDS budgets of the first class (13 KB - pad)
