@@ -435,7 +435,7 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
     fprintf(stderr, "gcorr stamps (shader cycles, summed over waves): info %llu stage %llu G %llu P %llu edges %llu tail %llu life %llu\n",
             h_cnt[9], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
   if (ctx->debug_gform & 2048)      // the same stripes, written by gtables_wave_kernel's waves instead (kernels_gtables.hip)
-    fprintf(stderr, "gtables stamps (shader cycles, summed over waves): loads %llu maps_xy %llu maps_z %llu tables_xy %llu tables_z %llu cells %llu life %llu\n",
+    fprintf(stderr, "gtables stamps (shader cycles, summed over waves): loads %llu maps %llu batch_prologue %llu tables_xy %llu tables_z %llu cells %llu life %llu\n",
             h_cnt[9], h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
   ctx->stats.n_overflow = (int64_t)h_cnt[2];
   ctx->chain_hits = (int64_t)h_cnt[3];

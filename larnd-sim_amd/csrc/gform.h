@@ -19,6 +19,25 @@
 #define G_ZS (G_NUCAP + 16) // == 16 mod 32: the four 16-shift runs of an A operand read conflict-free
 #define G_CELLCAP 2048      // cells of a batch held in LDS as 16-bit (col, j) codes: every pair fits (40 columns x 48 rows)
 #define G_CELLPAD 16        // the cell list is padded to whole prefetch rounds of gcorr_kernel (4 cells x GPF groups; 32 until round 4: 11 % of the G products were padding)
+// The maps of a pair that the wave tables kernel takes (wave_ok != 0), written by pair_setup_kernel -- one THREAD per pair there, where
+// the same index arithmetic and a counting sort cost a twentieth of the ballots a whole wave spent on them (round 4: the maps were 30 %
+// of gtables_wave_kernel's cycle stamps).  G_MAPB bytes per pair, read back with one 8-byte load per lane:
+//   XPOS  [40]  position of x sample s in the member list ordered by (response column, s); 0xFF: outside the table
+//   YPOS  [40]  the same for the y samples, ordered by (row j, s)
+//   COLI  [40]  response column i of the pair's k-th distinct column     COLSTART [41]  first member of column k, then the count
+//   JSTART[49]  first member of row jmin + k, then the count
+//   ZSH   [64]  response shift of slice iz_lo + k, minus u_min           ZINV [64]  window edges the slice is invalid at (bits)
+//   AMB   [1]   slices whose shift was a rounding tie (statistics)
+#define G_MAP_NS 40
+#define G_MAPB 384
+#define G_MAP_XPOS 0
+#define G_MAP_YPOS 40
+#define G_MAP_COLI 80
+#define G_MAP_COLSTART 120
+#define G_MAP_JSTART 168
+#define G_MAP_ZSH 224
+#define G_MAP_ZINV 288
+#define G_MAP_AMB 352
 #define G_HDR 0             // header ints of a record (none: what gcorr_kernel needs first sits in GInfo, one load away)
 #define G_CELL0 4           // ints before the first cell entry of a batch (counts; four, so that every table starts 16-byte aligned)
 
@@ -68,6 +87,7 @@ struct GArgs {
   CurArgs c;
   const PairParams* pp;
   GInfo* gi;
+  const unsigned char* maps;    // [n_pairs][G_MAPB], pairs with wave_ok != 0
   double* rec;                   // record pool
   int32_t* flags;                // [n_pairs] 1 = the monolithic kernel recomputes this pair
   const double* resp_pad;        // response rows with RESP_PAD zeros either side, zeros outside the staged range

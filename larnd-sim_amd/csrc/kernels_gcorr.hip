@@ -550,7 +550,8 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   SplitArgs S{};
   S.c = a;
   GInfo* gi = (GInfo*)ctx->scratch[SB_HDR].p;
-  if ((rc = qpair_setup_launch(ctx, S, M, ctx->scratch[SB_PPAR].p, gi))) return rc;
+  if ((rc = ldsim_ensure(ctx, SB_GMAPS, (size_t)n * G_MAPB))) return rc;      // the wave tables kernel's maps (gform.h)
+  if ((rc = qpair_setup_launch(ctx, S, M, ctx->scratch[SB_PPAR].p, gi, ctx->scratch[SB_GMAPS].p))) return rc;
   unsigned long long* d_sz = (unsigned long long*)ctx->scratch[SB_CORR].p;
   unsigned long long* d_off = d_sz + n;
   unsigned long long* d_total = d_off + n;
@@ -623,6 +624,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   GA.c = a;
   GA.pp = (const PairParams*)ctx->scratch[SB_PPAR].p;
   GA.gi = gi;
+  GA.maps = (const unsigned char*)ctx->scratch[SB_GMAPS].p;
   GA.rec = (double*)ctx->scratch[SB_WBUF].p;
   GA.flags = (int32_t*)ctx->scratch[SB_ITEMS].p;
   GA.glx = ctx->d_glx;

@@ -399,25 +399,25 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 // it (wide diffusion or steep segments: a fifth of the ndlar pairs)
 
 template <int M, int XYS>
-__global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list) {
+__global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list) {
   const CurArgs& A = GA.c;
-  const LdsimConsts* c = A.c;
   constexpr int NUW = XYS <= 55 ? G_NUCAP : 2 * G_NUCAP;       // shifts of a pair this instantiation takes
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
   const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   if (pair >= A.n_pairs) return;
   const bool stamps = (GA.dbg & 2048) != 0;      // timing tools: cycle stamps into the statistics stripes 9..15 (chain.hip prints them)
-  unsigned long long ts0 = 0, ts_a = 0, ts_b = 0, ts_c = 0, ts_xy = 0, ts_z = 0, ts_cells = 0, ts_m = 0;
+  unsigned long long ts0 = 0, ts_a = 0, ts_c = 0, ts_xy = 0, ts_z = 0, ts_cells = 0, ts_m = 0;
   if (stamps) ts0 = __builtin_amdgcn_s_memtime();
   GInfo* __restrict__ gip = GA.gi + pair;
   // (everything the pair's two records hold is requested before the first branch: one round trip to memory instead of three)
   const GInfo gi0 = *gip;
   const PairParams* __restrict__ P = GA.pp + pair;
-  int p_i[8];
+  int p_i[4];
 #pragma unroll
-  for (int k = 0; k < 8; k++) p_i[k] = ((const int*)P)[k];
+  for (int k = 0; k < 4; k++) p_i[k] = ((const int*)P)[k];
   const double par_l = lane < PP_COUNT ? ((const double*)((const char*)P + 32))[lane] : 0.0;
   const double e2_l = g_exp2_64[lane];
+  const unsigned long long map_l = lane < G_MAPB / 8 ? ((const unsigned long long*)(GA.maps + pair * G_MAPB))[lane] : 0ull;
   const int status = (A.debug_phases & 0x100) ? 0 : gi0.status;
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
     if (lane == 0 && !list) {
@@ -429,99 +429,47 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   if (gi0.wave_ok != (XYS <= 55 ? 1 : 2) || (GA.dbg & 64)) return;      // the other instantiation's or gtables_kernel's pair
   const int ncol_g = gi0.ncol, NJ_g = gi0.NJ, u_min = gi0.u_min, NU = gi0.NU, ebound = gi0.edge_bound, NB = gi0.NB;
   double* __restrict__ rec = GA.rec + gi0.off;
-  // PairParams: status, NQ, iz_lo, iz_hi, it0, T, it_w0, it_w1
-  const int NQ = p_i[1], iz_lo = p_i[2], iz_hi = p_i[3], it0 = p_i[4], T = p_i[5], it_w0 = p_i[6], it_w1 = p_i[7];
+  // PairParams: status, NQ, iz_lo, iz_hi (, it0, T, it_w0, it_w1: in the edge flags of the maps already)
+  const int NQ = p_i[1], iz_lo = p_i[2], iz_hi = p_i[3];
   const int NUr = g_nur(NU);
+  // Gauss-Legendre nodes (lanes 0..15) and weights (16..31) of the first batch: one load per lane, in flight while the maps are
+  // unpacked.  [Until round 4 each of a lane's four nodes was a conditional load followed by its own wait: eight trips to L2 per batch.]
+  const double* gxw_tab = (lane < 16 ? GA.glx : GA.glw) + (int64_t)NQ * (NQ - 1) / 2;
+  double node_l = 0.0;
+  if (lane < 32 && u16 < min(G_NODES, NQ)) node_l = gxw_tab[u16];
 
   __shared__ double s_par[32], s_e2[64];
   __shared__ double s_dxs[NS_MAX], s_dys[NS_MAX], s_dzs[ZC];
   __shared__ double s_XY[G_NODES][XYS], s_zs[G_NODES];
   __shared__ unsigned char s_invs[ZC];
-  __shared__ short s_coli[NS_MAX], s_colstart[NS_MAX + 1], s_jstart[NJ_MAX + 2], s_ustart[NUW + 1];
+  __shared__ unsigned long long s_map64[G_MAPB / 8];
+  __shared__ double s_gxw[2 * G_NODES];      // the batch's node positions | weights on [-1, 1] (0 past the rule's last node)
+  __shared__ short s_ustart[NUW + 1];
+  // the maps pair_setup_kernel made (gform.h): sample -> position in its column's / row's member list, the lists' starts, the
+  // slices' shifts and edge flags.  [Until round 4 this wave derived them itself: two f64 divisions per sample and one ballot per
+  // distinct column, row and shift -- 30 % of its cycles.]
+  const unsigned char* s_mapb = (const unsigned char*)s_map64;
+  const unsigned char* s_coli = s_mapb + G_MAP_COLI;
+  const unsigned char* s_colstart = s_mapb + G_MAP_COLSTART;
+  const unsigned char* s_jstart = s_mapb + G_MAP_JSTART;
 
   if (lane < PP_COUNT) s_par[lane] = par_l;
   s_e2[lane] = e2_l;
+  if (lane < G_MAPB / 8) s_map64[lane] = map_l;
+  if (lane < 2 * G_NODES) s_gxw[lane] = node_l;
   wsync();
   if (stamps) ts_a = __builtin_amdgcn_s_memtime();
-  const int NS = c->sampled_points;
-  const double bin = c->response_bin_size;
-  const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};      // (edge_ks of the launch's constants, from the host)
-  const int k_stage_lo = GA.k_stage_lo, k_stage_hi = GA.k_stage_hi;
+  const unsigned long long ts_ld = ts_a - ts0;
   bool bad = false;          // (wave-uniform) inconsistent with the set-up pass: monolithic kernel
-
-  // ---- sample -> response cell maps, member lists ordered by response index ----------------------------------------------------------
-  int ncol, jmin, NJ;
-  {
-    int i = -1;
-    double ddx = 0;
-    if (lane < NS) {
-      double x = s_par[PP_X_START] + s_par[PP_SGNX] * (lane * s_par[PP_X_STEP] - 4 * s_par[PP_ST]);
-      double xd = fabs(s_par[PP_X_P] - x);
-      if (!(xd > bin * A.ni)) {
-        i = (int)py_round(xd / bin - 0.5);
-        if (i < 0 || i >= A.ni) i = -1;
-      }
-      ddx = x - s_par[PP_SX];
-    }
-    const bool valid = lane < NS && i >= 0;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    unsigned long long present = 0;
-    {
-      const int mlo = wave_lane_i32(wave_scan_i32(valid && i < 32 ? (1 << i) : 0, 0, [](int a, int b) { return a | b; }), 63);
-      const int mhi = wave_lane_i32(wave_scan_i32(valid && i >= 32 ? (1 << (i - 32)) : 0, 0, [](int a, int b) { return a | b; }), 63);
-      present = (unsigned long long)(unsigned)mlo | ((unsigned long long)(unsigned)mhi << 32);
-    }
-    const int slot = valid ? __popcll(present & ((1ull << i) - 1ull)) : 0;    // rank of this column's i among the distinct i
-    ncol = __popcll(present);
-    int posn = 0;
-    bool is_leader = false;
-    for (unsigned long long m = present; m; m &= m - 1) {
-      const int bcell = __ffsll((long long)m) - 1;
-      const unsigned long long bal = __ballot(valid && i == bcell);
-      if (valid && i > bcell) posn += __popcll(bal);
-      if (valid && i == bcell) {
-        const int before = __popcll(bal & lane_lt);
-        posn += before;
-        is_leader = before == 0;
-      }
-    }
-    if (is_leader) s_coli[slot] = (short)i;
-    if (valid) s_dxs[posn] = ddx;
-    if (is_leader) s_colstart[slot] = (short)posn;
-    const int nvalid = __popcll(__ballot(valid));
-    if (lane == 0) s_colstart[ncol] = (short)nvalid;
+  const int ncol = ncol_g, NJ = NJ_g, jmin = gi0.jmin;
+  if (lane < G_MAP_NS) {      // (samples past SAMPLED_POINTS carry 0xFF like the ones outside the table)
+    const double x = s_par[PP_X_START] + s_par[PP_SGNX] * (lane * s_par[PP_X_STEP] - 4 * s_par[PP_ST]);
+    const double y = s_par[PP_Y_START] + s_par[PP_SGNY] * (lane * s_par[PP_Y_STEP] - 4 * s_par[PP_ST]);
+    const int px = s_mapb[G_MAP_XPOS + lane], py = s_mapb[G_MAP_YPOS + lane];
+    if (px != 0xFF) s_dxs[px] = x - s_par[PP_SX];
+    if (py != 0xFF) s_dys[py] = y - s_par[PP_SY];
   }
-  {
-    int j = -1;
-    double ddy = 0;
-    if (lane < NS) {
-      double y = s_par[PP_Y_START] + s_par[PP_SGNY] * (lane * s_par[PP_Y_STEP] - 4 * s_par[PP_ST]);
-      double yd = fabs(s_par[PP_Y_P] - y);
-      if (!(yd > bin * A.nj)) {
-        j = (int)py_round(yd / bin - 0.5);
-        if (j < 0 || j >= A.nj) j = -1;
-      }
-      ddy = y - s_par[PP_SY];
-    }
-    jmin = wave_min_i32((j >= 0) ? j : (1 << 20));
-    const int jmax = wave_max_i32(j);
-    NJ = jmax - jmin + 1;
-    int posn = 0, below = 0;
-    if (jmax >= jmin) {
-      const unsigned long long lane_lt = (1ull << lane) - 1ull;
-      for (int bj = jmin; bj <= jmax; bj++) {               // the few distinct j, one ballot each
-        const unsigned long long bal = __ballot(j == bj);
-        const int cnt = __popcll(bal);
-        if (j > bj) posn += cnt;
-        if (j == bj) posn += __popcll(bal & lane_lt);
-        if (bj < jmin + lane) below += cnt;
-      }
-    }
-    if (j >= 0) s_dys[posn] = ddy;
-    if (jmax >= jmin && lane <= NJ && lane <= NJ_MAX) s_jstart[lane] = (short)below;   // nj <= NJ_MAX < 64
-  }
-  if (ncol != ncol_g || NJ != NJ_g || jmin != gi0.jmin || ncol + NJ > XYS - 1) bad = true;
-  if (stamps) ts_b = __builtin_amdgcn_s_memtime();
+  if (ncol + NJ > XYS - 1) bad = true;
 
   // ---- the slices (one chunk): response shift, edge flags, member list ordered by shift --------------------------------------------------
   int NUc, anyinv = 0;
@@ -530,26 +478,12 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     int sh = 0, inval = 0;
     double dzv = 0;
     if (lane < nmax) {
-      double z, t0;
-      bool amb;
-      sh = slice_shift_of<M>(c, s_par[PP_Z_START_INT], s_par[PP_Z_STEP], s_par[PP_Z_ANODE], s_par[PP_T_START], iz_lo + lane, z, t0,
-                             amb);
-      if (amb) stat_add(A.counters, 0, 1ull);
+      sh = u_min + (int)s_mapb[G_MAP_ZSH + lane];
+      inval = s_mapb[G_MAP_ZINV + lane];
+      const double z = s_par[PP_Z_START_INT] + (iz_lo + lane) * s_par[PP_Z_STEP];
       dzv = z - s_par[PP_SZ];
-#pragma unroll
-      for (int e = 0; e < NEDGE; e++) {
-        bool need = false;      // (as gtables_kernel's chunk set-up)
-        const int num = edge_k[e] - sh;
-        if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
-          const int it_e = num / M;
-          if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
-            int64_t kk;
-            need = !(slice_valid_at(c, s_par[PP_T_START], t0, it_e, kk) && kk == edge_k[e]);
-          }
-        }
-        if (need) inval |= 1 << e;
-      }
     }
+    if (lane == 0 && s_mapb[G_MAP_AMB]) stat_add(A.counters, 0, (unsigned long long)s_mapb[G_MAP_AMB]);
     const int lo = wave_min_i32(lane < nmax ? sh : (1 << 30)), hi = wave_max_i32(lane < nmax ? sh : -(1 << 30));
     NUc = hi - lo + 1;
     if (nmax != iz_hi - iz_lo + 1 || NUc > NUW || NUc != NU || lo != u_min) bad = true;
@@ -623,8 +557,6 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   if (stamps) ts_c = __builtin_amdgcn_s_memtime();
   if (A.debug_phases & 0x1000000) return;      // timing tools: stop after the maps
 
-  const double* gx_tab = GA.glx + (int64_t)NQ * (NQ - 1) / 2;
-  const double* gw_tab = GA.glw + (int64_t)NQ * (NQ - 1) / 2;
   const bool do_prune = A.prune_log > 0;
   // (wave-uniform values read from LDS land in vector registers: moved to scalar ones, 20 VGPRs less)
   auto uni = [](double v) {
@@ -640,6 +572,8 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
   const unsigned nj_inv = (1u << 20) / (unsigned)NJ + 1u;      // cc / NJ = cc * nj_inv >> 20 for cc < 2048, NJ <= 48
 
   for (int b = 0; b < NB; b++) {
+    unsigned long long ts_pro = 0;
+    if (stamps) ts_pro = __builtin_amdgcn_s_memtime();
     const int n0 = b * G_NODES, nb = min(G_NODES, NQ - n0);
     double* brec = rec + G_HDR / 2 + (unsigned long long)b * batch_d;
     int32_t* cells = (int32_t*)brec;                         // [0] count, [2..] entries (entry e at cells[G_CELL0 + e])
@@ -648,16 +582,20 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     double* gY = gX + rows * ncol;
     double* gZ = gY + rows * NJ;
     // this lane's four nodes: position along the segment and weight (a node past the batch's last one: rows of zeros)
+    if (b > 0) {           // (batch 0's were requested before the maps)
+      wsync();
+      if (lane < 2 * G_NODES) s_gxw[lane] = u16 < nb ? gxw_tab[n0 + u16] : 0.0;
+      wsync();
+    }
     double sn[4], wn[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
       const int n = 4 * m + q;
-      const bool on = n < nb;
-      const double gx = on ? gx_tab[n0 + n] : 0.0, gw = on ? gw_tab[n0 + n] : 0.0;
+      const double gx = s_gxw[n], gw = s_gxw[G_NODES + n];
       sn[m] = s_lo + 0.5 * qlen * (1.0 + gx);
       double w = wscale * gw;
-      if (kappa != 0.0) w *= exp_neg(-sn[m] * sn[m] * kappa);
-      wn[m] = on ? w : 0.0;
+      if (kappa != 0.0) w *= exp_neg_tab(-sn[m] * sn[m] * kappa, s_e2);
+      wn[m] = n < nb ? w : 0.0;
     }
     wsync();          // the previous batch's tables are no longer read
     // The two table phases, compiled for MC = 1 .. 4 node groups (a batch's last nodes fill fewer than four: 59 % of the survey
@@ -666,7 +604,7 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     auto tables = [&](auto mc_tag) {
       constexpr int MC = decltype(mc_tag)::value;
       // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
-      if (stamps) ts_m = __builtin_amdgcn_s_memtime();
+      if (stamps) { ts_m = __builtin_amdgcn_s_memtime(); ts_a += ts_m - ts_pro; }
       for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
         const int bi = b0 + u16;
         const bool act = bi < nbins, isx = bi < ncol;
@@ -681,16 +619,22 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         double cen[4], sum[4] = {0, 0, 0, 0};
   #pragma unroll
         for (int m = 0; m < 4; m++) cen[m] = sn[m] * ur;
+        double dd_next = k < ke ? src[k] : 0.0;          // (the next member's offset is read while this one's Gaussians run)
         for (; __ballot(k < ke); k++) {
-          if (k < ke) {
-            const double dd = src[k];
+          const double dd = dd_next;
+          const bool on = k < ke;
+          dd_next = k + 1 < ke ? src[k + 1] : 0.0;
+          if (on) {
+            double xg[4], g[4];
   #pragma unroll
             for (int m = 0; m < 4; m++) {
-              if (m < MC) {
-                const double d = dd - cen[m];
-                sum[m] += exp_neg_tab(-d * d * i2T, s_e2);
-              }
+              const double d = dd - cen[m];
+              xg[m] = -d * d * i2T;
             }
+            exp_neg_tab_n<MC>(xg, g, s_e2);
+  #pragma unroll
+            for (int m = 0; m < 4; m++)
+              if (m < MC) sum[m] += g[m];
           }
         }
         if (act) {
@@ -722,19 +666,47 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
           int k = 0, ke = 0;
           if (ub < NUc) { k = s_ustart[ub]; ke = s_ustart[ub + 1]; }
           double z[4] = {0, 0, 0, 0}, zi[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-          for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
-            if (k < ke) {
-              const double dd = s_dzs[k];
-              const int inv = s_invs[k];
-              const bool i0 = (inv >> e0) & 1, i1 = e1 >= 0 && ((inv >> e1) & 1);
+          double dd_next = k < ke ? s_dzs[k] : 0.0;
+          if (!emask) {                  // (most pairs: no slice is invalid at a window edge, no edge tables)
+            for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+              const double dd = dd_next;
+              const bool on = k < ke;
+              dd_next = k + 1 < ke ? s_dzs[k + 1] : 0.0;
+              if (on) {
+                double xg[4], g[4];
   #pragma unroll
-              for (int m = 0; m < 4; m++) {
-                if (m < MC) {
+                for (int m = 0; m < 4; m++) {
                   const double d = dd - cen[m];
-                  const double g = exp_neg_tab(-d * d * i2L, s_e2);
-                  z[m] += g;
-                  zi[0][m] += i0 ? g : 0.0;
-                  zi[1][m] += i1 ? g : 0.0;
+                  xg[m] = -d * d * i2L;
+                }
+                exp_neg_tab_n<MC>(xg, g, s_e2);
+  #pragma unroll
+                for (int m = 0; m < 4; m++)
+                  if (m < MC) z[m] += g[m];
+              }
+            }
+          } else {
+            for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+              const double dd = dd_next;
+              const bool on = k < ke;
+              dd_next = k + 1 < ke ? s_dzs[k + 1] : 0.0;
+              if (on) {
+                const int inv = s_invs[k];
+                const bool i0 = (inv >> e0) & 1, i1 = e1 >= 0 && ((inv >> e1) & 1);
+                double xg[4], g[4];
+  #pragma unroll
+                for (int m = 0; m < 4; m++) {
+                  const double d = dd - cen[m];
+                  xg[m] = -d * d * i2L;
+                }
+                exp_neg_tab_n<MC>(xg, g, s_e2);
+  #pragma unroll
+                for (int m = 0; m < 4; m++) {
+                  if (m < MC) {
+                    z[m] += g[m];
+                    zi[0][m] += i0 ? g[m] : 0.0;
+                    zi[1][m] += i1 ? g[m] : 0.0;
+                  }
                 }
               }
             }
@@ -810,8 +782,18 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
         int col = 0, jj = 0;
         if (cc < ncand) {
           col = (int)(((unsigned)cc * nj_inv) >> 20); jj = cc - col * NJ;
+          // (rows past nb are zero: four nodes at a time, their twelve LDS reads in flight together -- one round trip per
+          // group instead of one per node; the sum takes the nodes in the same order)
           double w = 0;
-          for (int n = 0; n < nb; n++) w = fma(s_XY[n][col] * s_XY[n][ncol + jj], s_zs[n], w);      // (rows past nb are zero)
+          for (int n = 0; n < ((nb + 3) & ~3); n += 4) {
+            const double x0 = s_XY[n][col], x1 = s_XY[n + 1][col], x2 = s_XY[n + 2][col], x3 = s_XY[n + 3][col];
+            const double y0 = s_XY[n][ncol + jj], y1 = s_XY[n + 1][ncol + jj], y2 = s_XY[n + 2][ncol + jj], y3 = s_XY[n + 3][ncol + jj];
+            const double z0 = s_zs[n], z1 = s_zs[n + 1], z2 = s_zs[n + 2], z3 = s_zs[n + 3];
+            w = fma(x0 * y0, z0, w);
+            w = fma(x1 * y1, z1, w);
+            w = fma(x2 * y2, z2, w);
+            w = fma(x3 * y3, z3, w);
+          }
           keep = do_prune ? w > thr : w != 0.0;
         }
         const unsigned long long bal = __ballot(keep);
@@ -828,9 +810,9 @@ __global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(G
     if (stamps) ts_cells += __builtin_amdgcn_s_memtime() - ts_m;
   }
   if (stamps && lane == 0) {
-    stat_add(A.counters, 9, ts_a - ts0);
-    stat_add(A.counters, 10, ts_b - ts_a);
-    stat_add(A.counters, 11, ts_c - ts_b);
+    stat_add(A.counters, 9, ts_ld);
+    stat_add(A.counters, 10, ts_c - (ts0 + ts_ld));
+    stat_add(A.counters, 11, ts_a - (ts0 + ts_ld));
     stat_add(A.counters, 12, ts_xy);
     stat_add(A.counters, 13, ts_z);
     stat_add(A.counters, 14, ts_cells);

@@ -11,7 +11,11 @@
 // =============================================================================================================
 template <int M>
 __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams* __restrict__ pp, int qn_max, double qn0,
-                                                         double qslope, GInfo* __restrict__ gi) {
+                                                         double qslope, GInfo* __restrict__ gi, unsigned char* __restrict__ maps) {
+  // per thread: response column / row of every sample, and the counters of the counting sorts ([k][thread]: a wave's 64 bytes of
+  // one k are contiguous)
+  __shared__ unsigned char s_si[G_MAP_NS][256], s_sj[G_MAP_NS][256], s_cnt[64][256];
+  const int tx = threadIdx.x;
   const CurArgs& A = S.c;
   const LdsimConsts* c = A.c;
   const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -37,16 +41,18 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   for (int s = 0; s < NS; s++) {
     const double x = g.x_start + g.sgnx * (s * g.x_step - 4 * g.sT);
     const double xd = fabs(g.x_p - x);
+    int i_s = 0xFF, j_s = 0xFF;
     if (!(xd > bin * A.ni)) {
       const int i = (int)py_round(xd / bin - 0.5);
-      if (i >= 0 && i < A.ni) { xlo = fmin(xlo, x - g.sx); xhi = fmax(xhi, x - g.sx); i_present |= 1ull << i; }
+      if (i >= 0 && i < A.ni) { xlo = fmin(xlo, x - g.sx); xhi = fmax(xhi, x - g.sx); i_present |= 1ull << i; i_s = i; }
     }
     const double y = g.y_start + g.sgny * (s * g.y_step - 4 * g.sT);
     const double yd = fabs(g.y_p - y);
     if (!(yd > bin * A.nj)) {
       const int j = (int)py_round(yd / bin - 0.5);
-      if (j >= 0 && j < A.nj) { ylo = fmin(ylo, y - g.sy); yhi = fmax(yhi, y - g.sy); j_lo = min(j_lo, j); j_hi = max(j_hi, j); }
+      if (j >= 0 && j < A.nj) { ylo = fmin(ylo, y - g.sy); yhi = fmax(yhi, y - g.sy); j_lo = min(j_lo, j); j_hi = max(j_hi, j); j_s = j; }
     }
+    if (maps && s < G_MAP_NS) { s_si[s][tx] = (unsigned char)i_s; s_sj[s][tx] = (unsigned char)j_s; }
   }
   if (xhi < xlo || yhi < ylo) { pp[pair] = P; return; }
   int edge_k[NEDGE], k_stage_lo, k_stage_hi;
@@ -145,6 +151,7 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
     if (Gi.NU <= G_NUCAP && Gi.ncol + Gi.NJ <= 54) Gi.wave_ok = 1;
     else if (Gi.NU <= 2 * G_NUCAP && Gi.ncol + Gi.NJ <= 80) Gi.wave_ok = 2;
   }
+  if (!maps || NS > G_MAP_NS) Gi.wave_ok = 0;      // (the wave kernel works from the maps below)
   if (P.status == 1 && (Gi.ncol > G_NCOL || Gi.NJ > NJ_MAX || Gi.ncol * Gi.NJ > G_CELLCAP - G_CELLPAD)) {
     Gi.status = 2;
     pp[pair].status = 2;
@@ -152,20 +159,113 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
   if (Gi.status == 1) {
     // the window edges that need a table of their own: a slice's weight would be used at a tick where the reference does not
     // use it (the predicates of qweights_kernel's chunk set-up)
-    int eb = 0;
+    const bool wmap = Gi.wave_ok != 0;
+    unsigned long long* mrec = (unsigned long long*)(maps + (wmap ? pair : 0) * G_MAPB);
+    int eb = 0, n_amb = 0;
+    unsigned long long w_sh = 0, w_inv = 0;
     for (int iz = iz_lo; iz <= iz_hi; iz++) {
       double z, t0;
       bool amb;
       const int sh = slice_shift_of<M>(c, g.z_start_int, g.z_step, g.z_anode, g.t_start, iz, z, t0, amb);
+      n_amb += amb;
+      int inval = 0;
       for (int e = 0; e < NEDGE; e++) {
         const int num = edge_k[e] - sh;
         if (edge_k[e] >= k_stage_lo && edge_k[e] <= k_stage_hi && num >= 0 && (num % M) == 0) {
           const int it_e = num / M;
           if (it_e >= max(it0, it_w0) && it_e < min(T, it_w1)) {
             int64_t kk;
-            if (!(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e])) eb |= 1 << e;
+            if (!(slice_valid_at(c, g.t_start, t0, it_e, kk) && kk == edge_k[e])) inval |= 1 << e;
           }
         }
+      }
+      eb |= inval;
+      if (wmap) {          // (<= ZC = 64 slices, <= 256 shifts)
+        const int k = iz - iz_lo;
+        w_sh |= (unsigned long long)(unsigned)(sh - sh_min) << (8 * (k & 7));
+        w_inv |= (unsigned long long)(unsigned)inval << (8 * (k & 7));
+        if ((k & 7) == 7 || iz == iz_hi) {
+          mrec[G_MAP_ZSH / 8 + (k >> 3)] = w_sh;
+          mrec[G_MAP_ZINV / 8 + (k >> 3)] = w_inv;
+          w_sh = w_inv = 0;
+        }
+      }
+    }
+    if (wmap) {
+      mrec[G_MAP_AMB / 8] = (unsigned long long)n_amb;
+      // ---- x samples ordered by (column, s): counting sort over the columns that are present ------------------------------------------
+      for (unsigned long long m = i_present; m; m &= m - 1) s_cnt[__ffsll((long long)m) - 1][tx] = 0;
+      for (int s = 0; s < NS; s++) {
+        const int i = s_si[s][tx];
+        if (i != 0xFF) s_cnt[i][tx]++;
+      }
+      {
+        unsigned long long wc = 0, ws = 0;
+        int slot = 0, running = 0;
+        for (unsigned long long m = i_present; m; m &= m - 1) {
+          const int col = __ffsll((long long)m) - 1, cn = s_cnt[col][tx];
+          s_cnt[col][tx] = (unsigned char)running;
+          wc |= (unsigned long long)(unsigned)col << (8 * (slot & 7));
+          ws |= (unsigned long long)(unsigned)running << (8 * (slot & 7));
+          running += cn;
+          slot++;
+          if ((slot & 7) == 0) {
+            mrec[G_MAP_COLI / 8 + (slot >> 3) - 1] = wc;
+            mrec[G_MAP_COLSTART / 8 + (slot >> 3) - 1] = ws;
+            wc = ws = 0;
+          }
+        }
+        ws |= (unsigned long long)(unsigned)running << (8 * (slot & 7));      // the count, behind the last column's start
+        if (slot & 7) mrec[G_MAP_COLI / 8 + (slot >> 3)] = wc;
+        mrec[G_MAP_COLSTART / 8 + (slot >> 3)] = ws;
+      }
+      for (int s8 = 0; s8 < G_MAP_NS; s8 += 8) {
+        unsigned long long w = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int s = s8 + k;
+          int pos = 0xFF;
+          if (s < NS) {
+            const int i = s_si[s][tx];
+            if (i != 0xFF) { pos = s_cnt[i][tx]; s_cnt[i][tx] = (unsigned char)(pos + 1); }
+          }
+          w |= (unsigned long long)(unsigned)pos << (8 * k);
+        }
+        mrec[G_MAP_XPOS / 8 + (s8 >> 3)] = w;
+      }
+      // ---- y samples ordered by (row, s); JSTART[k] = samples in rows below jmin + k -----------------------------------------------------------
+      const int NJ = Gi.NJ;
+      for (int k = 0; k < NJ; k++) s_cnt[k][tx] = 0;
+      for (int s = 0; s < NS; s++) {
+        const int j = s_sj[s][tx];
+        if (j != 0xFF) s_cnt[j - j_lo][tx]++;
+      }
+      {
+        unsigned long long ws = 0;
+        int running = 0;
+        for (int k = 0; k <= NJ; k++) {           // (NJ <= NJ_MAX = 48: entries 0 .. 48)
+          ws |= (unsigned long long)(unsigned)running << (8 * (k & 7));
+          if (k < NJ) {
+            const int cn = s_cnt[k][tx];
+            s_cnt[k][tx] = (unsigned char)running;
+            running += cn;
+          }
+          if ((k & 7) == 7 || k == NJ) { mrec[G_MAP_JSTART / 8 + (k >> 3)] = ws; ws = 0; }
+        }
+      }
+      for (int s8 = 0; s8 < G_MAP_NS; s8 += 8) {
+        unsigned long long w = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int s = s8 + k;
+          int pos = 0xFF;
+          if (s < NS) {
+            const int j = s_sj[s][tx];
+            if (j != 0xFF) { pos = s_cnt[j - j_lo][tx]; s_cnt[j - j_lo][tx] = (unsigned char)(pos + 1); }
+          }
+          w |= (unsigned long long)(unsigned)pos << (8 * k);
+        }
+        mrec[G_MAP_YPOS / 8 + (s8 >> 3)] = w;
       }
     }
     Gi.edge_bound = eb;
@@ -177,7 +277,7 @@ __global__ void __launch_bounds__(256) pair_setup_kernel(SplitArgs S, PairParams
 extern "C++" size_t qpair_params_bytes(int64_t n_pairs) { return (size_t)n_pairs * sizeof(PairParams); }
 
 // the per-pair records of both quadrature weight kernels
-extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params, void* ginfo) {
+extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params, void* ginfo, void* maps) {
   if (S.c.n_pairs == 0) return 0;
   if (!ctx->d_glx || !ctx->d_glw || !params) {
     ldsim_set_error("Gauss-Legendre tables / pair parameter buffer missing");
@@ -187,9 +287,9 @@ extern "C++" int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, v
   const unsigned g0 = (unsigned)((S.c.n_pairs + 255) / 256);
   GInfo* gi = (GInfo*)ginfo;
   if (M == 1) hipLaunchKernelGGL(pair_setup_kernel<1>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0,
-                                 ctx->quad_slope, gi);
+                                 ctx->quad_slope, gi, (unsigned char*)maps);
   else hipLaunchKernelGGL(pair_setup_kernel<2>, dim3(g0), dim3(256), 0, ctx->stream, S, pp, ctx->gl_nmax, ctx->quad_n0, ctx->quad_slope,
-                          gi);
+                          gi, (unsigned char*)maps);
   HIPCHK(hipGetLastError());
   return 0;
 }

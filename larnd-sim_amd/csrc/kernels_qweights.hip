@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) qweights_kernel(SplitArgs S, c
 
 extern "C++" int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params) {
   if (S.c.n_pairs == 0) return 0;
-  int rc = qpair_setup_launch(ctx, S, M, params, nullptr);
+  int rc = qpair_setup_launch(ctx, S, M, params, nullptr, nullptr);
   if (rc) return rc;
   const PairParams* pp = (const PairParams*)params;
   if (M == 1)

@@ -117,6 +117,6 @@ int split_launch_mac(ldsim_ctx* ctx, const CurArgs& args, void* items, void* hdr
                      unsigned long long wbuf_cap, unsigned long long* cursor);
 struct SplitArgs;
 int qweights_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params);
-int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params, void* ginfo);
+int qpair_setup_launch(ldsim_ctx* ctx, const SplitArgs& S, int M, void* params, void* ginfo, void* maps);
 size_t qpair_params_bytes(int64_t n_pairs);
 int split_sizes(const ldsim_ctx* ctx, const CurArgs& args, size_t* item_bytes, size_t* hdr_bytes, size_t* corr_bytes);

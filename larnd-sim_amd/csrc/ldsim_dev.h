@@ -236,7 +236,7 @@ struct ldsim_ctx {
 enum {
   SB_ACTIVE = 0, SB_NEIGH, SB_NRAD, SB_NLIST, SB_STARTS, SB_MISC, SB_KEYS, SB_KEYS2, SB_VALS, SB_VALS2,
   SB_SORTTMP, SB_PAIRSEG, SB_PAIRPIX, SB_HEADS, SB_UOFF, SB_UPIX, SB_UBATCH, SB_WAVES, SB_ADC, SB_TICKS,
-  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN, SB_SPAN
+  SB_DIGIT, SB_TPM, SB_FRAC, SB_HITS, SB_ITEMS, SB_HDR, SB_CORR, SB_WBUF, SB_NOISE, SB_NDRAWS, SB_PPAR, SB_CPT, SB_CPO, SB_WIN, SB_SPAN, SB_GMAPS
 };
 
 void ldsim_set_error(const char* fmt, ...);

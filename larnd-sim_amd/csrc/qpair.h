@@ -108,6 +108,38 @@ __device__ __forceinline__ double exp_neg_tab(double x, const double* __restrict
   return x < -708.0 ? 0.0 : v;
 }
 
+// MC of them side by side: the index parts first, so that the MC table reads are in flight together and the polynomials run under
+// them (one after the other, as the compiler schedules separate calls, a wave waited on LDS MC times per member).  No clamp at -708:
+// the argument is bounded below once (one v_max instead of a compare and four selects per value) and ldexp underflows to 0 by itself
+// -- values in (-745, -708) come out as subnormals instead of 0.
+template <int MC>
+__device__ __forceinline__ void exp_neg_tab_n(const double (&x)[4], double (&v)[4], const double* __restrict__ tab) {
+  double k[4], t[4], xc[4];
+  int ki[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    if (m < MC) {
+      xc[m] = fmax(x[m], -2000.0);
+      k[m] = rint(xc[m] * 0x1.71547652b82fep+6);
+      ki[m] = (int)k[m];
+      t[m] = tab[ki[m] & 63];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    if (m < MC) {
+      double r = fma(-k[m], 0x1.62e4200000000p-7, xc[m]);
+      r = fma(-k[m], 0x1.fdf473de6af28p-28, r);
+      double p = 1.0 / 24.0;
+      p = fma(p, r, 1.0 / 6.0);
+      p = fma(p, r, 0.5);
+      p = fma(p, r, 1.0);
+      p = fma(p, r, 1.0);
+      v[m] = ldexp(t[m] * p, ki[m] >> 6);
+    }
+  }
+}
+
 // response shift of slice iz (k - M * it for the tick in the middle of the slice's window), as weights_kernel / qweights_kernel
 template <int M>
 __device__ __forceinline__ int slice_shift_of(const LdsimConsts* c, double z_start_int, double z_step, double z_anode,
