@@ -139,8 +139,9 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * f64 matrix pipe, no weight pool ("mac_mode" does not apply); 1 = qweights_kernel, Gauss-Legendre quadrature along the
  * segment, then the correlation kernel of "mac_mode"; 0 = weights_kernel, the closed form per charge sample),
  * "gform_max_support" (weights_mode 2 runs the node-separable form for response tables whose staged support is at most this
- * many time ticks, default 768, and the kernels of weights_mode 1 for wider ones: the matrix form pays per response tick, the
- * shifted-window kernels per 512-tick tile; 0 = never, 1e9 = always), "gform_wave_tables" (weights_mode 2, tables stage: 1 =
+ * many time ticks and the kernels of weights_mode 1 for wider ones: the matrix form pays per response tick, the shifted-window
+ * kernels per 512-tick tile; 0 = never, 1e9 = always = the default since round 4 -- 768 before, when full-support tables were
+ * faster in the shifted-window kernels), "gform_wave_tables" (weights_mode 2, tables stage: 1 =
  * gtables_wave_kernel, one wave per pair, for the pairs that fit it and gtables_kernel, one workgroup per pair, for the rest
  * (default); 0 = gtables_kernel for all: same tables entry for entry), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),
@@ -214,8 +215,8 @@ int ldsim_time_intervals(ldsim_ctx* ctx, const void* tracks, int64_t n, const Ld
  * Runs the kernels the options select, exactly like ldsim_charge_chain does for its sorted pair list ("split_kernels",
  * "weights_mode", "mac_mode", "gform_max_support").  Default: the node-separable form (weights_mode 2) -- pair_setup_kernel,
  * gtables_wave_kernel (Gauss-Legendre tables X, Y, Z per pair) and gcorr_kernel (the two products on v_mfma_f64_16x16x4) -- for
- * response tables whose staged support is at most gform_max_support (768) ticks; wider tables are handed to round 2's
- * qweights_kernel + mac_shift kernels (weights_mode 1); pairs beyond a kernel's capacities (rules of more than quad_max_nodes
+ * response tables of any support (gform_max_support ticks at most, default unlimited; wider tables would be handed to round 2's
+ * qweights_kernel + mac_shift kernels, weights_mode 1); pairs beyond a kernel's capacities (rules of more than quad_max_nodes
  * nodes ...) are recomputed by the monolithic closed-form kernel.  Response ticks below exp(-trim_response_log) (default 23:
  * 1e-10) of the table's largest entry are not read: an approximation relative to the reference of < 1e-10 of a waveform's peak
  * that the headline throughput on the SURVEY table relies on (bench.py reports `exact_zero_trim` beside it).  All on the dense

@@ -66,11 +66,12 @@ static int run_tracks_current(ldsim_ctx* ctx, CurArgs& a, int64_t n_seg, unsigne
   a.win = nullptr;
   if (win_used) *win_used = false;
   if (ctx->mc_current) return current_mc_launch(ctx, a, n_seg);   // the driver's call site (cli/simulate_pixels.py:1016)
-  // The node-separable form pays per response tick of the staged support (16 nodes x cells x ticks on the matrix pipe), the
-  // shifted-window kernels per 512-tick tile: a table whose support is a few hundred ticks (the survey table) is 2x faster in
-  // the former, one with full support (no exact zeros over ~2000 ticks) 20 % faster in the latter -- measured, DESIGN.md
-  // section 4.  "gform_max_support" (ticks of TIME_SAMPLING) is where the default hands over; weights_mode 1 / 0 force the
-  // shifted-window path, a huge gform_max_support forces the matrix form.
+  // The node-separable form pays per response tick of the staged support (nodes x cells x ticks on the matrix pipe), the
+  // shifted-window kernels per 512-tick tile and (weight, tick) pair.  Until round 4 a table with full support (no exact zeros
+  // over ~2000 ticks) was 20 % faster in the latter and "gform_max_support" = 768 ticks handed it over; with the 1e-7 node rule
+  // (one batch of <= 16 nodes for most pairs) the matrix form is ahead there too -- module0 / 2x2 +18 %, ndlar +33 %
+  // (profiles/r04_dense_handover.log) -- and the default no longer hands over.  weights_mode 1 / 0 force the shifted-window path,
+  // a finite gform_max_support (ticks of TIME_SAMPLING) restores the hand-over.
   const int M_ratio = (int)llround(ctx->h_consts.time_sampling / ctx->h_consts.response_sampling);
   const int support_ticks = (a.k_last - a.k_first + 1) / (M_ratio > 0 ? M_ratio : 1);
   const bool use_gform = ctx->weights_mode == 2 && support_ticks <= ctx->gform_max_support;

@@ -157,7 +157,8 @@ struct ldsim_ctx {
   int wbuf_doubles_per_pair = 6144; // initial average budget of the split path's weight pool, doubles per pair
   int split_max_items = 0;          // validation knob, see CurArgs
   int weights_mode = 2;             // split path: 2 = node-separable form (gtables_kernel + gcorr_kernel, gform.h), 1 = qweights_kernel (Gauss-Legendre along the segment) + mac kernel, 0 = weights_kernel (per-sample closed form) + mac kernel
-  int gform_max_support = 768;      // staged response support (ticks) up to which weights_mode 2 runs the node-separable form; wider tables take the shifted-window kernels
+  int gform_max_support = 1000000000;   // staged response support (ticks) up to which weights_mode 2 runs the node-separable form (round 4: every table -- with the 1e-7 node rule
+                                        // the matrix form is ahead on full-support tables too, profiles/r04_dense_handover.log; 768 until then: wider tables took the shifted-window kernels)
   int mc_current = 0;               // 1: the chain's induced currents come from current_mc_kernel (tracks_current_mc) instead of tracks_current
   int numba_f32 = 0;                // 1: evaluate the sub-expressions Numba types f32 for f4 record fields in float
   double* d_glx = nullptr;          // Gauss-Legendre nodes / weights on [-1, 1] for every N <= gl_nmax, rule N at N(N-1)/2

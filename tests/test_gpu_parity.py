@@ -1776,7 +1776,7 @@ def _two_event_set(cfg, seed, n=1200):
 def _reset_current_options():
     for name, v in (("split_kernels", 1), ("weights_mode", 2), ("wbuf_doubles_per_pair", 6144), ("split_max_items", 0),
                     ("quad_max_nodes", 256), ("numba_f32", 0), ("tail_log", 14.0), ("prune_log", 23.0), ("mac_mode", 1),
-                    ("quad_accuracy_log10", 7), ("gform_max_support", 768), ("trim_response_log", 23.0),
+                    ("quad_accuracy_log10", 7), ("gform_max_support", 1e9), ("trim_response_log", 23.0),
                     ("gform_wave_tables", 1)):
         lib.set_option(name, v)
 
