@@ -517,15 +517,27 @@ __global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned* 
 // read and written once, coalesced.  One thread per cell walked its run alone with a global-memory slot search per record:
 // a busy tick of a busy detector (thousands of records) set the kernel's time.
 #define RW_BLOCK 256
+// Round 4, second form: 2.4e7 records per 2x2 batch make this kernel a matter of instructions per record (the walk is sequential by
+// the reference's definition: an f4 sum rounded after every addend, slots given out first come first served).  Record by record
+// through v_readlane it cost ~35 instructions each (1.65 ms per batch, 37 % of the 2x2 + light step).  Now a cell's records are
+// taken 64 at a time, one per lane: which slot a record's track holds is looked up by all lanes at once against the slots filled
+// so far (ids mirrored in LDS), tracks seen for the first time get the next slots in order of first appearance (one ballot round
+// per NEW track: at most max_truth per cell), and only the two chains that must be sequential stay in the per-record loop --
+// the f4 sum and "slot s += photons" on the lane that owns slot s -- fed from LDS broadcasts, 9 instructions per record.
+// A run with a track id of -1 above the threshold (an id that looks like an empty slot: it is overwritten by the next track)
+// or a sum that accumulates into the caller's arrays (fresh = 0: slots may be anything) is walked record by record as before.
 __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned* __restrict__ keys,
                                                                const unsigned long long* __restrict__ vals, int64_t n_rec,
                                                                int tick_bits, double tick_size,
                                                                const int64_t* __restrict__ track_id, int64_t n_ticks,
                                                                double truth_threshold, float* __restrict__ out,
                                                                int64_t* __restrict__ true_id, double* __restrict__ true_ph,
-                                                               int max_truth) {
+                                                               int max_truth, int fresh) {
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * RW_BLOCK, b1 = min(b0 + RW_BLOCK, n_rec);
+  __shared__ double s_pt[64];
+  __shared__ long long s_sid[64];
+  __shared__ unsigned char s_slot[64];
   auto rl64 = [](unsigned long long v, int l) {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, l);
@@ -535,6 +547,7 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned* _
   float acc = 0.f;
   int64_t slot_id = -1;              // lane k: truth slot k of the open cell
   double slot_ph = 0.0;
+  int n_filled = 0;                  // slots 0 .. n_filled - 1 hold a track (fresh sums: slots fill from the front)
   auto close_cell = [&]() {
     if (lane == 0) out[o] = acc;
     if (lane < max_truth) {
@@ -557,30 +570,97 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned* _
     }
     const int nv = (int)min((int64_t)64, n_rec - c0);
     bool done = false;
-    for (int t = 0; t < nv && !done; t++) {
-      const unsigned ct = (unsigned)__builtin_amdgcn_readlane((int)cell, t);
+    int ta = 0;
+    while (ta < nv && !done) {
+      // ---- the run [ta, tb) of records of one cell ----------------------------------------------------------------------------------------
+      const unsigned ct = (unsigned)__builtin_amdgcn_readlane((int)cell, ta);
+      const unsigned long long differ = __ballot(cell != ct) & ~((2ull << ta) - 1ull);      // lanes past ta of another cell
+      const int tb = differ ? __ffsll((long long)differ) - 1 : 64;         // (lanes >= nv carry the sentinel cell)
       const bool head = ct != prev_cell;
       prev_cell = ct;
       if (head) {
         if (open) { close_cell(); open = false; }
-        if (c0 + t >= b1) { done = true; break; }          // the next block's cell
+        if (c0 + ta >= b1) { done = true; break; }          // the next block's cell
         open = true;
+        // fresh (the resident sum, whose arrays the call initialises): the cell starts from 0 photons and empty slots, nothing is
+        // read back; otherwise (the host-array entry accumulates into what the caller passed, like the reference's +=) the rows are read
         o = (int64_t)(ct >> tick_bits) * n_ticks + (int64_t)(ct & ((1u << tick_bits) - 1));
-        acc = out[o];
-        slot_id = lane < max_truth ? true_id[o * max_truth + lane] : -2;
-        slot_ph = lane < max_truth ? true_ph[o * max_truth + lane] : 0.0;
+        acc = fresh ? 0.f : out[o];
+        slot_id = lane < max_truth ? (fresh ? -1 : true_id[o * max_truth + lane]) : -2;
+        slot_ph = lane < max_truth && !fresh ? true_ph[o * max_truth + lane] : 0.0;
+        n_filled = 0;
       }
-      if (!open) continue;                                   // the tail of a cell that began in an earlier block
-      const double pt = __longlong_as_double((long long)rl64((unsigned long long)__double_as_longlong(ph), t));
-      acc = (float)((double)acc + pt);
-      if (pt > truth_threshold) {
-        const int64_t it = (int64_t)rl64((unsigned long long)id, t);
-        const unsigned long long m = __ballot(lane < max_truth && (slot_id == -1 || slot_id == it));
-        if (m && lane == __ffsll((long long)m) - 1) {
-          slot_id = it;
-          slot_ph += pt;
+      if (!open) { ta = tb; continue; }                      // the tail of a cell that began in an earlier block
+      const bool in_run = lane >= ta && lane < tb;
+      const bool valid = in_run && ph > truth_threshold;
+      if (!fresh || __ballot(valid && id == -1)) {
+        // ---- record by record (light_sim.py:101-110,118-127 as written) ----------------------------------------------------------------------
+        for (int t = ta; t < tb; t++) {
+          const double pt = __longlong_as_double((long long)rl64((unsigned long long)__double_as_longlong(ph), t));
+          acc = (float)((double)acc + pt);
+          if (pt > truth_threshold) {
+            const int64_t it = (int64_t)rl64((unsigned long long)id, t);
+            const unsigned long long m = __ballot(lane < max_truth && (slot_id == -1 || slot_id == it));
+            if (m && lane == __ffsll((long long)m) - 1) {
+              slot_id = it;
+              slot_ph += pt;
+            }
+          }
+        }
+        n_filled = __popcll(__ballot(lane < max_truth && slot_id != -1));
+        s_sid[lane] = slot_id;
+        ta = tb;
+        continue;
+      }
+      // ---- slot of each record: the ones filled so far, then new tracks in order of first appearance ---------------------------------------
+      int slot = 0xFF;
+      for (int k = 0; k < n_filled; k++)
+        if (s_sid[k] == id) slot = k;
+      slot = valid ? slot : 0xFF;
+      unsigned long long fresh_ids = __ballot(valid && slot == 0xFF);
+      while (fresh_ids) {
+        const int t1 = __ffsll((long long)fresh_ids) - 1;
+        const int64_t idn = (int64_t)rl64((unsigned long long)id, t1);
+        const bool same = valid && slot == 0xFF && id == idn;
+        if (n_filled < max_truth) {
+          if (same) slot = n_filled;
+          if (lane == n_filled) slot_id = idn;
+          if (lane == 0) s_sid[n_filled] = idn;
+          n_filled++;
+          fresh_ids &= ~__ballot(same);
+        } else {
+          fresh_ids = 0;                      // every slot holds another track: these records leave no trace in the slots
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (in_run) {
+        s_pt[lane] = ph;
+        s_slot[lane] = (unsigned char)slot;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- the two sequential chains ---------------------------------------------------------------------------------------------------------
+      int t = ta;
+      for (; t + 8 <= tb; t += 8) {
+        double p[8];
+        int sl[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { p[u] = s_pt[t + u]; sl[u] = s_slot[t + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          acc = (float)((double)acc + p[u]);
+          slot_ph += sl[u] == lane ? p[u] : 0.0;
+        }
+      }
+      for (; t < tb; t++) {
+        const double p = s_pt[t];
+        acc = (float)((double)acc + p);
+        slot_ph += s_slot[t] == lane ? p : 0.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      ta = tb;
     }
     if (done) break;
   }
@@ -730,7 +810,8 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   const double tick_size = ctx->h_consts.light_tick_size;
   if (max_truth <= 64)
     hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_rec, RW_BLOCK)), dim3(64), 0, st, k1, v1, n_rec, tick_bits, tick_size,
-                       track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);
+                       track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth,
+                       n_rec_out != nullptr /* the resident sum: arrays initialised by the call */);
   else
     hipLaunchKernelGGL(light_replay_kernel, dim3(nblk(n_rec, 256)), dim3(256), 0, st, k1, v1, n_rec, tick_bits, tick_size, track_id,
                        n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth);

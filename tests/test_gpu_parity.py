@@ -1118,6 +1118,43 @@ def test_resident_light_leg_golden(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_tracks,with_none", [(3, False), (7, True), (40, True)])
+def test_resident_photon_sum_slot_walk_equals_the_record_walk(n_tracks, with_none):
+    """The resident photon sum gives out truth slots 64 records at a time (light_replay_wave_kernel: slot lookup by all lanes, new
+    tracks in order of first appearance, two sequential chains); the host-array stage call accumulates into the caller's arrays
+    and walks record by record as light_sim.py:101-127 is written.  Same arrays bit for bit when many segments share a track
+    (slots re-used), when there are more tracks than slots (records dropped), and with track id -1 among them (a slot holding -1
+    looks empty and is taken over by the next track, its photons staying)."""
+    cfg = "2x2_no_modvar" if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "light_2x2_no_modvar.npz")) else "module0"
+    H.load_cfg(cfg)
+    g = H.gold(f"light_{cfg}.npz")
+    r = np.concatenate([H.quench_drift(O, g["segments_in"])] * 6)      # (six segments on every spot: each cell meets several tracks)
+    n = len(r)
+    lut = synth.make_lut((14, 26, 8), 48, int(g["n_prof"]), int(g["lut_seed"]))
+    opc = g["op_channel"]
+    nt = int(g["n_ticks"])
+    rng = np.random.default_rng(100 + n_tracks)
+    ids = rng.integers(0, n_tracks, n).astype('i8') * 11 + 5
+    if with_none:
+        ids[rng.random(n) < 0.15] = -1
+    Mt = 2
+    consts.sim.MC_TRUTH_THRESHOLD = 1e-9          # (the golden set is small: every deposit counts for the slots)
+    ch = ChargeChain()
+    ch.upload(r, np.zeros(n, dtype=np.int32))
+    ch.light_incidence(lut)
+    inc, vox = ch.download_light_incidence()
+    n_ticks, t_start = ch.sum_light(0, n, opc, ids, max_truth=Mt, max_ticks=nt)
+    out, tid, tph = ch.download_light()
+    filled = (tid >= 0).sum(axis=-1)
+    assert out.sum() > 0 and filled.max() == Mt, np.bincount(filled.ravel())          # some cell's slots are all taken
+    # the resident sum's visiting order: descending photons per detector, ties by descending index
+    order = np.ascontiguousarray(np.stack([np.argsort(inc['n_photons_det'][:, c], kind="stable")[::-1] for c in opc]), dtype=np.int32)
+    out2 = np.zeros_like(out); tid2 = np.full_like(tid, -1); tph2 = np.zeros_like(tph)
+    light_sim.sum_light_signals[1, 64](r, vox, ids, inc, opc, lut, float(t_start), out2, tid2, tph2, order, int(g["n_prof"]))
+    assert np.array_equal(out2, out) and np.array_equal(tid2, tid) and np.array_equal(tph2, tph)
+
+
+@pytest.mark.gpu
 def test_resident_photon_sums_in_a_row_start_from_clean_arrays():
     """ldsim_dev_sum_light with truth slots does not clear its arrays when the same buffers served the sum before: it resets the
     cells that sum wrote.  Sums of different batches, tick counts and slot counts in a row on one context must equal the same sums
