@@ -440,6 +440,108 @@ __global__ void light_fill_ordered_kernel(LightSum L, const int32_t* __restrict_
   });
 }
 
+// ---- round 4, resident sum: only the (detector, segment) pairs that carry photons are ordered, and a wave emits a pair's records ----
+// A segment lights the detectors of its own TPC: 1 in 8 (2x2) to 1 in 70 (ndlar) of the n_det x n pairs hold photons.  The pairs
+// that do are compacted (any order: the sort that follows orders them, their keys are distinct) ...
+#define LIGHT_NONE 0xFFFFFFFFu        // key of an unused record slot: sorts behind every (detector, tick) cell (those use <= 31 bits)
+__global__ void __launch_bounds__(256) light_active_pairs_kernel(LightSum L, unsigned long long* __restrict__ keys,
+                                                                int32_t* __restrict__ vals, unsigned* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool on = false;
+  unsigned long long key = 0;
+  if (p < (int64_t)L.n_det * L.n) {
+    const int64_t idet = p / L.n, r = p - idet * L.n;
+    const float ph = L.nph[r * L.n_inc + L.op_channel[idet]];
+    on = ph > 0;
+    key = ((unsigned long long)idet << 52) | ((unsigned long long)(~(unsigned int)__float_as_int(ph)) << LK_RANK_BITS) |
+          (unsigned long long)((~(unsigned int)r) & ((1u << LK_RANK_BITS) - 1));
+  }
+  const unsigned long long m = __ballot(on);
+  if (!m) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  if (on) {
+    const unsigned w = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    keys[w] = key;
+    vals[w] = (int32_t)p;
+  }
+}
+// ... and each, in visiting order q, gets `cap` record slots from q * cap on, filled by a wave: lane ip takes profile bin ip, the
+// bins that deposit (light_deposits_ph: the tick whose open window holds the arrival time -- at a window edge the reference's
+// expressions can admit two ticks, both are emitted, tick ascending) are ranked by ballot and written side by side; the slots
+// left over carry LIGHT_NONE.  No count pass, no scan, no read-back of the record count, and the stores are coalesced (a thread per
+// pair wrote its ~100 records alone: 0.63 ms per 2x2 batch).  cap = bins + 8; a pair that would need more (eight window-edge
+// coincidences in one pair) raises *overflow and the sum fails loudly.
+__global__ void __launch_bounds__(256) light_emit_wave_kernel(LightSum L, const int32_t* __restrict__ order, int64_t n_act, int cap,
+                                                             int tick_bits, unsigned* __restrict__ keys,
+                                                             unsigned long long* __restrict__ vals, unsigned* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_act) return;
+  const LdsimConsts* c = L.c;
+  const int64_t p = order[q];
+  const int idet = (int)(p / L.n);
+  const int64_t r = p - (int64_t)idet * L.n;
+  const int opch = L.op_channel[idet];
+  const float ph = L.nph[r * L.n_inc + opch];
+  const double ns = 1.0, mus = 1e-6 * 1e9, tick = c->light_tick_size;
+  const double track_time = L.s.f[LDSIM_T0][L.seg0 + r];
+  const double track_end = track_time + L.nprof * ns / mus;
+  const int32_t* vx = L.voxel + r * 3;
+  const int64_t lb = ((((int64_t)vx[0] * L.ny + vx[1]) * L.nz + vx[2]) * L.ndet_lut + (opch % L.ndet_lut));
+  const bool smear = c->enable_lut_smearing != 0;
+  const int nbin = smear ? L.nprof : 1;
+  const float* prof = L.time_dist + lb * L.nprof;
+  const int64_t base = q * (int64_t)cap;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int n_out = 0;
+  for (int ip0 = 0; ip0 < nbin; ip0 += 64) {
+    const int ip = ip0 + lane;
+    bool e[3] = {false, false, false};
+    int64_t it0 = 0;
+    float pp = 0.f;
+    if (ip < nbin) {
+      const double pt = smear ? track_time + ip * ns / mus : track_time + (double)L.t0_avg[lb] * ns / mus;
+      pp = smear ? ph * prof[ip] : ph;              // (the f4 product of light_sim.py:100)
+      const double fl = floor((pt - L.start_time) / tick);
+      if (fl > -2.0 && fl < (double)L.n_ticks + 1.0) {
+        it0 = (int64_t)fl;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int64_t it = it0 - 1 + k;
+          if (it < 0 || it >= L.n_ticks) continue;
+          const double st = it * tick + L.start_time, en = st + tick;
+          if (track_end < st || track_time > en) continue;
+          e[k] = pt < en && pt > st;
+        }
+      }
+    }
+    const unsigned long long m0 = __ballot(e[0]), m1 = __ballot(e[1]), m2 = __ballot(e[2]);
+    int w = n_out + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (e[k]) {
+        if (w < cap) {
+          keys[base + w] = ((unsigned)idet << tick_bits) | (unsigned)(it0 - 1 + k);
+          vals[base + w] = ((unsigned long long)(unsigned)r << 32) | (unsigned long long)(unsigned)__float_as_int(pp);
+        }
+        w++;
+      }
+    }
+    n_out += __popcll(m0) + __popcll(m1) + __popcll(m2);
+  }
+  if (n_out > cap) {
+    if (lane == 0) atomicOr(overflow, 1u);
+    n_out = cap;
+  }
+  for (int k = n_out + lane; k < cap; k += 64) {
+    keys[base + k] = LIGHT_NONE;
+    vals[base + k] = 0ull;
+  }
+}
+
 // one thread per (detector, tick) cell that received something: replay its records in order (light_sim.py:101-110,118-127)
 __global__ void light_replay_kernel(const unsigned* __restrict__ keys, const unsigned long long* __restrict__ vals, int64_t n_rec,
                                     int tick_bits, double tick_size, const int64_t* __restrict__ track_id, int64_t n_ticks,
@@ -490,7 +592,7 @@ __global__ void __launch_bounds__(256) light_reset_cells_kernel(const unsigned* 
   bool head = false;
   if (i < n_rec) {
     cell = keys[i];
-    head = i == 0 || keys[i - 1] != cell;
+    head = (i == 0 || keys[i - 1] != cell) && cell != 0xFFFFFFFFu;      // (an unused record slot of the compact form: no cell)
   }
   const unsigned long long m = __ballot(head);
   int base = 0;
@@ -580,7 +682,7 @@ __global__ void __launch_bounds__(64) light_replay_wave_kernel(const unsigned* _
       prev_cell = ct;
       if (head) {
         if (open) { close_cell(); open = false; }
-        if (c0 + ta >= b1) { done = true; break; }          // the next block's cell
+        if (c0 + ta >= b1 || ct == 0xFFFFFFFFu) { done = true; break; }          // the next block's cell, or the unused slots at the end
         open = true;
         // fresh (the resident sum, whose arrays the call initialises): the cell starts from 0 photons and empty slots, nothing is
         // read back; otherwise (the host-array entry accumulates into what the caller passed, like the reference's +=) the rows are read
@@ -676,6 +778,20 @@ int light_launch_reset_cells(ldsim_ctx* ctx, int64_t n_rec, int64_t n_ticks, int
   HIPCHK(hipGetLastError());
   return 0;
 }
+// the record-slot overflow flag of the last compact photon sum (light_emit_wave_kernel); the caller has synchronised the stream
+int light_check_emit_overflow(ldsim_ctx* ctx) {
+  if (!ctx->light_emit_flag) return 0;
+  unsigned f = 0;
+  HIPCHK(hipMemcpy(&f, ctx->light_emit_flag, 4, hipMemcpyDeviceToHost));
+  ctx->light_emit_flag = nullptr;
+  if (f) {
+    HIPCHK(hipMemset(ctx->light_flag_dev, 0, 4));
+    ldsim_set_error("photon sum with truth slots: a (detector, segment) pair deposited into more ticks than its record slots hold "
+                    "(profile bins + 8); the arrays of that sum are incomplete");
+    return LDSIM_ESTATE;
+  }
+  return 0;
+}
 int light_launch_clear_list(ldsim_ctx* ctx, const LightAct* act, float* out) {
   hipLaunchKernelGGL(light_clear_list_kernel, dim3(256), dim3(256), 0, ctx->stream, *act, out);
   HIPCHK(hipGetLastError());
@@ -766,6 +882,57 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   const int64_t np = (int64_t)n_det * n;
   DevBuf* T = ctx->light_tmp;
   int rc;
+  const double tick_size = ctx->h_consts.light_tick_size;
+  if (!sorted_idx && max_truth <= 64 && tick_bits + det_bits <= 31 && n_rec_out) {
+    // ---- resident sum, compact form (kernels above): pairs with photons -> visiting order -> records by wave -> cells -> replay ----
+    const int cap = (ctx->h_consts.enable_lut_smearing ? ctx->lut_nprof : 1) + 8;
+    if ((rc = ldsim_ensure_buf(ctx, &T[1], 64))) return rc;                        // [0] pairs with photons
+    if (!ctx->light_flag_dev) {                                                       // record slot overflow: sticky until read
+      HIPCHK(hipMalloc((void**)&ctx->light_flag_dev, 8));
+      HIPCHK(hipMemsetAsync(ctx->light_flag_dev, 0, 8, st));
+    }
+    if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)np * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[0], (size_t)np * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[5], (size_t)np * 4))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[6], (size_t)np * 4))) return rc;
+    unsigned* d_cnt = (unsigned*)T[1].p;
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 4, st));
+    hipLaunchKernelGGL(light_active_pairs_kernel, dim3(nblk(np, 256)), dim3(256), 0, st, L, (unsigned long long*)T[3].p, (int32_t*)T[5].p,
+                       d_cnt);
+    HIPCHK(hipGetLastError());
+    unsigned n_act_u = 0;
+    HIPCHK(hipMemcpyAsync(&n_act_u, d_cnt, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = light_check_emit_overflow(ctx))) return rc;            // (of the previous compact sum, if nobody looked since)
+    const int64_t n_act = n_act_u, n_slots = n_act * cap;
+    if (n_act == 0) return 0;
+    if (n_slots >= 0x7fffffffLL) {
+      ldsim_set_error("photon sum with truth slots: %lld (detector, segment) pairs with photons x %d record slots exceed 2^31; sum "
+                      "fewer segments per call", (long long)n_act, cap);
+      return LDSIM_EINVAL;
+    }
+    if ((rc = sort_pairs_bits(ctx, (unsigned long long*)T[3].p, (unsigned long long*)T[0].p, (int32_t*)T[5].p, (int32_t*)T[6].p, n_act, 0,
+                              52 + det_bits)))
+      return rc;
+    // records: T[3] keys in, T[4] keys sorted (kept for the next sum's lazy reset), T[7] / T[8] payloads in / sorted
+    if ((rc = ldsim_ensure_buf(ctx, &T[3], (size_t)n_slots * 4))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[4], (size_t)n_slots * 4))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[7], (size_t)n_slots * 8))) return rc;
+    if ((rc = ldsim_ensure_buf(ctx, &T[8], (size_t)n_slots * 8))) return rc;
+    unsigned *k0 = (unsigned*)T[3].p, *k1 = (unsigned*)T[4].p;
+    unsigned long long *v0 = (unsigned long long*)T[7].p, *v1 = (unsigned long long*)T[8].p;
+    hipLaunchKernelGGL(light_emit_wave_kernel, dim3(nblk(n_act, 4)), dim3(256), 0, st, L, (const int32_t*)T[6].p, n_act, cap, tick_bits,
+                       k0, v0, ctx->light_flag_dev);
+    HIPCHK(hipGetLastError());
+    if ((rc = sort_pairs_u32_u64(ctx, k0, k1, v0, v1, n_slots, tick_bits + det_bits + 1))) return rc;      // (+ 1: the unused slots' bit)
+    ctx->light_lazy_tick_bits = tick_bits;
+    hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_slots, RW_BLOCK)), dim3(64), 0, st, k1, v1, n_slots, tick_bits, tick_size,
+                       track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth, 1);
+    HIPCHK(hipGetLastError());
+    *n_rec_out = n_slots;
+    ctx->light_emit_flag = ctx->light_flag_dev;  // (read at the next synchronising call: light_check_emit_overflow)
+    return 0;
+  }
   if ((rc = ldsim_ensure_buf(ctx, &T[1], (size_t)np * 4 + 16))) return rc;     // count, then offsets in T[2]
   if ((rc = ldsim_ensure_buf(ctx, &T[2], (size_t)np * 4 + 16))) return rc;
   int32_t* d_count = (int32_t*)T[1].p;
@@ -807,7 +974,6 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   HIPCHK(hipGetLastError());
   if ((rc = sort_pairs_u32_u64(ctx, k0, k1, v0, v1, n_rec, tick_bits + det_bits))) return rc;
   ctx->light_lazy_tick_bits = tick_bits;
-  const double tick_size = ctx->h_consts.light_tick_size;
   if (max_truth <= 64)
     hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_rec, RW_BLOCK)), dim3(64), 0, st, k1, v1, n_rec, tick_bits, tick_size,
                        track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth,

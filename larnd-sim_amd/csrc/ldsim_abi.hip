@@ -37,6 +37,7 @@ int light_launch_t0_range(ldsim_ctx*, const float*, const float*, int64_t, int*)
 int light_launch_sum(ldsim_ctx*, int64_t, int64_t, const int32_t*, const int64_t*, const float*, int, const int32_t*, int,
                      const int32_t*, double, int64_t, float*, int64_t*, double*, int, int64_t*, const LightAct* = nullptr);
 int light_launch_reset_cells(ldsim_ctx*, int64_t, int64_t, int, float*, int64_t*, double*);
+int light_check_emit_overflow(ldsim_ctx*);
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
@@ -238,7 +239,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_consts, ctx->d_resp,      ctx->d_eff,    ctx->d_ch2tpc, ctx->d_lut_vis, ctx->d_lut_t0,
                   ctx->d_lut_t0avg, ctx->d_lut_td, ctx->seg_block.p, ctx->raw.p,  ctx->d_pix_thr, ctx->d_pix_gain,
-                  ctx->d_glx, ctx->d_glw};
+                  ctx->d_glx, ctx->d_glw, ctx->light_flag_dev};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->copy_stream) {
@@ -1186,6 +1187,7 @@ extern "C" int ldsim_dev_light_download(ldsim_ctx* ctx, float* light_sample_inc,
       HIPCHK(hipMemcpyAsync(true_photons, ctx->light_tph.p, bo * ctx->light_sum_truth * 8, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  CK(light_check_emit_overflow(ctx));
   return 0;
 }
 

@@ -185,6 +185,8 @@ struct ldsim_ctx {
   // (detector, tick) cells except where the records still sorted in light_tmp[4] fell
   int light_lazy_valid = 0, light_lazy_mt = 0, light_lazy_tick_bits = 16;
   long long light_lazy_nrec = 0, light_lazy_nticks = 0;
+  unsigned* light_flag_dev = nullptr;    // 8 bytes of device memory for that flag (sticky until read)
+  unsigned* light_emit_flag = nullptr;   // device word of the last compact photon sum: a pair ran out of record slots (checked at the next synchronising light call)
   size_t light_clean_cells = 0, light_lazy_cap[3] = {0, 0, 0};
   void *light_lazy_out = nullptr, *light_lazy_tid = nullptr, *light_lazy_tph = nullptr;
   // the same for a sum without truth slots: clean except the tiles in light_act's list (LightAct; geometry of that sum below)
