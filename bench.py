@@ -432,21 +432,30 @@ def main():
             extras["dense_response_value"] = len(seg) / t_dense
             nl_d = max(acc["launches"], 1)
             useful_d = acc["dfma_useful"] if acc["dfma_useful"] > 0 else acc["dfma"]
-            tr_d, tr_src = profiled_traffic(a.config + "_dense", "mac_shift_kernel" if round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING) == 1 else "mac_shift2_kernel")
-            # first-class roofline of the path a full-support response table takes (gform_max_support hands it to the round-2 kernels)
+            # the path a full-support response table takes: since round 4 the default (weights_mode 2) keeps it in the matrix form
+            # (gform_max_support unlimited: profiles/r04_dense_handover.log); weights_mode 1 / 0 run the shifted-window kernels
+            Md = int(round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING))
+            dense_gform = a.weights_mode == 2
+            dk = f"gcorr_kernel<{Md}>" if dense_gform else ("mac_shift_kernel" if Md == 1 else "mac_shift2_kernel")
+            dwk = f"gtables_wave_kernel<{Md}, 55>" if dense_gform else "qweights_kernel"
+            tr_d, tr_src = profiled_traffic(a.config + "_dense", dk)
             extras["roofline_dense"] = {
-                "bound": "valu_f64", "kernel": "mac_shift_kernel" if round(consts.detector.TIME_SAMPLING / consts.detector.RESPONSE_SAMPLING) == 1 else "mac_shift2_kernel",
-                "launch_ms_avg": acc["m_ms"] / nl_d, "weights_kernel": "qweights_kernel", "weights_kernel_ms_avg": acc["w_ms"] / nl_d,
+                "bound": "mfma" if dense_gform else "valu_f64", "kernel": dk,
+                "launch_ms_avg": acc["m_ms"] / nl_d, "weights_kernel": dwk, "weights_kernel_ms_avg": acc["w_ms"] / nl_d,
                 "achieved": (2.0 * useful_d / (acc["m_ms"] * 1e-3) / 1e12) if acc["m_ms"] > 0 else None, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (2.0 * useful_d / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if acc["m_ms"] > 0 else None,
                 "issued_frac": (2.0 * acc["dfma"] / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if acc["m_ms"] > 0 else None,
                 "traffic": tr_d, "traffic_source": tr_src,
-                "note": "algorithmic flops = 2 x (weights kept) x (window ticks) over the correlation kernel's time against the f64 DFMA peak; "
-                        "issued counts every FMA lane (8-shift block and 512-tick tile padding)"}
+                "note": ("algorithmic flops = 2 x (nodes x cells x response ticks + the Toeplitz sum) over the correlation kernel's time against "
+                         "the f64 matrix peak (the same 78.6 TFLOP/s as the DFMA peak); issued = 2 x 1024 per v_mfma_f64_16x16x4"
+                         if dense_gform else
+                         "algorithmic flops = 2 x (weights kept) x (window ticks) over the correlation kernel's time against the f64 DFMA peak; "
+                         "issued counts every FMA lane (8-shift block and 512-tick tile padding)")}
             extras["dense_response"] = {"value": len(seg) / t_dense, "unit": "segments/s", "ms_per_step": 1e3 * t_dense,
                                         "steps": nd, "mac_kernel_ms_avg": acc["m_ms"] / max(acc["launches"], 1),
                                         "dfma_per_segment": acc["dfma"] / max(acc["S"], 1),
+                                        "kernel": dk,
                                         "valu_f64_frac": (2.0 * acc["dfma"] / (acc["m_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS)
                                         if acc["m_ms"] > 0 else None,
                                         "useful_share_of_issued": (acc["dfma_useful"] / acc["dfma"]) if acc["dfma"] else None,
