@@ -1118,13 +1118,16 @@ def test_resident_light_leg_golden(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("smear", [True, False])
 @pytest.mark.parametrize("n_tracks,with_none", [(3, False), (7, True), (40, True)])
-def test_resident_photon_sum_slot_walk_equals_the_record_walk(n_tracks, with_none):
+def test_resident_photon_sum_slot_walk_equals_the_record_walk(n_tracks, with_none, smear):
     """The resident photon sum gives out truth slots 64 records at a time (light_replay_wave_kernel: slot lookup by all lanes, new
     tracks in order of first appearance, two sequential chains); the host-array stage call accumulates into the caller's arrays
     and walks record by record as light_sim.py:101-127 is written.  Same arrays bit for bit when many segments share a track
     (slots re-used), when there are more tracks than slots (records dropped), and with track id -1 among them (a slot holding -1
-    looks empty and is taken over by the next track, its photons staying)."""
+    looks empty and is taken over by the next track, its photons staying).  The two sums also build their records differently: the
+    resident one from the compacted pairs with photons, a wave per pair (light_emit_wave_kernel), the stage call from the caller's
+    sorted_indices, a thread per pair after a count pass -- with and without LUT smearing."""
     cfg = "2x2_no_modvar" if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "light_2x2_no_modvar.npz")) else "module0"
     H.load_cfg(cfg)
     g = H.gold(f"light_{cfg}.npz")
@@ -1139,6 +1142,7 @@ def test_resident_photon_sum_slot_walk_equals_the_record_walk(n_tracks, with_non
         ids[rng.random(n) < 0.15] = -1
     Mt = 2
     consts.sim.MC_TRUTH_THRESHOLD = 1e-9          # (the golden set is small: every deposit counts for the slots)
+    consts.light.ENABLE_LUT_SMEARING = smear       # (with: a record per profile bin; without: one per pair, at the LUT's mean arrival time)
     ch = ChargeChain()
     ch.upload(r, np.zeros(n, dtype=np.int32))
     ch.light_incidence(lut)
