@@ -224,6 +224,31 @@ def test_tracks_current_vs_oracle_full_ticks(path):
         assert st.n_fallback <= 0.1 * (np.abs(ref).max(axis=-1) > 0).sum()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [24, 40, 48])
+def test_tracks_current_other_sample_counts_vs_oracle(ns):
+    """detector.SAMPLED_POINTS other than the reference's 40: the wave tables kernel reads its sample maps from the 40-sample map
+    records pair_setup_kernel writes (gform.h G_MAP_NS) -- fewer samples leave the tail of a record unused, more send every pair to
+    the workgroup tables kernel (wave_ok 0), which derives its maps itself.  All ticks against the oracle at the same setting."""
+    H.load_cfg("module0")
+    consts.detector.SAMPLED_POINTS = ns
+    seg = synth.make_segments(8, seed=13, segs_per_event=8)
+    batching.swap_coordinates(seg)
+    seg["x_end"][1] = seg["x_start"][1] + 1.1; seg["y_end"][1] = seg["y_start"][1] - 0.7
+    for ax in "xyz":
+        seg[ax] = 0.5 * (seg[ax + "_start"].astype(np.float64) + seg[ax + "_end"])
+    r = H.quench_drift(O, seg)
+    nmax = O.max_pixels(r)
+    P = 3 * nmax + 6
+    _, neigh, nrad, _ = O.get_pixels(r, nmax, P, 1)
+    _, T = O.time_intervals(r)
+    resp = synth.make_response("golden")
+    ref = O.tracks_current(r, neigh, T, resp)
+    sig, st = _tracks_current_on("gform", neigh, r, resp, T)
+    H.assert_wave_close(sig, ref, rtol=1e-5, atol_peak=1e-7, what=f"tracks_current, {ns} samples per axis")
+    assert (ref != 0).sum() > 10000 and st.n_fallback <= 0.1 * (np.abs(ref).max(axis=-1) > 0).sum()
+
+
 @pytest.mark.parametrize("cfg", ["module0", "ndlar"])
 @pytest.mark.parametrize("path", ["gform", "quad"])
 def test_tracks_current_length_sweep_vs_oracle(cfg, path):
