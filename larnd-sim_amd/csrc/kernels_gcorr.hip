@@ -22,6 +22,7 @@
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+#define G_WRAP 24        // words behind a pair's cell list in LDS that repeat its first ones: the G loop looks up to GPF + 1 groups past its range
 #define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
 static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padded to whole prefetch rounds");
 
@@ -46,7 +47,7 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
   // (one 32-bit word per listed cell since round 4: cell index | X column << 12 | Y row entry << 18 -- 64-bit words with the row's
   // offset spelled out cost a KB per 256 cells, which is what kept the Z table of a typical pair out of LDS)
-  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys)) + 4 * L.cellcap + 16;
+  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys)) + 4 * (L.cellcap + G_WRAP) + 16;
   // Z in LDS where the pair's budget has room for it; else (and for the steepest long segments, NU > G_NUCAP) the P step reads
   // it from the record: a pair never drops to the low-occupancy class because of its Z table
   // M = 1: == 16 mod 32, the four 16-shift runs of an A operand read conflict-free; M = 2 reads every other shift (one parity):
@@ -230,17 +231,24 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
               }
           }
           if (c8 == 0) s_X[n * xs + ncol] = 0.0;
-          // (entries past the list's padded count are never read: the loops below stop at the count)
-          if (tid_l < cell_cap) s_info[tid_l] = info_word(ce0);
-          if (tid_l + GT < cell_cap) s_info[tid_l + GT] = info_word(ce1);
+          // (only the list's padded count of entries: behind it sits the repeated head, written below by other threads)
+          if (tid_l < ncell_l) s_info[tid_l] = info_word(ce0);
+          if (tid_l + GT < ncell_l) s_info[tid_l + GT] = info_word(ce1);
           for (int i = tid_l + 2 * GT; i < ncell_l; i += GT) s_info[i] = info_word((unsigned)cells[G_CELL0 + i]);
+          // the list's first G_WRAP = 24 words once more behind its end (it holds a multiple of 16, at least 16): the look-ahead of
+          // the G loop reads straight on instead of wrapping its group index -- three compare / select pairs per index and slot,
+          // ~20 scalar instructions per cell group.  (Thread t < 24 holds word t already.)
+          if (tid_l < G_WRAP) {
+            if (ncell_l >= 32 || tid_l < 16) s_info[ncell_l + tid_l] = info_word(ce0);
+            if (ncell_l == 16 && tid_l < 8) s_info[32 + tid_l] = info_word(ce0);
+          }
           if (tid_l == 0) { s_ncell = ncell_l; s_nreal = nreal_l; }
         }
         loaded = b;
       }
       __syncthreads();
-      if (stamps) ts_stage += __builtin_amdgcn_s_memtime() - ts_mark;
       const int ncell = s_ncell;
+      if (stamps) ts_stage += __builtin_amdgcn_s_memtime() - ts_mark;
       const int ngrp = ncell >> 2;                 // a multiple of GPF (gtables_kernel pads the list with weightless cells)
       if (tid == 0)
         n_useful += (unsigned long long)min(G_NODES, NQ - b * G_NODES) *
@@ -332,14 +340,13 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       const unsigned* s_inf32 = s_info;
       const char* xl = (const char*)(s_X + jj * xs);
       const char* yl = (const char*)(s_Y + jj * ys);
-      auto wrap = [&](int g) {            // (g < 3 ngrp)
-        g = g >= ngrp ? g - ngrp : g;
-        return g >= ngrp ? g - ngrp : g;
-      };
       // row word: the cell's offset into the padded response table (doubles); column word: byte offsets of its X column and Y row entry
-      auto row_word = [&](int g) { return (s_inf32[4 * wrap(g) + kk] & 0xFFFu) * (unsigned)nkp; };
+      // (g < ngrp + G_WRAP / 4: the list is repeated behind its end)
+      // (the cell index bounded by the table's last row: a stray word must not become a stray address)
+      const unsigned cell_last = (unsigned)(A.ni * A.nj - 1);
+      auto row_word = [&](int g) { return min(s_inf32[4 * g + kk] & 0xFFFu, cell_last) * (unsigned)nkp; };
       auto col_word = [&](int g) {
-        const unsigned w = s_inf32[4 * wrap(g) + kk];
+        const unsigned w = s_inf32[4 * g + kk];
         return ((w >> 9) & 0x1F8u) | (((w >> 15) & 0x1F8u) << 16);      // (col * 8) | (j * 8) << 16
       };
       // The tile pairs are dealt to the pair's two waves alternately; an odd one left over (the survey table's 82 staged ticks are
@@ -572,15 +579,18 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // ticks per tile of the correlation: the pairs' windows are as long as the staged response support (over M) plus their
   // shift range; one tile where that fits 128 or 256 ticks, 512-tick tiles for a table with full support
   const int support = (GA.k_hi - GA.k_lo + 1) / M + 64;
-  const int TT = support <= 128 ? 128 : (support <= 256 ? 256 : 512);
+  const int TT = support <= 128 ? 128 : ((support <= 256 || (ctx->debug_gform & 8192)) ? 256 : 512);      // (debug_gform 8192: 256-tick tiles for any support)
   // [round 4: 12 KB for M = 1 -- swept again on the kernel without spills: 12 KB 5.04, 13 KB 5.24-5.40, 11 KB 5.20, 14 KB 5.44 ms per
   // 50 k segments (profiles/r04_gcorr_lds_budget.log); at 13312 + the static words a CU held eleven workgroups, not twelve]
   // Launches of the correlation by LDS need (g_lds_class): pairs that fit 13 KB (M = 1: 80 VGPRs, six waves per SIMD; M = 2, whose
   // kernel spills at 80: 16 KB, 96 VGPRs, five) run twelve (ten) to a CU in the launch over all pairs, the
   // rest -- listed here, counted on the host together with the pool size -- seven to a CU at 22 KB (every such pair of the ndlar
   // workload fits it; at 32 KB they ran five to a CU: 18.8 -> 17.6 ms per 50 k segments, tools/lds_b1_sweep.py) or two to three at the caps' size.
+  // [round 4: with 512-tick tiles (a table with full support: 8 KB of tick sums per pair) the second class is 17 KB at M = 1 -- nine pairs per CU
+  // instead of seven, Z read from the record where it no longer fits: 92.3 -> 83.1 ms per 50 k segments on the dense table, 87 at 18 KB, 85 at
+  // 16 KB, 97 at 15 KB (tools/lds_b1_sweep_dense.py, profiles/r04_gcorr_lds_b1_dense.log); ndlar's (M = 2) optimum stays above 22 KB.]
   const int Mz = M | ((ctx->debug_gform & 1024) ? 16 : 0);
-  const int b0 = (M == 1 ? 12288 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : 22528, b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, Mz).bytes;
+  const int b0 = (M == 1 ? 12288 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : (M == 1 && TT >= 512 ? 17408 : 22528), b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, Mz).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));

@@ -298,7 +298,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     if (!ctx->h_resp_kmax.empty()) resp_support_update(ctx);
   }
   else if (!strcmp(name, "debug_phases")) ctx->debug_phases = (int)value;
-  else if (!strcmp(name, "debug_lds_b1_kb")) ctx->debug_lds_b1_kb = value >= 17 && value <= 64 ? (int)value : 0;
+  else if (!strcmp(name, "debug_lds_b1_kb")) ctx->debug_lds_b1_kb = value >= 12 && value <= 64 ? (int)value : 0;
   else if (!strcmp(name, "debug_lds_pad_kb")) ctx->debug_lds_pad_kb = value >= -40 && value <= 16 ? (int)value : 0;
   else if (!strcmp(name, "debug_gform")) ctx->debug_gform = (int)value;
   else if (!strcmp(name, "gform_wave_tables")) ctx->gform_wave_tables = value != 0;
