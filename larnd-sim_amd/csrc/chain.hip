@@ -16,6 +16,7 @@ int seg_launch_get_pixels(ldsim_ctx*, int64_t, int64_t, int, int32_t*, int, int3
 int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t, int, int64_t, unsigned long long*,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
+int sort_pairs_bits(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t, int, int);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
 int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
@@ -310,7 +311,13 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   int32_t* d_vals = (int32_t*)ctx->scratch[SB_VALS].p;
   int32_t* d_vals2 = (int32_t*)ctx->scratch[SB_VALS2].p;
   CK(sort_make_keys(ctx, d_neigh, d_nrad, seg_begin, batch0, P, n_entries, d_keys, d_vals, counters));
-  CK(sort_pairs(ctx, d_keys, d_keys2, d_vals, d_vals2, n_entries));
+  {
+    // key = batch << 36 | pixel << 4 | ring code, ~0 for an empty slot: the bits above the launch's batch count are zero in every
+    // valid key and one in the empty ones, so the sort stops one bit above them (20 batches: 42 bits, six 8-bit passes instead of eight)
+    int bb = 0;
+    while ((1ll << bb) < n_batches) bb++;
+    CK(sort_pairs_bits(ctx, d_keys, d_keys2, d_vals, d_vals2, n_entries, 0, 36 + bb + 1));
+  }
   unsigned long long n_valid_ull = 0;
   std::vector<int32_t> h_tmax(n_batches);
   HIPCHK(hipMemcpyAsync(&n_valid_ull, &counters[4], 8, hipMemcpyDeviceToHost, st));
