@@ -149,7 +149,9 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * weight, v = 7 (default since round 4: N = ceil(3.4 + 1.38 r) nodes for a clipped segment r Gaussian widths long; per tick the
  * result stays at 0.012 of the parity tolerance 1e-5 |ref| + 1e-7 peak against the reference's goldens, where the f4 rounding of
  * the stored currents already is -- tools/quad_sweep.py, profiles/r04_acc_sweep_module0.log), 8, 9, 10 (4.8 + 1.6 r, the default
- * of rounds 2-3) or 12 (6 + 1.9 r)),
+ * of rounds 2-3), 12 (6 + 1.9 r), or looser: 6 (3.0 + 1.3 r: 3.7 % faster, 0.033 of the tolerance at worst, but the pixel charges
+ * move by 4.5e-8 against the closed form -- beyond the 2e-8 the parity tests hold them to, so it is not the default) and 5
+ * (2.8 + 1.2 r: 0.32 of the tolerance) -- profiles/r04_acc_sweep_module0_5_6.log),
  * "mac_mode" (split path, correlation stage: 1 = mac_shift_kernel / mac_shift2_kernel (default), 0 = mac_kernel<M>, rows
  * staged in LDS; bit-identical results), "light_incidence_scalar" (1 = calculate_light_incidence with one channel per lane
  * instead of four (the form used when n_out or the LUT's detector count is not a multiple of 4); identical bits; default 0),

@@ -331,11 +331,11 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     // relative quadrature error of the tables / weights stage as a power of ten of the peak weight (fits of tools/quad_nodes.py,
     // upper envelopes: N = ceil(n0 + slope r) nodes for a segment r Gaussian widths long)
     static const struct { int acc; double n0, slope; } rules[] = {
-      {7, 3.4, 1.38}, {8, 3.8, 1.46}, {9, 4.4, 1.54}, {10, 4.8, 1.6}, {12, 6.0, 1.9}};
+      {5, 2.8, 1.2}, {6, 3.0, 1.3}, {7, 3.4, 1.38}, {8, 3.8, 1.46}, {9, 4.4, 1.54}, {10, 4.8, 1.6}, {12, 6.0, 1.9}};
     bool ok = false;
     for (const auto& r : rules)
       if (value == r.acc) { ctx->quad_n0 = r.n0; ctx->quad_slope = r.slope; ok = true; }
-    if (!ok) { ldsim_set_error("quad_accuracy_log10 must be 7, 8, 9, 10 or 12"); return LDSIM_EINVAL; }
+    if (!ok) { ldsim_set_error("quad_accuracy_log10 must be 5, 6, 7, 8, 9, 10 or 12"); return LDSIM_EINVAL; }
   }
   else if (!strcmp(name, "quad_max_nodes")) {
     if (!(value >= 8 && value <= 256)) { ldsim_set_error("quad_max_nodes must be in [8, 256]"); return LDSIM_EINVAL; }

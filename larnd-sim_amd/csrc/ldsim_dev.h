@@ -125,7 +125,7 @@ struct ldsim_ctx {
   int32_t n_light_ch = 0;
   DevBuf resp_pad;                           // zero-padded copy of the response rows for mac_shift_kernel
   int32_t resp_pad_lo = 0, resp_pad_hi = -2; // staged range it was built for (-2: not built)
-  double quad_n0 = 3.4, quad_slope = 1.38;   // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-7 of the peak weight (option quad_accuracy_log10, tools/quad_sweep.py)
+  double quad_n0 = 3.4, quad_slope = 1.38;   // Gauss-Legendre node rule N = ceil(n0 + slope * r): 1e-7 of the peak weight (option quad_accuracy_log10, tools/quad_sweep.py; 6 = 3.0 + 1.3 r is 3.7 % faster and fails the 2e-8 charge tests against the closed form)
   // overlapped download of the chain's results (ldsim_chain_download_async): a second stream copies launch k's per-pixel
   // arrays to the host while launch k + 1 computes into the other set of output buffers
   DevBuf light_wtid, light_wtph, light_wtid2;            // slot-major working copies of a response stage's output truth rows

@@ -40,7 +40,6 @@ def stage(neigh, r, resp, T, acc):
     set_acc(acc)
     lib.set_option("gform_max_support", 1e9)
     detsim.tracks_current[(1, 1, 1), (1, 1, 64)](sig, np.ascontiguousarray(neigh), r, resp)
-    lib.set_option("gform_max_support", 768)
     return sig
 
 
