@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
                     ((unsigned long long)s_nreal * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
       // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k] -- for both tiles of the wave at once: one A
       // operand (Z of the lane's shift and node) feeds two independent accumulation chains.
+      const bool no_sum = (GA.dbg & 16384) != 0;       // timing tools: the P products without their sums into the tick array
       auto pstep2 = [&](const d4& g0acc, const d4& g1acc, int k0) {
         auto zrow = [&](int st, double* za) {
 #pragma unroll
@@ -296,8 +297,8 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
               const int u0 = 2 * v + par0, u1 = 2 * v + par1;
               const int idx0 = ((k0 + 2 * jj - (u_min + u0)) >> 1) - sup0;          // (even numerators by construction)
               const int idx1 = ((k0 + 2 * jj + 1 - (u_min + u1)) >> 1) - sup0;
-              if (u0 < NU && idx0 >= 0 && idx0 < wlen) atomicAdd(&ow[idx0], p0[r]);
-              if (u1 < NU && idx1 >= 0 && idx1 < wlen) atomicAdd(&ow[idx1], p1[r]);
+              if (u0 < NU && idx0 >= 0 && idx0 < wlen && !no_sum) atomicAdd(&ow[idx0], p0[r]);
+              if (u1 < NU && idx1 >= 0 && idx1 < wlen && !no_sum) atomicAdd(&ow[idx1], p1[r]);
             }
           }
           n_mfma += 2 * nq4 * NV16;
@@ -321,8 +322,8 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             const int idx = (M == 1 ? num : (num >> 1)) - sup0;        // (k0 and k0 + 16 have the same parity)
             const int idx1 = idx + 16 / M;
             const bool on = u < NU && (M == 1 || (num & 1) == 0);
-            if (on && idx >= 0 && idx < wlen) atomicAdd(&ow[idx], p0[r]);
-            if (on && idx1 >= 0 && idx1 < wlen) atomicAdd(&ow[idx1], p1[r]);
+            if (on && idx >= 0 && idx < wlen && !no_sum) atomicAdd(&ow[idx], p0[r]);
+            if (on && idx1 >= 0 && idx1 < wlen && !no_sum) atomicAdd(&ow[idx1], p1[r]);
           }
         }
         n_mfma += 2 * nq4 * NU16;

@@ -32,6 +32,8 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
         "stamps": ((0, 0, 128), (0, 0, 0)),
         # the same for gtables_wave_kernel (debug_gform 2048)
         "tstamps": ((0, 0, 2048), (0, 0, 0)),
+        # the P step without its LDS atomics (debug_gform 16384; results are wrong), with cycle stamps
+        "psum": ((0, 0, 128), (0, 0, 128 + 16384), (0, 0, 0), (0, 0, 16384)),
         # an odd tile pair shared by the pair's two waves (default) against dealt whole (debug_gform 256)
         # Z staged in LDS where it fits (default) against read from the record in the P step for every pair (debug_gform 1024), at
         # several LDS budgets of the first class (13 KB - pad)
