@@ -443,6 +443,7 @@ __global__ void light_fill_ordered_kernel(LightSum L, const int32_t* __restrict_
 // ---- round 4, resident sum: only the (detector, segment) pairs that carry photons are ordered, and a wave emits a pair's records ----
 // A segment lights the detectors of its own TPC: 1 in 8 (2x2) to 1 in 70 (ndlar) of the n_det x n pairs hold photons.  The pairs
 // that do are compacted (any order: the sort that follows orders them, their keys are distinct) ...
+#define LIGHT_SPARE 2                 // record slots of a pair beyond its profile bins (a bin at a window edge can deposit into two ticks: ~1e-10 per bin)
 #define LIGHT_NONE 0xFFFFFFFFu        // key of an unused record slot: sorts behind every (detector, tick) cell (those use <= 31 bits)
 __global__ void __launch_bounds__(256) light_active_pairs_kernel(LightSum L, unsigned long long* __restrict__ keys,
                                                                 int32_t* __restrict__ vals, unsigned* __restrict__ count) {
@@ -472,8 +473,8 @@ __global__ void __launch_bounds__(256) light_active_pairs_kernel(LightSum L, uns
 // bins that deposit (light_deposits_ph: the tick whose open window holds the arrival time -- at a window edge the reference's
 // expressions can admit two ticks, both are emitted, tick ascending) are ranked by ballot and written side by side; the slots
 // left over carry LIGHT_NONE.  No count pass, no scan, no read-back of the record count, and the stores are coalesced (a thread per
-// pair wrote its ~100 records alone: 0.63 ms per 2x2 batch).  cap = bins + 8; a pair that would need more (eight window-edge
-// coincidences in one pair) raises *overflow and the sum fails loudly.
+// pair wrote its ~100 records alone: 0.63 ms per 2x2 batch).  cap = bins + LIGHT_SPARE; a pair that would need more (three window-edge
+// coincidences in one pair: ~1e-24) raises *overflow and the sum fails loudly.
 __global__ void __launch_bounds__(256) light_emit_wave_kernel(LightSum L, const int32_t* __restrict__ order, int64_t n_act, int cap,
                                                              int tick_bits, unsigned* __restrict__ keys,
                                                              unsigned long long* __restrict__ vals, unsigned* __restrict__ overflow) {
@@ -787,7 +788,7 @@ int light_check_emit_overflow(ldsim_ctx* ctx) {
   if (f) {
     HIPCHK(hipMemset(ctx->light_flag_dev, 0, 4));
     ldsim_set_error("photon sum with truth slots: a (detector, segment) pair deposited into more ticks than its record slots hold "
-                    "(profile bins + 8); the arrays of that sum are incomplete");
+                    "(profile bins + 2); the arrays of that sum are incomplete");
     return LDSIM_ESTATE;
   }
   return 0;
@@ -885,7 +886,7 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   const double tick_size = ctx->h_consts.light_tick_size;
   if (!sorted_idx && max_truth <= 64 && tick_bits + det_bits <= 31 && n_rec_out) {
     // ---- resident sum, compact form (kernels above): pairs with photons -> visiting order -> records by wave -> cells -> replay ----
-    const int cap = (ctx->h_consts.enable_lut_smearing ? ctx->lut_nprof : 1) + 8;
+    const int cap = (ctx->h_consts.enable_lut_smearing ? ctx->lut_nprof : 1) + LIGHT_SPARE;
     if ((rc = ldsim_ensure_buf(ctx, &T[1], 64))) return rc;                        // [0] pairs with photons
     if (!ctx->light_flag_dev) {                                                       // record slot overflow: sticky until read
       HIPCHK(hipMalloc((void**)&ctx->light_flag_dev, 8));
