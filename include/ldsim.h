@@ -141,7 +141,8 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * "gform_max_support" (weights_mode 2 runs the node-separable form for response tables whose staged support is at most this
  * many time ticks and the kernels of weights_mode 1 for wider ones: the matrix form pays per response tick, the shifted-window
  * kernels per 512-tick tile; 0 = never, 1e9 = always = the default since round 4 -- 768 before, when full-support tables were
- * faster in the shifted-window kernels), "gform_wave_tables" (weights_mode 2, tables stage: 1 =
+ * faster in the shifted-window kernels), "gform_chunks" (weights_mode 2: tables and correlation in this many ranges of the pair list, the tables of a range on a second
+ * stream beside the correlation of the one before; 1..32, default 1: measured no faster), "gform_wave_tables" (weights_mode 2, tables stage: 1 =
  * gtables_wave_kernel, one wave per pair, for the pairs that fit it and gtables_kernel, one workgroup per pair, for the rest
  * (default); 0 = gtables_kernel for all: same tables entry for entry), "quad_max_nodes" (qweights_kernel: pairs that need more nodes,
  * i.e. segments longer than ~value/2 Gaussian widths, are recomputed by the monolithic kernel; 8..256, default 256),

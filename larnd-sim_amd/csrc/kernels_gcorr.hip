@@ -19,6 +19,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -70,11 +71,11 @@ __host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, in
 
 template <int M>
 __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
-                                                      int cls) {
+                                                      int cls, int pair0) {
   const CurArgs& A = GA.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x;
+  const int64_t pair = big_list ? (int64_t)big_list[blockIdx.x] : (int64_t)blockIdx.x + pair0;      // (pair0: first pair of a range launch)
   if (pair >= A.n_pairs) return;
   // timing tools (debug_gform 128): where a wave's residency goes, in shader cycles summed over the waves (counters 9 .. 15:
   // GInfo wait | table staging incl. its barriers | G loops | P steps | edge columns | final barrier + store | whole life)
@@ -520,6 +521,9 @@ __global__ void __launch_bounds__(256) goff_scatter_kernel(GInfo* __restrict__ g
 int sort_exclusive_scan_u64(ldsim_ctx*, const unsigned long long*, unsigned long long*, int64_t);
 extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* wg_list, int64_t n_wg, const int32_t* w2_list,
                                 int64_t n_w2);
+extern "C++" int gtables_launch_range(ldsim_ctx* ctx, const GArgs& GA, int M, hipStream_t ts, int64_t pair0, int64_t n);
+extern "C++" int gtables_launch_lists(ldsim_ctx* ctx, const GArgs& GA, int M, hipStream_t ts, const int32_t* wg_list, int64_t n_wg,
+                                      const int32_t* w2_list, int64_t n_w2);
 extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* wg_list, unsigned long long* wg_count, int32_t* w2_list,
                                      unsigned long long* w2_count);
 extern "C++" int resp_pad_ensure(ldsim_ctx* ctx, const CurArgs& A, int* k_lo, int* k_hi, int* nkp);
@@ -641,15 +645,43 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   GA.glx = ctx->d_glx;
   GA.glw = ctx->d_glw;
   GA.resp_pad = (const double*)ctx->resp_pad.p;
-  if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg, d_w2, (int64_t)n_w2))) return rc;
-  HIPCHK(hipEventRecord(ctx->ev[5], st));
-  for (int cls = 0; cls < 3; cls++) {
-    if (n_cls[cls] == 0) continue;
+  auto corr = [&](int cls, int64_t pair0, int64_t count) -> int {
+    if (count <= 0) return 0;
     const int32_t* list = cls == 0 ? nullptr : d_big + (int64_t)(cls - 1) * n;
     const size_t dyn = (size_t)(cls == 0 ? b0 : (cls == 1 ? b1 : b2));
-    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)n_cls[cls]), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls);
-    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)n_cls[cls]), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls);
+    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
+    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
     HIPCHK(hipGetLastError());
+    return 0;
+  };
+  const int K = (int)std::min<int64_t>(ctx->gform_chunks, std::max<int64_t>(1, n / 4096));
+  if (K <= 1) {
+    if ((rc = gtables_launch(ctx, GA, M, d_wg, (int64_t)n_wg, d_w2, (int64_t)n_w2))) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[5], st));
+    for (int cls = 0; cls < 3; cls++)
+      if ((rc = corr(cls, 0, (int64_t)n_cls[cls]))) return rc;
+  } else {
+    // Tables and correlation in K pair ranges on two streams: the tables of range c + 1 run beside the correlation of range c -- a
+    // VALU-bound kernel beside one that waits on memory and the matrix pipe -- and a range's records (tens of MB) are read back
+    // while they are still in the Infinity Cache.  Order: the tables of the listed pairs (wide wave kernel, workgroup kernel) first,
+    // then range after range; the correlation's listed launches (larger LDS classes) after the last range.
+    if (!ctx->tab_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->tab_stream, hipStreamNonBlocking));
+    for (int c = 0; c <= K; c++)
+      if (!ctx->tab_ev[c]) HIPCHK(hipEventCreateWithFlags(&ctx->tab_ev[c], hipEventDisableTiming));
+    hipStream_t ts = ctx->tab_stream;
+    HIPCHK(hipEventRecord(ctx->tab_ev[K], st));                  // (everything the tables need is queued on st before this)
+    HIPCHK(hipStreamWaitEvent(ts, ctx->tab_ev[K], 0));
+    if ((rc = gtables_launch_lists(ctx, GA, M, ts, d_wg, (int64_t)n_wg, d_w2, (int64_t)n_w2))) return rc;
+    for (int c = 0; c < K; c++) {
+      const int64_t p0 = n * c / K, p1 = n * (c + 1) / K;
+      if ((rc = gtables_launch_range(ctx, GA, M, ts, p0, p1 - p0))) return rc;
+      HIPCHK(hipEventRecord(ctx->tab_ev[c], ts));
+      HIPCHK(hipStreamWaitEvent(st, ctx->tab_ev[c], 0));
+      if (c == 0) HIPCHK(hipEventRecord(ctx->ev[5], st));       // (weights_ms: up to the first range's tables; mac_ms: the rest, tables of the later ranges beside it)
+      if ((rc = corr(0, p0, p1 - p0))) return rc;
+    }
+    for (int cls = 1; cls < 3; cls++)
+      if ((rc = corr(cls, 0, (int64_t)n_cls[cls]))) return rc;
   }
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   // the pool's size in the statistics slot of the split paths (doubles)

@@ -399,11 +399,11 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 // it (wide diffusion or steep segments: a fifth of the ndlar pairs)
 
 template <int M, int XYS>
-__global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list) {
+__global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list, int pair0) {
   const CurArgs& A = GA.c;
   constexpr int NUW = XYS <= 55 ? G_NUCAP : 2 * G_NUCAP;       // shifts of a pair this instantiation takes
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
-  const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
+  const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x + pair0;      // (pair0: first pair of a range launch)
   if (pair >= A.n_pairs) return;
   const bool stamps = (GA.dbg & 2048) != 0;      // timing tools: cycle stamps into the statistics stripes 9..15 (chain.hip prints them)
   unsigned long long ts0 = 0, ts_a = 0, ts_c = 0, ts_xy = 0, ts_z = 0, ts_cells = 0, ts_m = 0;
@@ -855,23 +855,36 @@ extern "C++" int gtables_list_launch(ldsim_ctx* ctx, const GArgs& GA, int32_t* w
   return 0;
 }
 
+// the wave kernel over the pair range [pair0, pair0 + n) on stream `ts`
+extern "C++" int gtables_launch_range(ldsim_ctx* ctx, const GArgs& GA, int M, hipStream_t ts, int64_t pair0, int64_t n) {
+  if (n <= 0) return 0;
+  if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 55>), dim3((unsigned)n), dim3(64), 0, ts, GA, (const int32_t*)nullptr, (int)pair0);
+  else hipLaunchKernelGGL((gtables_wave_kernel<2, 55>), dim3((unsigned)n), dim3(64), 0, ts, GA, (const int32_t*)nullptr, (int)pair0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// its wide instantiation over the `n_w2` pairs of `w2_list`, and the workgroup kernel over the `n_wg` listed ones, on stream `ts`
+extern "C++" int gtables_launch_lists(ldsim_ctx* ctx, const GArgs& GA, int M, hipStream_t ts, const int32_t* wg_list, int64_t n_wg,
+                                      const int32_t* w2_list, int64_t n_w2) {
+  if (n_w2 > 0) {
+    if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 81>), dim3((unsigned)n_w2), dim3(64), 0, ts, GA, w2_list, 0);
+    else hipLaunchKernelGGL((gtables_wave_kernel<2, 81>), dim3((unsigned)n_w2), dim3(64), 0, ts, GA, w2_list, 0);
+    HIPCHK(hipGetLastError());
+  }
+  if (n_wg > 0) {
+    if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ts, GA, wg_list);
+    else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ts, GA, wg_list);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
 // wave kernel over all pairs, its wide instantiation over the `n_w2` pairs of `w2_list`, then the workgroup kernel over the `n_wg`
 // listed ones
 extern "C++" int gtables_launch(ldsim_ctx* ctx, const GArgs& GA, int M, const int32_t* wg_list, int64_t n_wg, const int32_t* w2_list,
                                 int64_t n_w2) {
   if (GA.c.n_pairs == 0) return 0;
-  if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 55>), dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA, (const int32_t*)nullptr);
-  else hipLaunchKernelGGL((gtables_wave_kernel<2, 55>), dim3((unsigned)GA.c.n_pairs), dim3(64), 0, ctx->stream, GA, (const int32_t*)nullptr);
-  HIPCHK(hipGetLastError());
-  if (n_w2 > 0) {
-    if (M == 1) hipLaunchKernelGGL((gtables_wave_kernel<1, 81>), dim3((unsigned)n_w2), dim3(64), 0, ctx->stream, GA, w2_list);
-    else hipLaunchKernelGGL((gtables_wave_kernel<2, 81>), dim3((unsigned)n_w2), dim3(64), 0, ctx->stream, GA, w2_list);
-    HIPCHK(hipGetLastError());
-  }
-  if (n_wg > 0) {
-    if (M == 1) hipLaunchKernelGGL(gtables_kernel<1>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ctx->stream, GA, wg_list);
-    else hipLaunchKernelGGL(gtables_kernel<2>, dim3((unsigned)n_wg), dim3(CUR_THREADS), 0, ctx->stream, GA, wg_list);
-    HIPCHK(hipGetLastError());
-  }
-  return 0;
+  int rc = gtables_launch_range(ctx, GA, M, ctx->stream, 0, GA.c.n_pairs);
+  if (rc) return rc;
+  return gtables_launch_lists(ctx, GA, M, ctx->stream, wg_list, n_wg, w2_list, n_w2);
 }

@@ -250,6 +250,12 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->light_stream);
     (void)hipStreamDestroy(ctx->light_stream);
   }
+  if (ctx->tab_stream) {
+    (void)hipStreamSynchronize(ctx->tab_stream);
+    (void)hipStreamDestroy(ctx->tab_stream);
+  }
+  for (auto& e : ctx->tab_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_light_in) (void)hipEventDestroy(ctx->ev_light_in);
   if (ctx->ev_light_done) (void)hipEventDestroy(ctx->ev_light_done);
   for (auto& b : ctx->scratch)
@@ -302,6 +308,10 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
   else if (!strcmp(name, "debug_lds_pad_kb")) ctx->debug_lds_pad_kb = value >= -40 && value <= 16 ? (int)value : 0;
   else if (!strcmp(name, "debug_gform")) ctx->debug_gform = (int)value;
   else if (!strcmp(name, "gform_wave_tables")) ctx->gform_wave_tables = value != 0;
+  else if (!strcmp(name, "gform_chunks")) {
+    if (!(value >= 1 && value <= 32)) { ldsim_set_error("gform_chunks must be in [1, 32]"); return LDSIM_EINVAL; }
+    ctx->gform_chunks = (int)value;
+  }
   else if (!strcmp(name, "fee_one_class")) ctx->fee_one_class = value != 0;
   else if (!strcmp(name, "split_kernels")) ctx->split_kernels = value != 0;
   else if (!strcmp(name, "wbuf_doubles_per_pair")) { ctx->wbuf_doubles_per_pair = (int)value; ctx->wbuf_learned = 0; }

@@ -151,6 +151,9 @@ struct ldsim_ctx {
   int debug_lds_pad_kb = 0;                  // timing tools: KB taken off the LDS budget of gcorr_kernel's small class
   long long frac_clean_gen = -1;             // out_gen of the output set whose dense fractions array has been completed with zeros
   int fee_one_class = 0;                     // option: 1 = pixel_adc_kernel with 256 threads and the whole tick axis for every pixel (A/B checks)
+  int gform_chunks = 1;                      // tables and correlation of the node-separable form in this many pair ranges, the tables of range c + 1 on a second stream beside the correlation of range c (1: one after the other)
+  hipStream_t tab_stream = nullptr;          // that second stream, and its per-range events
+  hipEvent_t tab_ev[34] = {};
   int gform_wave_tables = 1;                 // 1: gtables_wave_kernel (a wave per pair) for the pairs that fit it, 0: gtables_kernel for all
   int debug_gform = 0;                       // timing tools: parts of gtables_kernel / gcorr_kernel switched off (tools/gform_phases.py)
   int split_kernels = 1;            // 1: weights_kernel + mac_kernel (default), 0: monolithic current_kernel

@@ -817,6 +817,33 @@ def test_chain_run_async_equals_run():
         ch.wait()
 
 
+@pytest.mark.parametrize("cfg", ["module0", "ndlar"])
+def test_chain_in_pair_ranges_on_two_streams_same_bits(cfg):
+    """Option gform_chunks: tables and correlation of the node-separable form in K pair ranges, the tables of range c + 1 on a second
+    stream beside the correlation of range c (measured: no faster, the default stays 1).  Same results bit for bit as the plain
+    order, for a K that divides the pairs unevenly and with listed pairs (wide wave tables, larger LDS classes) in the launch."""
+    H.load_cfg(cfg)
+    seg = synth.make_segments(20000, seed=9, segs_per_event=2500)
+    batching.swap_coordinates(seg)
+    bid, order, table = batching.assign_batches(seg)
+    seg, bid = seg[order], bid[order]
+    ch = ChargeChain(synth.make_response("survey"))
+    ch.upload(seg, bid)
+    ch.quench_drift()
+    try:
+        ch.run(0, len(seg), want_fractions=True)
+        good = ch.download()
+        for K in (3, 7):
+            lib.set_option("gform_chunks", K)
+            st = ch.run(0, len(seg), want_fractions=True)
+            out = ch.download()
+            assert st.n_pairs > 4096 * K
+            for k in good:
+                assert np.array_equal(good[k], out[k]), (K, k)
+    finally:
+        lib.set_option("gform_chunks", 1)
+
+
 def test_chain_with_nothing_to_simulate():
     """Launches that yield no (segment, pixel) pair at all -- every midpoint outside the TPCs (pixel_plane = 0xBEEF,
     drifting.py:34-39), and an empty segment range -- return empty results instead of launching zero-sized grids."""
