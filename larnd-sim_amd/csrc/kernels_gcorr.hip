@@ -27,8 +27,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
 static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padded to whole prefetch rounds");
 
-#define GT 128           // threads of a gcorr workgroup: two waves per pair, twice the pairs in flight per CU of a four-wave one
-#define GW 2             //   (the kernel waits on a chain of dependent latencies: DESIGN.md section 4, profiles/r03_occupancy*.log)
+#ifndef GCORR_WAVES
+#define GCORR_WAVES 2
+#endif
+#define GW GCORR_WAVES   // waves of a gcorr workgroup = per pair: 2 (twice the pairs in flight per CU of round 3's four-wave one), or 1 (build with
+#define GT (64 * GW)     //   -DGCORR_WAVES=1: the whole pair in one wave, half the LDS per pair -- an experiment)
 
 // LDS of a pair, carved from the dynamic block by its real dimensions (a typical pair needs 12 KB; sized for the caps it would
 // be 54 KB and two pairs per CU).  Size classes: pairs that fit the first budget run 10 - 12 per CU (measured,
@@ -180,6 +183,13 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
           asm volatile("" : "+v"(tid_l));
           const int n = tid_l >> 3, c8 = tid_l & 7;
           const bool row = n < rows;
+#if GW == 1
+          // one wave: 8 rows per pass -- rows n and n + 8 are both requested before the first store
+          const int nb_ = n + 8;
+          const bool rowb = nb_ < rows;
+          double xb0 = 0, xb1 = 0, yb0 = 0, yb1 = 0;
+          unsigned ce2 = 0, ce3 = 0;
+#endif
           double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
           double2 z0 = {0, 0}, z1 = {0, 0}, z2 = {0, 0}, z3 = {0, 0};
           unsigned ce0 = 0, ce1 = 0;
@@ -194,6 +204,17 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             x1 = xr[min(c8 + 8, ncol - 1)];
             y0 = yr[min(c8, NJ - 1)];
             y1 = yr[min(c8 + 8, NJ - 1)];
+#if GW == 1
+            {
+              const int nnb = min(nb_, rows - 1);
+              const double* xrb = gX + nnb * ncol;
+              const double* yrb = gY + nnb * NJ;
+              xb0 = xrb[min(c8, ncol - 1)];
+              xb1 = xrb[min(c8 + 8, ncol - 1)];
+              yb0 = yrb[min(c8, NJ - 1)];
+              yb1 = yrb[min(c8 + 8, NJ - 1)];
+            }
+#endif
             if (z_lds) {
               const double* zr = gZ + nn * NUr + 2 * c8;                 // (NUr is a multiple of 16)
               z0 = *(const double2*)zr;
@@ -204,6 +225,10 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
           }
           ce0 = (unsigned)cells[G_CELL0 + min(tid_l, cell_cap - 1)];
           ce1 = (unsigned)cells[G_CELL0 + min(tid_l + GT, cell_cap - 1)];
+#if GW == 1
+          ce2 = (unsigned)cells[G_CELL0 + min(tid_l + 2 * GT, cell_cap - 1)];
+          ce3 = (unsigned)cells[G_CELL0 + min(tid_l + 3 * GT, cell_cap - 1)];
+#endif
           const int ncell_l = cells[0], nreal_l = cells[1];
           auto info_word = [&](unsigned ce) {
             const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
@@ -214,28 +239,61 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
             if (c8 + 8 < ncol) s_X[n * xs + c8 + 8] = row ? x1 : 0.0;
             if (c8 < NJ) s_Y[n * ys + c8] = row ? y0 : 0.0;
             if (c8 + 8 < NJ) s_Y[n * ys + c8 + 8] = row ? y1 : 0.0;
+#if GW == 1
+            if (c8 < ncol) s_X[nb_ * xs + c8] = rowb ? xb0 : 0.0;
+            if (c8 + 8 < ncol) s_X[nb_ * xs + c8 + 8] = rowb ? xb1 : 0.0;
+            if (c8 < NJ) s_Y[nb_ * ys + c8] = rowb ? yb0 : 0.0;
+            if (c8 + 8 < NJ) s_Y[nb_ * ys + c8 + 8] = rowb ? yb1 : 0.0;
+#endif
             if (z_lds) {
               double* zd = s_Z + n * zs + 2 * c8;
               zd[0] = row ? z0.x : 0.0; zd[1] = row ? z0.y : 0.0;
               if (NUr > 16) { zd[16] = row ? z1.x : 0.0; zd[17] = row ? z1.y : 0.0; }
               if (NUr > 32) { zd[32] = row ? z2.x : 0.0; zd[33] = row ? z2.y : 0.0; }
               if (NUr > 48) { zd[48] = row ? z3.x : 0.0; zd[49] = row ? z3.y : 0.0; }
+#if GW == 1
+              for (int cc = 2 * c8; cc < min(NUr, 64); cc += 16) {      // (rows 8 .. 15: the plain loop -- Z is staged in the larger classes only)
+                double2 v = {0.0, 0.0};
+                if (rowb) v = *(const double2*)(gZ + nb_ * NUr + cc);
+                s_Z[nb_ * zs + cc] = v.x;
+                s_Z[nb_ * zs + cc + 1] = v.y;
+              }
+#endif
             }
             for (int cc = c8 + 16; cc < ncol; cc += 8) s_X[n * xs + cc] = row ? gX[n * ncol + cc] : 0.0;
             for (int cc = c8 + 16; cc < NJ; cc += 8) s_Y[n * ys + cc] = row ? gY[n * NJ + cc] : 0.0;
+#if GW == 1
+            for (int cc = c8 + 16; cc < ncol; cc += 8) s_X[nb_ * xs + cc] = rowb ? gX[nb_ * ncol + cc] : 0.0;
+            for (int cc = c8 + 16; cc < NJ; cc += 8) s_Y[nb_ * ys + cc] = rowb ? gY[nb_ * NJ + cc] : 0.0;
+#endif
             if (z_lds)
               for (int cc = 2 * c8 + 64; cc < NUr; cc += 16) {
                 double2 v = {0.0, 0.0};
                 if (row) v = *(const double2*)(gZ + n * NUr + cc);
                 s_Z[n * zs + cc] = v.x;
                 s_Z[n * zs + cc + 1] = v.y;
+#if GW == 1
+                double2 vb = {0.0, 0.0};
+                if (rowb) vb = *(const double2*)(gZ + nb_ * NUr + cc);
+                s_Z[nb_ * zs + cc] = vb.x;
+                s_Z[nb_ * zs + cc + 1] = vb.y;
+#endif
               }
           }
           if (c8 == 0) s_X[n * xs + ncol] = 0.0;
+#if GW == 1
+          if (c8 == 0) s_X[nb_ * xs + ncol] = 0.0;
+#endif
           // (only the list's padded count of entries: behind it sits the repeated head, written below by other threads)
           if (tid_l < ncell_l) s_info[tid_l] = info_word(ce0);
           if (tid_l + GT < ncell_l) s_info[tid_l + GT] = info_word(ce1);
+#if GW == 1
+          if (tid_l + 2 * GT < ncell_l) s_info[tid_l + 2 * GT] = info_word(ce2);
+          if (tid_l + 3 * GT < ncell_l) s_info[tid_l + 3 * GT] = info_word(ce3);
+          for (int i = tid_l + 4 * GT; i < ncell_l; i += GT) s_info[i] = info_word((unsigned)cells[G_CELL0 + i]);
+#else
           for (int i = tid_l + 2 * GT; i < ncell_l; i += GT) s_info[i] = info_word((unsigned)cells[G_CELL0 + i]);
+#endif
           // the list's first G_WRAP = 24 words once more behind its end (it holds a multiple of 16, at least 16): the look-ahead of
           // the G loop reads straight on instead of wrapping its group index -- three compare / select pairs per index and slot,
           // ~20 scalar instructions per cell group.  (Thread t < 24 holds word t already.)
@@ -355,7 +413,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
       // three tile pairs) is shared: each wave multiplies it with half of the cell groups, and both run the P step and the edge
       // column on their partial G -- every step after G is linear in it, and the two tick arrays are added anyway.  [Dealt whole,
       // one wave ran two tile pairs while the other waited at the barrier with one: a sixth of a wave's life by the cycle stamps.]
-      const int n_whole = (GA.dbg & 256) ? n32 : (n32 & ~1);
+      const int n_whole = (GW == 1 || (GA.dbg & 256)) ? n32 : (n32 & ~1);        // (one wave: every tile pair is its own)
       const int rounds = ngrp / GPF;
       for (int kt = wv; run_tiles; kt += GW) {
         int g_lo = 0, g_hi = ngrp;
@@ -458,7 +516,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
     for (int i = tid; i < wlen; i += GT) {
       const int it = sup0 + i;
       if (it < A.T && !(GA.dbg & 8)) {
-        const double v = s_out[i] + s_out[TT + i];
+        const double v = GW == 2 ? s_out[i] + s_out[TT + i] : s_out[i];
         out[it] = (it >= it0 && it < T) ? (float)v : 0.f;
       }
     }
@@ -595,7 +653,7 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
   // instead of seven, Z read from the record where it no longer fits: 92.3 -> 83.1 ms per 50 k segments on the dense table, 87 at 18 KB, 85 at
   // 16 KB, 97 at 15 KB (tools/lds_b1_sweep_dense.py, profiles/r04_gcorr_lds_b1_dense.log); ndlar's (M = 2) optimum stays above 22 KB.]
   const int Mz = M | ((ctx->debug_gform & 1024) ? 16 : 0);
-  const int b0 = (M == 1 ? 12288 : 16384) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : (M == 1 && TT >= 512 ? 17408 : 22528), b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, Mz).bytes;
+  const int b0 = (GW == 1 ? (M == 1 ? 7168 : 10240) : (M == 1 ? 12288 : 16384)) - ctx->debug_lds_pad_kb * 1024, b1 = ctx->debug_lds_b1_kb > 0 ? ctx->debug_lds_b1_kb * 1024 : (GW == 1 ? (M == 1 ? 12288 : 16384) : (M == 1 && TT >= 512 ? 17408 : 22528)), b2 = g_lds_layout(G_NCOL, NJ_MAX, G_NUCAP, TT, 1 << 30, Mz).bytes;
   int32_t* d_big = (int32_t*)(d_total + 8);        // [2][n]
   int32_t* d_wg = d_big + 2 * n;                   // the pairs the tables stage gives to its workgroup kernel
   HIPCHK(hipMemsetAsync(d_total + 1, 0, 56, st));
