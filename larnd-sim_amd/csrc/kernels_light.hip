@@ -884,7 +884,9 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
   DevBuf* T = ctx->light_tmp;
   int rc;
   const double tick_size = ctx->h_consts.light_tick_size;
-  if (!sorted_idx && max_truth <= 64 && tick_bits + det_bits <= 31 && n_rec_out) {
+  const int tick_bits_c = bits_for(n_ticks + 1);        // compact form: the all-ones tick is no tick, it marks the unused record slots
+  if (!sorted_idx && max_truth <= 64 && tick_bits_c + det_bits <= 31 && n_rec_out) {
+    const int tick_bits = tick_bits_c;
     // ---- resident sum, compact form (kernels above): pairs with photons -> visiting order -> records by wave -> cells -> replay ----
     const int cap = (ctx->h_consts.enable_lut_smearing ? ctx->lut_nprof : 1) + LIGHT_SPARE;
     if ((rc = ldsim_ensure_buf(ctx, &T[1], 64))) return rc;                        // [0] pairs with photons
@@ -925,7 +927,10 @@ int light_launch_sum(ldsim_ctx* ctx, int64_t seg0, int64_t n, const int32_t* vox
     hipLaunchKernelGGL(light_emit_wave_kernel, dim3(nblk(n_act, 4)), dim3(256), 0, st, L, (const int32_t*)T[6].p, n_act, cap, tick_bits,
                        k0, v0, ctx->light_flag_dev);
     HIPCHK(hipGetLastError());
-    if ((rc = sort_pairs_u32_u64(ctx, k0, k1, v0, v1, n_slots, tick_bits + det_bits + 1))) return rc;      // (+ 1: the unused slots' bit)
+    // The records leave the emit kernel detector after detector: a STABLE sort on the tick bits alone puts a (detector, tick) cell's
+    // records side by side -- tick-major, detectors ascending inside a tick -- in their order of emission, in two radix passes for up
+    // to 65 535 ticks instead of the three or four over (detector, tick); the unused slots (tick bits all ones) gather at the end.
+    if ((rc = sort_pairs_u32_u64(ctx, k0, k1, v0, v1, n_slots, tick_bits))) return rc;
     ctx->light_lazy_tick_bits = tick_bits;
     hipLaunchKernelGGL(light_replay_wave_kernel, dim3(nblk(n_slots, RW_BLOCK)), dim3(64), 0, st, k1, v1, n_slots, tick_bits, tick_size,
                        track_id, n_ticks, ctx->h_consts.mc_truth_threshold, out, true_id, true_ph, max_truth, 1);
