@@ -17,6 +17,7 @@ int sort_make_keys(ldsim_ctx*, const int32_t*, const int32_t*, int64_t, int32_t,
                    int32_t*, unsigned long long*);
 int sort_pairs(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t);
 int sort_pairs_bits(ldsim_ctx*, unsigned long long*, unsigned long long*, int32_t*, int32_t*, int64_t, int, int);
+int sort_compact_valid(ldsim_ctx*, const unsigned long long*, int64_t, unsigned long long*, int32_t*, unsigned int*);
 int sort_exclusive_scan_i32(ldsim_ctx*, const int32_t*, int32_t*, int64_t);
 int sort_heads(ldsim_ctx*, const unsigned long long*, int64_t, int32_t*);
 int sort_fill_unique(ldsim_ctx*, const unsigned long long*, const int32_t*, const int32_t*, int64_t, int32_t, int32_t*,
@@ -311,18 +312,24 @@ int chain_run(ldsim_ctx* ctx, int64_t seg_begin, int64_t seg_end, int want_fract
   int32_t* d_vals = (int32_t*)ctx->scratch[SB_VALS].p;
   int32_t* d_vals2 = (int32_t*)ctx->scratch[SB_VALS2].p;
   CK(sort_make_keys(ctx, d_neigh, d_nrad, seg_begin, batch0, P, n_entries, d_keys, d_vals, counters));
-  {
-    // key = batch << 36 | pixel << 4 | ring code, ~0 for an empty slot: the bits above the launch's batch count are zero in every
-    // valid key and one in the empty ones, so the sort stops one bit above them (20 batches: 42 bits, six 8-bit passes instead of eight)
-    int bb = 0;
-    while ((1ll << bb) < n_batches) bb++;
-    CK(sort_pairs_bits(ctx, d_keys, d_keys2, d_vals, d_vals2, n_entries, 0, 36 + bb + 1));
-  }
+  // The empty slots (key ~0: three quarters of the entries of the module0 bench) are dropped before the sort -- a stable compaction, so
+  // equal keys keep the order of their entries -- and the count comes back with the per-batch tick counts, before the sort instead
+  // of after it.
+  CK(sort_compact_valid(ctx, d_keys, n_entries, d_keys2, d_vals2, (unsigned int*)(misc + 64)));      // (its count: a word of its own; the launch uses counters[4])
   unsigned long long n_valid_ull = 0;
   std::vector<int32_t> h_tmax(n_batches);
   HIPCHK(hipMemcpyAsync(&n_valid_ull, &counters[4], 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(h_tmax.data(), d_tmax_b, n_batches * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  {
+    // key = batch << 36 | pixel << 4 | ring code: the sort stops above the launch's batch count (20 batches: 41 bits, six 8-bit passes
+    // instead of eight)
+    int bb = 0;
+    while ((1ll << bb) < n_batches) bb++;
+    CK(sort_pairs_bits(ctx, d_keys2, d_keys, d_vals2, d_vals, (int64_t)n_valid_ull, 0, 36 + bb));
+    std::swap(d_keys, d_keys2);         // (d_keys2 / d_vals2: the sorted list, as below)
+    std::swap(d_vals, d_vals2);
+  }
   const int64_t n_valid = (int64_t)n_valid_ull;
   ctx->stats.n_pairs = n_valid;
   int32_t T = 0;

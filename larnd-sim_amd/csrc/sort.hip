@@ -155,6 +155,34 @@ int sort_pairs(ldsim_ctx* ctx, unsigned long long* keys_in, unsigned long long* 
   return 0;
 }
 
+// The valid entries of make_keys_kernel's arrays (key != ~0) in their order of appearance: keys -> keys_out, their indices ->
+// vals_out, their number -> *d_count (a device word).  Two stable rocPRIM selects; the pair-list sort then runs over the valid
+// entries only (a quarter of the (segment, neighbour slot) entries of the module0 bench) and equal keys keep the entry order they
+// had among all entries.
+namespace {
+struct KeyValid {
+  __device__ bool operator()(const unsigned long long& k) const { return k != ~0ull; }
+};
+struct KeyFlag {
+  __device__ unsigned char operator()(const unsigned long long& k) const { return k != ~0ull ? 1 : 0; }
+};
+}  // namespace
+int sort_compact_valid(ldsim_ctx* ctx, const unsigned long long* keys_in, int64_t n, unsigned long long* keys_out, int32_t* vals_out,
+                       unsigned int* d_count) {
+  if (n == 0) return 0;
+  auto flags = rocprim::make_transform_iterator(keys_in, KeyFlag());
+  rocprim::counting_iterator<int32_t> idx(0);
+  size_t t1 = 0, t2 = 0;
+  HIPCHK(rocprim::select(nullptr, t1, keys_in, keys_out, d_count, (size_t)n, KeyValid(), ctx->stream));
+  HIPCHK(rocprim::select(nullptr, t2, idx, flags, vals_out, d_count, (size_t)n, ctx->stream));
+  int rc = ldsim_ensure(ctx, SB_SORTTMP, t1 > t2 ? t1 : t2);
+  if (rc) return rc;
+  t1 = t2 = ctx->scratch[SB_SORTTMP].bytes;
+  HIPCHK(rocprim::select(ctx->scratch[SB_SORTTMP].p, t1, keys_in, keys_out, d_count, (size_t)n, KeyValid(), ctx->stream));
+  HIPCHK(rocprim::select(ctx->scratch[SB_SORTTMP].p, t2, idx, flags, vals_out, d_count, (size_t)n, ctx->stream));
+  return 0;
+}
+
 // the same over the key bits [begin_bit, end_bit) only (a pass per 8 bits)
 int sort_pairs_bits(ldsim_ctx* ctx, unsigned long long* keys_in, unsigned long long* keys_out, int32_t* vals_in, int32_t* vals_out,
                     int64_t n, int begin_bit, int end_bit) {
