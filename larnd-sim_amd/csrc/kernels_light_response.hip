@@ -122,6 +122,24 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
       const bool inside = w_i0 + 63 < T && jb >= max(w_i0 + 63 - C, 0) && jb + nb64 - 1 <= w_i0;
       if (inside && !m_truth) {
         const double* wl = s_w + (i - jb) - n_lo;
+        if (todo == ~0ull) {
+          // all 64 ticks of the block (the SiPM stage, and lit stretches of the scintillation stage): lane numbers and weight
+          // offsets are constants -- no bit scan, no address arithmetic per term; what is left is the sample, the weight and the
+          // three dependent operations of the f4 sum (5-6 instructions per term instead of ~12)
+#pragma unroll
+          for (int t8 = 0; t8 < 64; t8 += 8) {
+            double w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w8[u] = wl[-(t8 + u)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_l), t8 + u));
+              if (RESPONSE && !premul) acc = (float)((double)acc + g * w8[u] * (double)xv);
+              else acc = (float)((double)acc + w8[u] * (double)xv);
+            }
+          }
+          continue;
+        }
         for (; todo; todo &= todo - 1) {
           const int t = __ffsll((long long)todo) - 1;
           const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_l), t));
