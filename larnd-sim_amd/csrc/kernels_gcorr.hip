@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -72,8 +73,11 @@ __host__ __device__ __forceinline__ int g_lds_class(int ncol, int NJ, int NU, in
   return g_lds_layout(ncol, NJ, NU, TT, b1, M).bytes <= b1 ? 1 : 2;
 }
 
-template <int M>
-__global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
+// QB: the G products of a batch of at most 12 nodes by 4-node blocks (v_mfma_f64_4x4x4, below).  Four loop variants in one kernel
+// cost registers (37 spilled VGPRs at the 80 of the launch over all pairs: 5.25 -> 6.8 ms per 50 k): the variant is compiled for the
+// listed launches of the larger LDS classes only, where at most nine pairs fit a CU and 128 VGPRs cost one of them.
+template <int M, bool QB>
+__global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(GArgs GA, int TT, int b0, int b1, int b2, const int32_t* __restrict__ big_list,
                                                       int cls, int pair0) {
   const CurArgs& A = GA.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
   const int edge_k[NEDGE] = {GA.edge_k[0], GA.edge_k[1], GA.edge_k[2]};
   const int kk = lane >> 4, jj = lane & 15;
   const int nkp = GA.nkp;
-  unsigned long long n_mfma = 0, n_useful = 0;
+  unsigned long long n_mfma = 0, n_mfma4 = 0, n_useful = 0;      // 16x16x4 products, 4x4x4 (4-block) products, algorithmic FMAs
   int loaded = -1;
 
   for (int sup0 = it_w0; sup0 < it_w1; sup0 += TT) {
@@ -435,39 +439,123 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
         const double* rpl = GA.resp_pad + RESP_PAD + k0 + (M == 2 ? 2 * jj : jj);
         constexpr int B1 = M == 2 ? 1 : 16;
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        double b0[GPF], b1[GPF], xv[2], yv[2];
-        unsigned lo[2], hi[2];
+        // G of the wave's two tiles over the cell groups [g_lo, g_hi).  NRB = 4: the 16-node product v_mfma_f64_16x16x4 (64 cycles per
+        // tile and group).  NRB = 1 .. 3 (QB kernels, a batch of at most 4 NRB nodes): per node block of four one
+        // v_mfma_f64_4x4x4_4b (17 cycles: four 4-node x 4-tick blocks = the tile's 16 ticks) -- its A operand the block's X Y in every
+        // tick block (lane 16 k + 4 b + i <- node 4 rb + i, cell k; LDS reads of one address broadcast; CBSZ / ABID do nothing on
+        // the f64 form, tools/micro/mfma_f64_4x4_bcast.hip), its B operand the very register of the 16-node form (lane 16 k + tick),
+        // its result (lane 16 i + 4 b + j) in the layout the P step's B operand wants: register rb of the accumulator, like the
+        // 16-node form's.  17 NRB cycles instead of 64.
+        auto gprod = [&](auto nrb_tag) {
+          constexpr int NRB = decltype(nrb_tag)::value;
+          constexpr bool Q = NRB < 4;
+          constexpr int NA = Q ? NRB : 1;
+          const char* xb = Q ? (const char*)(s_X + (lane & 3) * xs) : xl;
+          const char* yb = Q ? (const char*)(s_Y + (lane & 3) * ys) : yl;
+          const int xstep = 4 * xs * 8, ystep = 4 * ys * 8;      // bytes from a node block to the next
+          double g0[NA], g1[NA], xv[NA], yv[NA], b0[GPF], b1[GPF];
 #pragma unroll
-        for (int u = 0; u < GPF; u++) {
-          const double* q = rpl + row_word(g_lo + u);
-          b0[u] = q[0];
-          b1[u] = q[B1];
-        }
-        lo[0] = row_word(g_lo + GPF);
-        hi[0] = col_word(g_lo);
-        hi[1] = col_word(g_lo + 1);
-        xv[0] = *(const double*)(xl + (hi[0] & 0xFFFFu));
-        yv[0] = *(const double*)(yl + (hi[0] >> 16));
-        if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-        for (int g0 = g_lo; g0 < g_hi; g0 += GPF) {
+          for (int r = 0; r < NA; r++) g0[r] = g1[r] = 0.0;
+          unsigned lo[2], hi[2];
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
-            const double a = xv[u & 1] * yv[u & 1];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
-            const double* q = rpl + lo[u & 1];
+            const double* q = rpl + row_word(g_lo + u);
             b0[u] = q[0];
             b1[u] = q[B1];
-            lo[(u + 1) & 1] = row_word(g0 + u + GPF + 1);
-            xv[(u + 1) & 1] = *(const double*)(xl + (hi[(u + 1) & 1] & 0xFFFFu));
-            yv[(u + 1) & 1] = *(const double*)(yl + (hi[(u + 1) & 1] >> 16));
-            hi[u & 1] = col_word(g0 + u + 2);
-            __builtin_amdgcn_sched_barrier(0);
           }
+          lo[0] = row_word(g_lo + GPF);
+          hi[0] = col_word(g_lo);
+          hi[1] = col_word(g_lo + 1);
+#pragma unroll
+          for (int r = 0; r < NA; r++) {
+            xv[r] = *(const double*)(xb + r * xstep + (hi[0] & 0xFFFFu));
+            yv[r] = *(const double*)(yb + r * ystep + (hi[0] >> 16));
+          }
+          if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+          for (int g0i = g_lo; g0i < g_hi; g0i += GPF) {
+#pragma unroll
+            for (int u = 0; u < GPF; u++) {
+              double a[NA];
+#pragma unroll
+              for (int r = 0; r < NA; r++) a[r] = xv[r] * yv[r];
+              // (X and Y of the next group: their registers are free once the products above exist; the matrix instructions below
+              // cover the LDS latency)
+#pragma unroll
+              for (int r = 0; r < NA; r++) {
+                xv[r] = *(const double*)(xb + r * xstep + (hi[(u + 1) & 1] & 0xFFFFu));
+                yv[r] = *(const double*)(yb + r * ystep + (hi[(u + 1) & 1] >> 16));
+              }
+              if constexpr (Q) {
+#pragma unroll
+                for (int r = 0; r < NA; r++) {
+                  g0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[r], b0[u], g0[r], 0, 0, 0);
+                  g1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[r], b1[u], g1[r], 0, 0, 0);
+                }
+              } else {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b1[u], acc1, 0, 0, 0);
+              }
+              const double* q = rpl + lo[u & 1];
+              b0[u] = q[0];
+              b1[u] = q[B1];
+              lo[(u + 1) & 1] = row_word(g0i + u + GPF + 1);
+              hi[u & 1] = col_word(g0i + u + 2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if constexpr (Q) {
+#pragma unroll
+            for (int r = 0; r < NA; r++) { acc0[r] = g0[r]; acc1[r] = g1[r]; }
+            n_mfma4 += 2 * NA * (g_hi - g_lo);
+          } else {
+            n_mfma += 2 * (g_hi - g_lo);
+          }
+        };
+        if constexpr (QB) {
+          switch (rows >> 2) {
+            case 1: gprod(std::integral_constant<int, 1>{}); break;
+            case 2: gprod(std::integral_constant<int, 2>{}); break;
+            case 3: gprod(std::integral_constant<int, 3>{}); break;
+            default: gprod(std::integral_constant<int, 4>{}); break;
+          }
+        } else {
+          // (the launch over all pairs: the 16-node product alone, X and Y two registers deep -- the form that fits 80 VGPRs)
+          double b0[GPF], b1[GPF], xv[2], yv[2];
+          unsigned lo[2], hi[2];
+#pragma unroll
+          for (int u = 0; u < GPF; u++) {
+            const double* q = rpl + row_word(g_lo + u);
+            b0[u] = q[0];
+            b1[u] = q[B1];
+          }
+          lo[0] = row_word(g_lo + GPF);
+          hi[0] = col_word(g_lo);
+          hi[1] = col_word(g_lo + 1);
+          xv[0] = *(const double*)(xl + (hi[0] & 0xFFFFu));
+          yv[0] = *(const double*)(yl + (hi[0] >> 16));
+          if (stamps) ts_mark = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+          for (int g0 = g_lo; g0 < g_hi; g0 += GPF) {
+#pragma unroll
+            for (int u = 0; u < GPF; u++) {
+              const double a = xv[u & 1] * yv[u & 1];
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
+              const double* q = rpl + lo[u & 1];
+              b0[u] = q[0];
+              b1[u] = q[B1];
+              lo[(u + 1) & 1] = row_word(g0 + u + GPF + 1);
+              xv[(u + 1) & 1] = *(const double*)(xl + (hi[(u + 1) & 1] & 0xFFFFu));
+              yv[(u + 1) & 1] = *(const double*)(yl + (hi[(u + 1) & 1] >> 16));
+              hi[u & 1] = col_word(g0 + u + 2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          n_mfma += 2 * (g_hi - g_lo);
         }
-        n_mfma += 2 * (g_hi - g_lo);
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_g += t - ts_mark; ts_mark = t; }
         if (!(A.debug_phases & 0x200000)) {
           pstep2(acc0, acc1, k0);
@@ -539,7 +627,7 @@ __global__ void __launch_bounds__(GT, (M == 1 ? 6 : 5)) gcorr_kernel(GArgs GA, i
     stat_add(A.counters, 15, t - ts0);
   }
   if (GA.dbg & 1) return;
-  if (lane == 0 && n_mfma) stat_add(A.counters, 5, n_mfma * 1024ull);
+  if (lane == 0 && (n_mfma | n_mfma4)) stat_add(A.counters, 5, n_mfma * 1024ull + n_mfma4 * 256ull);
   if (tid == 0 && n_useful) stat_add(A.counters, 8, n_useful);
 }
 
@@ -707,8 +795,11 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
     if (count <= 0) return 0;
     const int32_t* list = cls == 0 ? nullptr : d_big + (int64_t)(cls - 1) * n;
     const size_t dyn = (size_t)(cls == 0 ? b0 : (cls == 1 ? b1 : b2));
-    if (M == 1) hipLaunchKernelGGL(gcorr_kernel<1>, dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
-    else hipLaunchKernelGGL(gcorr_kernel<2>, dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
+    const bool qb = cls > 0 && !(ctx->debug_gform & 4096);      // (debug_gform 4096: the 16-node product in every launch)
+    if (M == 1 && !qb) hipLaunchKernelGGL((gcorr_kernel<1, false>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
+    else if (M == 1) hipLaunchKernelGGL((gcorr_kernel<1, true>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
+    else if (!qb) hipLaunchKernelGGL((gcorr_kernel<2, false>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
+    else hipLaunchKernelGGL((gcorr_kernel<2, true>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
     HIPCHK(hipGetLastError());
     return 0;
   };

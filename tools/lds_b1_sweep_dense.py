@@ -15,7 +15,7 @@ ch.upload(seg, bid); ch.quench_drift()
 os.environ["LDSIM_DEBUG_GFORM"]="1"
 ch.run(0, len(seg), want_fractions=True)
 del os.environ["LDSIM_DEBUG_GFORM"]
-for pad, b1, dbg in ((0, 0, 0), (0, 0, 8192), (0, 13, 8192), (0, 14, 8192), (0, 15, 8192), (0, 17, 8192), (-2, 0, 8192), (0, 0, 0)):
+for pad, b1, dbg in ((0, 0, 0), (0, 18, 0), (0, 19, 0), (0, 20, 0), (0, 21, 0), (0, 22, 0), (0, 0, 0)):
     lib.set_option("debug_gform", dbg)
     lib.set_option("debug_lds_pad_kb", pad)
     lib.set_option("debug_lds_b1_kb", b1)
