@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
       // (g < ngrp + G_WRAP / 4: the list is repeated behind its end)
       // (the cell index bounded by the table's last row: a stray word must not become a stray address)
       const unsigned cell_last = (unsigned)(A.ni * A.nj - 1);
-      auto row_word = [&](int g) { return min(s_inf32[4 * g + kk] & 0xFFFu, cell_last) * (unsigned)nkp; };
+      const unsigned row_mask = (GA.dbg & 32768) ? 0u : 0xFFFu;      // (timing tools, debug_gform 32768: every cell reads response row 0 -- the B operands from L1)
+      auto row_word = [&](int g) { return min(s_inf32[4 * g + kk] & row_mask, cell_last) * (unsigned)nkp; };
       auto col_word = [&](int g) {
         const unsigned w = s_inf32[4 * g + kk];
         return ((w >> 9) & 0x1F8u) | (((w >> 15) & 0x1F8u) << 16);      // (col * 8) | (j * 8) << 16
