@@ -28,6 +28,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
 static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padded to whole prefetch rounds");
 
+// The timing switches of tools/gform_phases.py (debug_gform / debug_phases bits read inside gcorr_kernel) and its cycle stamps are
+// compiled in with -DLDSIM_GCORR_DEBUG only (make DEBUG_GCORR=1): every switch is a loop-invariant condition the compiler keeps in
+// two scalar registers, the kernel has more of those than registers, and a spilled one costs vector instructions -- which on
+// this part do not overlap with the f64 matrix instructions (SQ_VALU_MFMA_COEXEC_CYCLES = 0: their times add up to the kernel's).
+#ifdef LDSIM_GCORR_DEBUG
+#define GDBG(bit) ((GA.dbg & (bit)) != 0)
+#define GPHASE(bit) ((A.debug_phases & (bit)) != 0)
+#else
+#define GDBG(bit) false
+#define GPHASE(bit) false
+#endif
 #ifndef GCORR_WAVES
 #define GCORR_WAVES 2
 #endif
@@ -50,9 +61,11 @@ __host__ __device__ __forceinline__ GLds g_lds_layout(int ncol, int NJ, int NU, 
   L.ys = NJ | 1;                                     //   holds zeros (the weightless padding cells of the list point at it)
   const int nur = g_nur(NU);
   L.cellcap = (ncol * NJ + G_CELLPAD - 1) & ~(G_CELLPAD - 1);
-  // (one 32-bit word per listed cell since round 4: cell index | X column << 12 | Y row entry << 18 -- 64-bit words with the row's
-  // offset spelled out cost a KB per 256 cells, which is what kept the Z table of a typical pair out of LDS)
-  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys)) + 4 * (L.cellcap + G_WRAP) + 16;
+  // (two 32-bit words per listed cell, spelled out for the G loop: byte offset of the cell's response row | byte offsets of its X
+  // column and Y row entry.  For a while in round 4 it was ONE packed word, to make room for Z -- until the counters showed that f64
+  // matrix and vector instructions never execute together on this part (SQ_VALU_MFMA_COEXEC_CYCLES = 0) and their times ADD UP to the
+  // whole kernel: the ten vector instructions per cell group that unpacked the word cost more than Z read from the record)
+  const int rest = 8 * (GW * (TT + G_NODES) + G_NODES * (L.xs + L.ys)) + 8 * (L.cellcap + G_WRAP) + 16;
   // Z in LDS where the pair's budget has room for it; else (and for the steepest long segments, NU > G_NUCAP) the P step reads
   // it from the record: a pair never drops to the low-occupancy class because of its Z table
   // M = 1: == 16 mod 32, the four 16-shift runs of an A operand read conflict-free; M = 2 reads every other shift (one parity):
@@ -86,7 +99,13 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
   if (pair >= A.n_pairs) return;
   // timing tools (debug_gform 128): where a wave's residency goes, in shader cycles summed over the waves (counters 9 .. 15:
   // GInfo wait | table staging incl. its barriers | G loops | P steps | edge columns | final barrier + store | whole life)
+#ifdef LDSIM_GCORR_DEBUG
   const bool stamps = (GA.dbg & 128) != 0;
+#else
+  // (the stamps keep fourteen scalar registers alive through the whole kernel -- spilled ones cost vector instructions, and vector
+  // and f64 matrix instructions do not overlap on this part: built with -DLDSIM_GCORR_DEBUG for tools/gform_phases.py ... stamps)
+  constexpr bool stamps = false;
+#endif
   unsigned long long ts0 = 0, ts_stage = 0, ts_g = 0, ts_p = 0, ts_e = 0, ts_mark = 0;
   if (stamps) ts0 = __builtin_amdgcn_s_memtime();
   // The flag and the GInfo record in ONE round trip to memory: sixteen words requested back to back, and an empty asm statement
@@ -129,7 +148,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
     return;
   }
   const int NQ = gip->NQ, NB = gip->NB, ncol = gip->ncol, NJ = gip->NJ, u_min = gip->u_min, NU = gip->NU;
-  const int Mz = M | ((GA.dbg & 1024) ? 16 : 0);
+  const int Mz = M | (GDBG(1024) ? 16 : 0);
   if (g_lds_class(ncol, NJ, NU, TT, b0, b1, Mz) != cls) return;      // another launch's pair
   unsigned long long ts_info = 0;
   if (stamps) ts_info = __builtin_amdgcn_s_memtime();
@@ -147,7 +166,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
   double* s_Y = s_X + G_NODES * L.xs;               // [16][ys]
   double* s_Z = s_Y + G_NODES * L.ys;               // [16][zs]
   // per listed cell: response row offset (doubles into the padded table) | byte offsets of its X column and Y row << 32, << 48
-  unsigned* s_info = (unsigned*)(s_Z + G_NODES * L.zs);      // per listed cell: cell index | X column << 12 | Y row entry << 18
+  uint2* s_info = (uint2*)(s_Z + G_NODES * L.zs);            // per listed cell: {response row byte offset, X column byte offset | Y row entry byte offset << 16}
   __shared__ int s_ncell, s_nreal;
   const int xs = L.xs, ys = L.ys, zs = L.zs;
   double* ow = s_out + wv * TT;
@@ -197,7 +216,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
           double2 z0 = {0, 0}, z1 = {0, 0}, z2 = {0, 0}, z3 = {0, 0};
           unsigned ce0 = 0, ce1 = 0;
-          const bool stage = !(GA.dbg & 4);
+          const bool stage = !GDBG(4);
           if (stage) {
             // (unconditional loads from clamped, always valid addresses: a load under a per-lane condition is waited for at the
             // end of its branch, which serialises them again; the conditions are applied at the stores)
@@ -234,9 +253,12 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           ce3 = (unsigned)cells[G_CELL0 + min(tid_l + 3 * GT, cell_cap - 1)];
 #endif
           const int ncell_l = cells[0], nreal_l = cells[1];
+          // (timing tools, debug_gform 32768: every cell reads response row 0 -- the B operands from L1)
+          const unsigned cell_last_l = GDBG(32768) ? 0u : (unsigned)(A.ni * A.nj - 1), row_bytes = (unsigned)nkp * 8u;
           auto info_word = [&](unsigned ce) {
+            // (the cell index bounded by the table's last row: a stray word must not become a stray address)
             const unsigned col = (ce >> 31) ? (unsigned)ncol : ((ce >> 16) & 63u), jc = (ce >> 24) & 63u;
-            return (ce & 0xFFFu) | (col << 12) | (jc << 18);
+            return make_uint2(min(ce & 0xFFFFu, cell_last_l) * row_bytes, (col << 3) | (jc << 19));
           };
           if (stage) {
             if (c8 < ncol) s_X[n * xs + c8] = row ? x0 : 0.0;
@@ -318,7 +340,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
                     ((unsigned long long)s_nreal * (unsigned long long)(kB - kA + 1) + (unsigned long long)NU * (unsigned long long)wlen);
       // P[u][k] = sum_n Z[n][u] G[n][k]; out[(k - u_min - u) / M] += P[u][k] -- for both tiles of the wave at once: one A
       // operand (Z of the lane's shift and node) feeds two independent accumulation chains.
-      const bool no_sum = (GA.dbg & 16384) != 0;       // timing tools: the P products without their sums into the tick array
+      const bool no_sum = GDBG(16384);       // timing tools: the P products without their sums into the tick array
       auto pstep2 = [&](const d4& g0acc, const d4& g1acc, int k0) {
         auto zrow = [&](int st, double* za) {
 #pragma unroll
@@ -400,25 +422,18 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
       // group t + 2 (past the last group the indices wrap: valid, unused).  Every load is issued one slot (LDS) or GPF (L2) before
       // its use, no branch, and sched_barrier keeps the compiler from sinking them back to their uses.  [Prefetching the next tile
       // pair's first groups across the P step changed nothing: the loop runs at the rate the L1 delivers the B operands.]
-      const bool run_tiles = n32 > 0 && ngrp > 0 && !(A.debug_phases & 0x100000);
-      const unsigned* s_inf32 = s_info;
+      const bool run_tiles = n32 > 0 && ngrp > 0 && !GPHASE(0x100000);
       const char* xl = (const char*)(s_X + jj * xs);
       const char* yl = (const char*)(s_Y + jj * ys);
-      // row word: the cell's offset into the padded response table (doubles); column word: byte offsets of its X column and Y row entry
-      // (g < ngrp + G_WRAP / 4: the list is repeated behind its end)
-      // (the cell index bounded by the table's last row: a stray word must not become a stray address)
-      const unsigned cell_last = (unsigned)(A.ni * A.nj - 1);
-      const unsigned row_mask = (GA.dbg & 32768) ? 0u : 0xFFFu;      // (timing tools, debug_gform 32768: every cell reads response row 0 -- the B operands from L1)
-      auto row_word = [&](int g) { return min(s_inf32[4 * g + kk] & row_mask, cell_last) * (unsigned)nkp; };
-      auto col_word = [&](int g) {
-        const unsigned w = s_inf32[4 * g + kk];
-        return ((w >> 9) & 0x1F8u) | (((w >> 15) & 0x1F8u) << 16);      // (col * 8) | (j * 8) << 16
-      };
+      // row word: byte offset of the cell's row in the padded response table; column word: byte offsets of its X column and Y row
+      // entry -- both ready to add (g < ngrp + G_WRAP / 4: the list is repeated behind its end)
+      auto row_word = [&](int g) { return s_info[4 * g + kk].x; };
+      auto col_word = [&](int g) { return s_info[4 * g + kk].y; };
       // The tile pairs are dealt to the pair's two waves alternately; an odd one left over (the survey table's 82 staged ticks are
       // three tile pairs) is shared: each wave multiplies it with half of the cell groups, and both run the P step and the edge
       // column on their partial G -- every step after G is linear in it, and the two tick arrays are added anyway.  [Dealt whole,
       // one wave ran two tile pairs while the other waited at the barrier with one: a sixth of a wave's life by the cycle stamps.]
-      const int n_whole = (GW == 1 || (GA.dbg & 256)) ? n32 : (n32 & ~1);        // (one wave: every tile pair is its own)
+      const int n_whole = (GW == 1 || GDBG(256)) ? n32 : (n32 & ~1);        // (one wave: every tile pair is its own)
       const int rounds = ngrp / GPF;
       for (int kt = wv; run_tiles; kt += GW) {
         int g_lo = 0, g_hi = ngrp;
@@ -460,7 +475,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           unsigned lo[2], hi[2];
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
-            const double* q = rpl + row_word(g_lo + u);
+            const double* q = (const double*)((const char*)rpl + row_word(g_lo + u));
             b0[u] = q[0];
             b1[u] = q[B1];
           }
@@ -498,7 +513,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b0[u], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b1[u], acc1, 0, 0, 0);
               }
-              const double* q = rpl + lo[u & 1];
+              const double* q = (const double*)((const char*)rpl + lo[u & 1]);
               b0[u] = q[0];
               b1[u] = q[B1];
               lo[(u + 1) & 1] = row_word(g0i + u + GPF + 1);
@@ -527,7 +542,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           unsigned lo[2], hi[2];
 #pragma unroll
           for (int u = 0; u < GPF; u++) {
-            const double* q = rpl + row_word(g_lo + u);
+            const double* q = (const double*)((const char*)rpl + row_word(g_lo + u));
             b0[u] = q[0];
             b1[u] = q[B1];
           }
@@ -545,7 +560,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
               const double a = xv[u & 1] * yv[u & 1];
               acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[u], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1[u], acc1, 0, 0, 0);
-              const double* q = rpl + lo[u & 1];
+              const double* q = (const double*)((const char*)rpl + lo[u & 1]);
               b0[u] = q[0];
               b1[u] = q[B1];
               lo[(u + 1) & 1] = row_word(g0 + u + GPF + 1);
@@ -558,13 +573,13 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           n_mfma += 2 * (g_hi - g_lo);
         }
         if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_g += t - ts_mark; ts_mark = t; }
-        if (!(A.debug_phases & 0x200000)) {
+        if (!GPHASE(0x200000)) {
           pstep2(acc0, acc1, k0);
           if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ts_p += t - ts_mark; ts_mark = t; }
           // window edges: the share of the slices that are not valid at response index edge_k[e] comes off the tick it maps to,
           // sum_n Zi_e[n][u] G_n[edge_k[e]] per shift u.  The column of G sits in four lanes of this wave's accumulators
           // (register r of lane 16 q + col = G[4 r + q][k0 + col]): through LDS to all lanes, one shift per lane.
-          if (emask && !(GA.dbg & 2)) {
+          if (emask && !GDBG(2)) {
             int et = 0;
             for (int e = 0; e < NEDGE; e++) {
               if (!(ebound & (1 << e))) continue;
@@ -604,7 +619,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
     __syncthreads();
     for (int i = tid; i < wlen; i += GT) {
       const int it = sup0 + i;
-      if (it < A.T && !(GA.dbg & 8)) {
+      if (it < A.T && !GDBG(8)) {
         const double v = GW == 2 ? s_out[i] + s_out[TT + i] : s_out[i];
         out[it] = (it >= it0 && it < T) ? (float)v : 0.f;
       }
@@ -613,7 +628,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
   }
   if (A.win) {
     if (tid == 0) { A.win[2 * pair] = min(it_w0, A.T); A.win[2 * pair + 1] = min(it_w1, A.T); }
-  } else if (!(A.debug_phases & 0x10000000)) {    // (timing tools)
+  } else if (!GPHASE(0x10000000)) {    // (timing tools)
     for (int it = tid; it < A.T; it += GT)
       if (it < it_w0 || it >= it_w1) out[it] = 0.f;
   }
@@ -627,7 +642,7 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
     stat_add(A.counters, 14, t - ts_mark);
     stat_add(A.counters, 15, t - ts0);
   }
-  if (GA.dbg & 1) return;
+  if (GDBG(1)) return;
   if (lane == 0 && (n_mfma | n_mfma4)) stat_add(A.counters, 5, n_mfma * 1024ull + n_mfma4 * 256ull);
   if (tid == 0 && n_useful) stat_add(A.counters, 8, n_useful);
 }

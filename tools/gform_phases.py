@@ -1,4 +1,6 @@
-"""Where the time of gtables_kernel / gcorr_kernel goes, by switching parts off (results are wrong in those runs).
+"""[The switches and cycle stamps INSIDE gcorr_kernel (modes corr, stamps, share, zlds, psum, brow) need a library built with
+`make -C larnd-sim_amd/csrc DEBUG_GCORR=1`: the production build compiles them out -- they cost vector instructions.]
+Where the time of gtables_kernel / gcorr_kernel goes, by switching parts off (results are wrong in those runs).
 gcorr: 0x100000 no tile loop (prologue + combine + store), 0x200000 no P step, 0x400000 every cell reads response row 0,
 0x800000 no G products.  gtables: 0x1000000 stop after the sample maps, 0x2000000 no X / Y tables, 0x4000000 no Z tables,
 0x8000000 no cell list."""
