@@ -204,6 +204,18 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
           // hoisted out of the loops and spilled -- their reloads from scratch had put a wait in front of every load)
           int tid_l = tid;
           asm volatile("" : "+v"(tid_l));
+          // (and the batch's dimensions through one too: the conditions on them below -- NUr > 16, c8 < ncol ... -- are then
+          // evaluated here, scalar compares that cost nothing, instead of being hoisted as loop invariants into two scalar
+          // registers each, spilled at the top of the kernel and read back with v_readlane: vector instructions, which on this
+          // part are matrix time)
+          auto sc_ = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+          int rows_s = sc_(rows), ncol_s = sc_(ncol), NJ_s = sc_(NJ), NUr_s = sc_(NUr), zl_s = sc_(z_lds ? 1 : 0);
+          asm volatile("" : "+s"(rows_s), "+s"(ncol_s), "+s"(NJ_s), "+s"(NUr_s), "+s"(zl_s));
+#define rows rows_s
+#define ncol ncol_s
+#define NJ NJ_s
+#define NUr NUr_s
+#define z_lds (zl_s != 0)
           const int n = tid_l >> 3, c8 = tid_l & 7;
           const bool row = n < rows;
 #if GW == 1
@@ -328,6 +340,11 @@ __global__ void __launch_bounds__(GT, (QB ? 4 : (M == 1 ? 6 : 5))) gcorr_kernel(
             if (ncell_l == 16 && tid_l < 8) s_info[32 + tid_l] = info_word(ce0);
           }
           if (tid_l == 0) { s_ncell = ncell_l; s_nreal = nreal_l; }
+#undef rows
+#undef ncol
+#undef NJ
+#undef NUr
+#undef z_lds
         }
         loaded = b;
       }
@@ -811,7 +828,10 @@ extern "C++" int gform_launch(ldsim_ctx* ctx, const CurArgs& a, unsigned long lo
     if (count <= 0) return 0;
     const int32_t* list = cls == 0 ? nullptr : d_big + (int64_t)(cls - 1) * n;
     const size_t dyn = (size_t)(cls == 0 ? b0 : (cls == 1 ? b1 : b2));
-    const bool qb = cls > 0 && !(ctx->debug_gform & 4096);      // (debug_gform 4096: the 16-node product in every launch)
+    // (the 4-node-block kernel: the listed classes, and at M = 2 the launch over all pairs too -- 109 VGPRs, four waves per SIMD
+    // instead of five at 96: ndlar 12.33 -> 11.88 ms per 50 k; at M = 1 six waves at 80 VGPRs beat four: 4.93 against 5.67.
+    // debug_gform 4096: the 16-node product in every launch; 65536: the 4-node blocks in every launch)
+    const bool qb = (cls > 0 || M == 2 || (ctx->debug_gform & 65536)) && !(ctx->debug_gform & 4096);
     if (M == 1 && !qb) hipLaunchKernelGGL((gcorr_kernel<1, false>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
     else if (M == 1) hipLaunchKernelGGL((gcorr_kernel<1, true>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);
     else if (!qb) hipLaunchKernelGGL((gcorr_kernel<2, false>), dim3((unsigned)count), dim3(GT), dyn, st, GA, TT, b0, b1, b2, list, cls, (int)pair0);

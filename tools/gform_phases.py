@@ -34,6 +34,8 @@ RUNS = {"tables": ((0, 0, 0), (0x1000000, 0, 0), (0x2000000, 0, 0), (0x4000000, 
         "stamps": ((0, 0, 128), (0, 0, 0)),
         # the same for gtables_wave_kernel (debug_gform 2048)
         "tstamps": ((0, 0, 2048), (0, 0, 0)),
+        # the 4-node-block kernel (104 VGPRs, four waves per SIMD) also for the launch over all pairs (debug_gform 65536)
+        "qball": ((0, 0, 0), (0, 0, 65536), (0, 0, 0), (0, 0, 65536)),
         # every cell reads response row 0 (debug_gform 32768; results are wrong): what the G loop costs when its B operands come from L1
         "brow": ((0, 0, 0), (0, 0, 32768), (0, 0, 128), (0, 0, 128 + 32768)),
         # G by 4-node blocks in the launches of the larger LDS classes (default) against the 16-node product everywhere (debug_gform 4096)
