@@ -28,6 +28,17 @@
 //   JSTART[49]  first member of row jmin + k, then the count
 //   ZSH   [64]  response shift of slice iz_lo + k, minus u_min           ZINV [64]  window edges the slice is invalid at (bits)
 //   AMB   [1]   slices whose shift was a rounding tie (statistics)
+// The timing switches of tools/gform_phases.py (debug_gform / debug_phases bits read inside gcorr_kernel and gtables_wave_kernel) and their cycle stamps are
+// compiled in with -DLDSIM_GCORR_DEBUG only (make DEBUG_GCORR=1): every switch is a loop-invariant condition the compiler keeps in
+// two scalar registers, the kernel has more of those than registers, and a spilled one costs vector instructions -- which on
+// this part do not overlap with the f64 matrix instructions (SQ_VALU_MFMA_COEXEC_CYCLES = 0: their times add up to the kernel's).
+#ifdef LDSIM_GCORR_DEBUG
+#define GDBG(bit) ((GA.dbg & (bit)) != 0)
+#define GPHASE(bit) ((A.debug_phases & (bit)) != 0)
+#else
+#define GDBG(bit) false
+#define GPHASE(bit) false
+#endif
 #define G_MAP_NS 40
 #define G_MAPB 384
 #define G_MAP_XPOS 0

@@ -28,17 +28,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define GPF 4            // cell groups whose response loads are in flight ahead of the products of a wave (x 2 tiles)
 static_assert(G_CELLPAD % (4 * GPF) == 0 && GPF % 4 == 0, "the cell list is padded to whole prefetch rounds");
 
-// The timing switches of tools/gform_phases.py (debug_gform / debug_phases bits read inside gcorr_kernel) and its cycle stamps are
-// compiled in with -DLDSIM_GCORR_DEBUG only (make DEBUG_GCORR=1): every switch is a loop-invariant condition the compiler keeps in
-// two scalar registers, the kernel has more of those than registers, and a spilled one costs vector instructions -- which on
-// this part do not overlap with the f64 matrix instructions (SQ_VALU_MFMA_COEXEC_CYCLES = 0: their times add up to the kernel's).
-#ifdef LDSIM_GCORR_DEBUG
-#define GDBG(bit) ((GA.dbg & (bit)) != 0)
-#define GPHASE(bit) ((A.debug_phases & (bit)) != 0)
-#else
-#define GDBG(bit) false
-#define GPHASE(bit) false
-#endif
 #ifndef GCORR_WAVES
 #define GCORR_WAVES 2
 #endif

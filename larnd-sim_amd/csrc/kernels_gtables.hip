@@ -399,13 +399,17 @@ __global__ void __launch_bounds__(CUR_THREADS, 4) gtables_kernel(GArgs GA, const
 // it (wide diffusion or steep segments: a fifth of the ndlar pairs)
 
 template <int M, int XYS>
-__global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list, int pair0) {
+__global__ void __launch_bounds__(64, (XYS <= 55 ? 4 : 3)) gtables_wave_kernel(GArgs GA, const int32_t* __restrict__ list, int pair0) {
   const CurArgs& A = GA.c;
   constexpr int NUW = XYS <= 55 ? G_NUCAP : 2 * G_NUCAP;       // shifts of a pair this instantiation takes
   const int lane = threadIdx.x, u16 = lane & 15, q = lane >> 4;
   const int64_t pair = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x + pair0;      // (pair0: first pair of a range launch)
   if (pair >= A.n_pairs) return;
+#ifdef LDSIM_GCORR_DEBUG
   const bool stamps = (GA.dbg & 2048) != 0;      // timing tools: cycle stamps into the statistics stripes 9..15 (chain.hip prints them)
+#else
+  constexpr bool stamps = false;
+#endif
   unsigned long long ts0 = 0, ts_a = 0, ts_c = 0, ts_xy = 0, ts_z = 0, ts_cells = 0, ts_m = 0;
   if (stamps) ts0 = __builtin_amdgcn_s_memtime();
   GInfo* __restrict__ gip = GA.gi + pair;
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
   const double par_l = lane < PP_COUNT ? ((const double*)((const char*)P + 32))[lane] : 0.0;
   const double e2_l = g_exp2_64[lane];
   const unsigned long long map_l = lane < G_MAPB / 8 ? ((const unsigned long long*)(GA.maps + pair * G_MAPB))[lane] : 0ull;
-  const int status = (A.debug_phases & 0x100) ? 0 : gi0.status;
+  const int status = GPHASE(0x100) ? 0 : gi0.status;
   if (status != 1) {           // nothing to compute, or handed to the monolithic kernel
     if (lane == 0 && !list) {
       GA.flags[pair] = status == 2;
@@ -555,7 +559,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
   }
   wsync();
   if (stamps) ts_c = __builtin_amdgcn_s_memtime();
-  if (A.debug_phases & 0x1000000) return;      // timing tools: stop after the maps
+  if (GPHASE(0x1000000)) return;      // timing tools: stop after the maps
 
   const bool do_prune = A.prune_log > 0;
   // (wave-uniform values read from LDS land in vector registers: moved to scalar ones, 20 VGPRs less)
@@ -605,7 +609,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
       constexpr int MC = decltype(mc_tag)::value;
       // ---- X and Y tables: bins 0 .. ncol - 1 are the columns, ncol .. ncol + NJ - 1 the rows j ----------------------------------------------
       if (stamps) { ts_m = __builtin_amdgcn_s_memtime(); ts_a += ts_m - ts_pro; }
-      for (int b0 = 0; b0 < nbins && !(A.debug_phases & 0x2000000); b0 += 16) {
+      for (int b0 = 0; b0 < nbins && !GPHASE(0x2000000); b0 += 16) {
         const int bi = b0 + u16;
         const bool act = bi < nbins, isx = bi < ncol;
         const int bb = isx ? bi : bi - ncol;
@@ -643,7 +647,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
             const int n = 4 * m + q;
             const double v = n < nb ? sum[m] : 0.0;
             s_XY[n][bi] = v;
-            if (!(GA.dbg & 16) && n < rows) {
+            if (!GDBG(16) && n < rows) {
               if (isx) gX[n * ncol + bb] = v; else gY[n * NJ + bb] = v;
             }
           }
@@ -668,7 +672,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
           double z[4] = {0, 0, 0, 0}, zi[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
           double dd_next = k < ke ? s_dzs[k] : 0.0;
           if (!emask) {                  // (most pairs: no slice is invalid at a window edge, no edge tables)
-            for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+            for (; __ballot(k < ke) && !GPHASE(0x4000000); k++) {
               const double dd = dd_next;
               const bool on = k < ke;
               dd_next = k + 1 < ke ? s_dzs[k + 1] : 0.0;
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
               }
             }
           } else {
-            for (; __ballot(k < ke) && !(A.debug_phases & 0x4000000); k++) {
+            for (; __ballot(k < ke) && !GPHASE(0x4000000); k++) {
               const double dd = dd_next;
               const bool on = k < ke;
               dd_next = k + 1 < ke ? s_dzs[k + 1] : 0.0;
@@ -716,9 +720,9 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
             const int n = 4 * m + q;
             const double v = 0.0 + wn[m] * z[m];
             zsp[m] += v;
-            if (!(GA.dbg & 16) && n < rows) gZ[n * NUr + ub] = v;
+            if (!GDBG(16) && n < rows) gZ[n * NUr + ub] = v;
           }
-          if (!(GA.dbg & 48)) {
+          if (!GDBG(48)) {
   #pragma unroll
             for (int m = 0; m < 4; m++) {
               if (emask && 4 * m < rows) gZi0[(4 * m + q) * NUr + ub] = 0.0 + wn[m] * zi[0][m];
@@ -776,7 +780,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
       const int ncand = ncol * NJ;
       int base = 0;
       unsigned first_code = 0;
-      for (int c0 = 0; c0 < ncand && !(A.debug_phases & 0x8000000); c0 += 64) {
+      for (int c0 = 0; c0 < ncand && !GPHASE(0x8000000); c0 += 64) {
         const int cc = c0 + lane;
         bool keep = false;
         int col = 0, jj = 0;
@@ -821,7 +825,7 @@ __global__ void __launch_bounds__(64, 3) gtables_wave_kernel(GArgs GA, const int
   if (lane == 0) {
     gip->emask = emask;
     GA.flags[pair] = 0;
-    if (!(GA.dbg & 1)) stat_add(A.counters, 1, (unsigned long long)NQ);
+    if (!GDBG(1)) stat_add(A.counters, 1, (unsigned long long)NQ);
   }
 }
 
