@@ -162,6 +162,10 @@ int ldsim_set_light_lut(ldsim_ctx* ctx, const float* vis, const float* t0, const
  * ctx's own beside whatever its main stream carries next, e.g. the charge chain of the same segments; every entry point that
  * writes what they read -- segment upload / reset / quench-drift, incidence, LUT, channel tables, constants -- or reads their array
  * -- ldsim_dev_light_download, ldsim_dev_light_response, ldsim_synchronize -- waits for them first; default 0),
+ * "light_truth_lds" (the truth slots of ldsim_scintillation_effect / ldsim_light_detector_response / ldsim_dev_light_response, at most
+ * 64 of them: 1 (default) = by light_truth_lds_kernel, a wave's 64 output rows in LDS beside the plain sum; 0 = inside light_conv_kernel
+ * on slot-major copies of the rows in memory -- same bits for rows of distinct ids in front of their first -1, and the only path
+ * that follows light_sim.py:331-335 literally for other rows is the default),
  * "numba_f32" (1 = the sub-expressions Numba types float32 for f4 record fields are evaluated in float, detsim.py:74-79,
  * 116-118,141,387; 0 = all-f64, what the reference computes for f8 records and what the goldens pin; default 0),
  * "mc_current" (1 = the fused chain takes its induced currents from tracks_current_mc like the reference driver does;

@@ -279,6 +279,346 @@ __global__ void light_truth_max_kernel(const int64_t* __restrict__ tid, const do
   truth_max[e] = any ? (response ? m : fmax(m, 0.0)) : -1.0;
 }
 
+// ---- the truth slots on their own: a wave's 64 output rows in LDS (round 4) ----------------------------------------------------
+// The 2x2 batch of tools/light_wvfm_profile.py accepts ~10^9 (output tick, input tick, slot) terms per stage; in light_conv_kernel
+// every one is a read-modify-write of the output slot through L2 (and a search of the output row through L2 in the scintillation
+// stage), and a 64-tick block of input ticks that holds any truth takes the predicated path for the plain sum as well.  Here the
+// plain sum is left to light_conv_kernel (called without truth: its unrolled blocks) and one wave owns the truth rows of 64
+// consecutive output ticks of a detector, in LDS as [slot][tick] (stride LT_S words: lane = tick reads and adds without a bank
+// conflict whatever the slot, and the transposed load / store of the reference's [tick][slot] rows is conflict-free too):
+//   * the input ticks are screened 64 at a time -- lane l holds tick jb + l: its bound (light_truth_max_kernel) times the largest
+//     weight any of the wave's ticks can meet it with (light_env_kernel) against the threshold, one ballot per block;
+//   * a tick that passes is walked like the reference walks it (ascending slots, light_sim.py:171-184 / :323-337), the accepted
+//     term added with ds_add_f64 -- the adds of one lane to one address retire in program order, the sums are the reference's;
+//   * SiPM stage: the reference searches the INPUT row at the OUTPUT tick (:331-335), fixed while the kernel runs: slot min(a, f)
+//     for a row of distinct ids with its first -1 at f (other rows: the literal search);
+//   * scintillation stage: the output row fills from the front; per lane a 128-entry table (id hash -> slot, one byte) finds an
+//     id or proves it new in one or two LDS reads -- the id is the same for the whole wave, so are the hash and the probe sequence.
+// Rows are loaded at the wave's first accepted tick and only touched entries are written back.
+#define LT_S 65
+#define LT_TAB 128
+#define LT_NONE 0xFFu
+
+// env[m + 63], m = (first output tick of a wave) - (input tick) in [-63, C]: the largest weight (SiPM stage: magnitude) any of the
+// wave's 64 ticks meets that input tick with -- n = i - j in [m, m + 63], inside [0, C]; +inf where the per-term test cannot be
+// bounded (a negative weight in the scintillation stage's signed test, a weight that is not finite)
+__global__ void light_env_kernel(const double* __restrict__ weights, int C, int response, double* __restrict__ env) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > C + 63) return;
+  const int m = k - 63;
+  double e = 0.0;
+  bool open = false;
+  for (int n = max(m, 0); n <= min(m + 63, C); n++) {
+    const double w = weights[n];
+    if (!(fabs(w) <= 1.7e308) || (!response && !(w >= 0.0))) open = true;
+    e = fmax(e, response ? fabs(w) : w);
+  }
+  env[k] = open ? __builtin_inf() : e;
+}
+
+// env2[q] = max of env over the 64 offsets a block of 64 input ticks, q blocks in front of the wave's own, is met with
+__global__ void light_env2_kernel(const double* __restrict__ env, int C, double* __restrict__ env2) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (64 * q > C + 63) return;
+  double e = 0.0;
+  for (int k = 64 * q; k <= min(64 * q + 63, C + 63); k++) e = fmax(e, env[k]);
+  env2[q] = e;
+}
+
+// bound[d][j]: light_truth_max_kernel's bound of input tick j, -1 also where the scintillation stage skips the tick (a zero sample,
+// light_sim.py:166); block_bound[d][j / 64]: the largest of a block of 64 ticks (-1: none of them takes part) -- one wave per block
+__global__ void __launch_bounds__(64) light_truth_bound_kernel(const float* __restrict__ inc, const int64_t* __restrict__ tid,
+                                                               const double* __restrict__ tph, int T, int Mt, int response,
+                                                               double* __restrict__ bound, double* __restrict__ block_bound) {
+  const int d = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+  double m = -1.0;
+  if (j < T && (response || inc[(int64_t)d * T + j] != 0.f)) {
+    const int64_t e = (int64_t)d * T + j;
+    bool any = false;
+    for (int a = 0; a < Mt; a++) {
+      if (tid[e * Mt + a] == -1) break;
+      const double ph = response ? fabs(tph[e * Mt + a]) : tph[e * Mt + a];
+      m = any ? fmax(m, ph) : ph;
+      any = true;
+    }
+    m = any ? (response ? m : fmax(m, 0.0)) : -1.0;
+  }
+  if (j < T) bound[(int64_t)d * T + j] = m;
+  const double bm = wave_max_f64(m);
+  if (threadIdx.x == 0) block_bound[(int64_t)d * gridDim.x + blockIdx.x] = bm;
+}
+
+__device__ __forceinline__ int64_t wave_lane_i64(int64_t v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool RESPONSE>
+__global__ void __launch_bounds__(64) light_truth_lds_kernel(
+    const int64_t* __restrict__ tid, const double* __restrict__ tph, int T, int Mt, const double* __restrict__ weights, int C,
+    const double* __restrict__ env /* [C + 64] */, double truth_threshold, int64_t* __restrict__ out_tid,
+    double* __restrict__ out_tph /* [D][T][Mt], the reference's layout */, const double* __restrict__ truth_max /* [D][T] */,
+    const double* __restrict__ block_max /* [D][ceil(T / 64)] */, const double* __restrict__ env2) {
+  extern __shared__ double s_lt[];
+  double* s_acc = s_lt;                                        // [Mt][LT_S]: the output photons
+  int64_t* s_id = (int64_t*)(s_acc + (RESPONSE ? 0 : Mt * LT_S));      // scintillation: [Mt][LT_S] output ids (SiPM: the input ids, while the rows are classified only)
+  double* s_w = s_acc + (RESPONSE ? 1 : 2) * Mt * LT_S;        // [128]: the weights the wave's ticks meet a block of input ticks with
+  unsigned char* s_byte = (unsigned char*)(s_w + 128);         // SiPM: [Mt][64] last input slot added to an output slot; scintillation: [LT_TAB][64] id hash -> slot
+  const int lane = threadIdx.x;
+  const int d = blockIdx.y, i0 = blockIdx.x * 64, i = i0 + lane;
+  const bool live = i < T;
+  const int nrow = min(64, T - i0) * Mt;
+  const int64_t rbase = ((int64_t)d * T + i0) * Mt;           // the wave's rows: nrow contiguous words
+  const double* tmax = truth_max + (int64_t)d * T;
+  bool loaded = false, changed = false;
+  int filled = 0;                  // scintillation: slots in front of the row's first -1
+  bool literal = false;            // scintillation, wave-uniform: some row arrived with a hole in front of a filled slot
+  int row_f = Mt;                  // SiPM: first -1 of the input row at the output tick
+  bool regular = true;             // SiPM: distinct ids in front of it, -1 behind
+
+  auto id_hash = [](int64_t id) { return (int)(((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> 57); };
+  auto load_rows = [&]() {
+    // ids first (SiPM: into the accumulators' place), the per-row state from them, then the photons
+    int64_t* ids = RESPONSE ? (int64_t*)s_acc : s_id;
+    const int64_t* gid = RESPONSE ? tid : out_tid;
+    for (int e0 = lane; e0 < 64 * Mt; e0 += 512) {          // (eight words per lane in flight)
+      int64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = e0 + 64 * u < nrow ? gid[rbase + e0 + 64 * u] : (int64_t)-1;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + 64 * u, t = e / Mt, b = e - t * Mt;
+        if (e < 64 * Mt) ids[b * LT_S + t] = v[u];
+      }
+    }
+    const int nbyte = (RESPONSE ? Mt : LT_TAB) * 64;
+    for (int e = lane * 4; e < nbyte; e += 256) *(unsigned*)(s_byte + e) = 0xFFFFFFFFu;
+    wave_lds_sync();
+    if (RESPONSE) {
+      row_f = Mt;
+      for (int b = 0; b < Mt; b++)
+        if (ids[b * LT_S + lane] == -1) { row_f = b; break; }
+      regular = true;
+      for (int b = row_f + 1; b < Mt; b++)
+        if (ids[b * LT_S + lane] != -1) { regular = false; break; }
+      for (int b = 1; b < row_f && regular; b++) {
+        const int64_t idb = ids[b * LT_S + lane];
+        for (int e = 0; e < b; e++)
+          if (ids[e * LT_S + lane] == idb) { regular = false; break; }
+      }
+      wave_lds_sync();
+    } else {
+      bool seen_empty = false, clean = true;
+      filled = 0;
+      for (int b = 0; b < Mt; b++) {
+        if (ids[b * LT_S + lane] == -1) seen_empty = true;
+        else if (seen_empty) clean = false;
+        else filled = b + 1;
+      }
+      literal = __ballot(live && !clean) != 0ull;
+      if (!literal) {
+        for (int b = 0; b < filled; b++) {              // the ids the row arrives with (a repeated one keeps its first slot)
+          const int64_t id = ids[b * LT_S + lane];
+          const int h0 = id_hash(id);
+          for (int k = 0; k < LT_TAB; k++) {
+            const int idx = (h0 + k) & (LT_TAB - 1);
+            const unsigned p = s_byte[idx * 64 + lane];
+            if (p == LT_NONE) { s_byte[idx * 64 + lane] = (unsigned char)b; break; }
+            if (ids[(int)p * LT_S + lane] == id) break;
+          }
+        }
+      }
+    }
+    for (int e0 = lane; e0 < 64 * Mt; e0 += 512) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = e0 + 64 * u < nrow ? out_tph[rbase + e0 + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + 64 * u, t = e / Mt, b = e - t * Mt;
+        if (e < 64 * Mt) s_acc[b * LT_S + t] = v[u];
+      }
+    }
+    wave_lds_sync();
+  };
+
+  // Screening in two levels: 64 blocks of 64 input ticks per trip to memory (lane = block: its largest bound times the largest
+  // weight the wave meets it with), then the ticks of a block that passed (lane = tick) -- fetched, with the weights the wave meets
+  // the block with, one passing block ahead of the one being walked; the truth slots of a tick that passed one tick ahead.
+  const int j_lo = max(i0 - C, 0), j_hi = min(i0 + 63, T - 1);
+  const int B_lo = j_lo >> 6, B_hi = j_hi >> 6;
+  const double* bmax = block_max + (int64_t)d * ((T + 63) >> 6);
+  for (int Bg = B_lo; Bg <= B_hi; Bg += 64) {
+    unsigned long long m1;
+    {
+      const int B_l = Bg + lane;
+      const bool bv = B_l <= B_hi;
+      const double b_l = bv ? bmax[B_l] : -1.0;
+      const double e2 = bv ? env2[(i0 >> 6) - B_l] : 0.0;
+      m1 = __ballot(b_l >= 0.0 && !(e2 * b_l < truth_threshold));
+    }
+    if (!m1) continue;
+    double tn, en, wan, wbn;
+    auto fetch_block = [&](int B) {
+      const int j_l = 64 * B + lane;
+      const bool jv = j_l >= j_lo && j_l <= j_hi;
+      tn = jv ? tmax[j_l] : -1.0;
+      en = jv ? env[i0 - j_l + 63] : 0.0;
+      const int n1 = i0 - 64 * B - 63 + lane, n2 = n1 + 64;
+      wan = (n1 >= 0 && n1 <= C) ? weights[n1] : 0.0;
+      wbn = (n2 >= 0 && n2 <= C) ? weights[n2] : 0.0;
+    };
+    int Bn = Bg + __ffsll((long long)m1) - 1;
+    m1 &= m1 - 1;
+    fetch_block(Bn);
+    for (bool more_b = true; more_b;) {
+      const int jb = 64 * Bn;
+      const double t_l = tn, e_l = en, wa = wan, wb = wbn;
+      more_b = m1 != 0ull;
+      if (more_b) {
+        Bn = Bg + __ffsll((long long)m1) - 1;
+        m1 &= m1 - 1;
+        fetch_block(Bn);
+      }
+      unsigned long long mc = __ballot(t_l >= 0.0 && !(e_l * t_l < truth_threshold));
+      if (!mc) continue;
+      wave_lds_sync();
+      s_w[lane] = wa;
+      s_w[64 + lane] = wb;
+      wave_lds_sync();
+      int64_t id_n = -1;
+      double ph_n = 0.0;
+      auto fetch_row = [&](int jj) {
+        const int64_t src = ((int64_t)d * T + jj) * Mt;
+        id_n = -1;
+        ph_n = 0.0;
+        if (lane < Mt) { id_n = tid[src + lane]; ph_n = tph[src + lane]; }
+      };
+      int tnx = __ffsll((long long)mc) - 1;
+      mc &= mc - 1;
+      fetch_row(jb + tnx);
+      for (bool more_t = true; more_t;) {
+        const int t = tnx;
+        const int64_t my_id = id_n;
+        const double my_ph = ph_n;
+        more_t = mc != 0ull;
+        if (more_t) {
+          tnx = __ffsll((long long)mc) - 1;
+          mc &= mc - 1;
+          fetch_row(jb + tnx);
+        }
+        const int j = jb + t;
+        const int n = i - j;
+        const bool mine = live && n >= 0 && n <= C;
+        const double w = mine ? s_w[lane + 63 - t] : 0.0;
+        const double bound = wave_lane_f64(t_l, t);
+        const bool walk = mine && !(RESPONSE ? (fabs(w) * bound < truth_threshold) : (w >= 0.0 && w * bound < truth_threshold));
+        if (!__ballot(walk)) continue;
+        if (!loaded) { load_rows(); loaded = true; }
+        // the input tick's slots: lane a holds slot a
+        const unsigned long long empty = __ballot(lane < Mt && my_id == -1);
+        const int nfill = empty ? __ffsll((long long)empty) - 1 : Mt;          // (the walk stops at the first empty slot)
+        const double wmax = wave_max_f64(walk ? fabs(w) : 0.0);
+        // the slots some lane's product can pass on, in ascending order
+        unsigned long long cand;
+        if (RESPONSE) cand = __ballot(lane < nfill && !(wmax * fabs(my_ph) < truth_threshold));
+        else if (__ballot(walk && w < 0.0)) cand = nfill >= 64 ? ~0ull : ((1ull << nfill) - 1ull);
+        else cand = __ballot(lane < nfill && !(my_ph >= 0.0 ? wmax * my_ph < truth_threshold : truth_threshold > 0.0));
+        for (; cand; cand &= cand - 1) {
+          const int a = __ffsll((long long)cand) - 1;
+          const double ph = wave_lane_f64(my_ph, a);
+          const double v = w * ph;
+          const bool pass = walk && !(RESPONSE ? (fabs(v) < truth_threshold) : (v < truth_threshold));
+          if (!__ballot(pass)) continue;
+          if (RESPONSE) {
+            if (pass) {
+              int b = Mt;
+              if (regular) {
+                b = min(a, row_f);
+              } else {
+                // :331-335 literally: the slot test reads the INPUT ids at [idet, itick]
+                const int64_t* grow = tid + rbase + (int64_t)lane * Mt;
+                const int64_t ida = grow[a];
+                for (int e = 0; e < Mt; e++) {
+                  const int64_t idb = grow[e];
+                  if (idb == ida || idb == -1) { b = e; break; }
+                }
+              }
+              if (b < Mt) {
+                atomicAdd(&s_acc[b * LT_S + lane], v);
+                s_byte[b * 64 + lane] = (unsigned char)a;
+                changed = true;
+              }
+            }
+          } else {
+            const int64_t id = wave_lane_i64(my_id, a);
+            if (literal) {
+              if (pass) {
+                for (int b = 0; b < Mt; b++) {                                  // :180-183
+                  const int64_t cur = s_id[b * LT_S + lane];
+                  if (cur == id || cur == -1) {
+                    s_id[b * LT_S + lane] = id;
+                    atomicAdd(&s_acc[b * LT_S + lane], v);
+                    changed = true;
+                    break;
+                  }
+                }
+              }
+            } else {
+              const int h0 = id_hash(id);
+              bool need = pass;
+              for (int k = 0; k < LT_TAB && __ballot(need); k++) {
+                const int idx = (h0 + k) & (LT_TAB - 1);
+                if (need) {
+                  const unsigned p = s_byte[idx * 64 + lane];
+                  if (p == LT_NONE) {                   // not in the row: its first empty slot, if it has one
+                    if (filled < Mt) {
+                      s_id[filled * LT_S + lane] = id;
+                      s_byte[idx * 64 + lane] = (unsigned char)filled;
+                      atomicAdd(&s_acc[filled * LT_S + lane], v);
+                      filled++;
+                      changed = true;
+                    }
+                    need = false;
+                  } else if (s_id[(int)p * LT_S + lane] == id) {
+                    atomicAdd(&s_acc[(int)p * LT_S + lane], v);
+                    changed = true;
+                    need = false;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!loaded || !__ballot(changed)) return;
+  // write back what was touched, in the reference's layout (neighbouring lanes: neighbouring words)
+  unsigned char* s_fill = (unsigned char*)s_w;          // scintillation: slots to write per tick
+  wave_lds_sync();
+  if (!RESPONSE) s_fill[lane] = (unsigned char)(changed ? (literal ? Mt : filled) : 0);
+  wave_lds_sync();
+  for (int e = lane; e < nrow; e += 64) {
+    const int t = e / Mt, b = e - t * Mt;
+    if (RESPONSE) {
+      const unsigned la = s_byte[b * 64 + t];
+      if (la != LT_NONE) {
+        out_tid[rbase + e] = tid[rbase + (int64_t)t * Mt + (int)la];
+        out_tph[rbase + e] = s_acc[b * LT_S + t];
+      }
+    } else if (b < (int)s_fill[t]) {
+      out_tid[rbase + e] = s_id[b * LT_S + t];
+      out_tph[rbase + e] = s_acc[b * LT_S + t];
+    }
+  }
+}
+
 // [detector][tick][slot] <-> [detector][slot][tick] of an 8-byte array, TR_TICKS ticks of one detector per workgroup through LDS
 // (both sides in runs of at least 512 bytes)
 #define TR_TICKS 64
@@ -313,10 +653,70 @@ __global__ void __launch_bounds__(256) light_truth_transpose_kernel(const unsign
   }
 }
 
+// the plain sum of a stage (no truth slots) on `st`
+extern "C++" int light_response_plain(ldsim_ctx* ctx, hipStream_t st, bool response, const float* inc, int D, int T, const double* weights,
+                                      int C, const double* gain, float* out) {
+  if (D <= 0 || T <= 0) return 0;
+  dim3 grid((unsigned)((T + LR_THREADS - 1) / LR_THREADS), (unsigned)D), block(LR_THREADS);
+  const double thr = ctx->h_consts.mc_truth_threshold;
+  if (response)
+    hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, st, inc, (const int64_t*)nullptr, (const double*)nullptr, D, T, 0, weights,
+                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr);
+  else
+    hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, st, inc, (const int64_t*)nullptr, (const double*)nullptr, D, T, 0, weights,
+                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// can the truth slots of a stage go by light_truth_lds_kernel?
+extern "C++" bool light_truth_in_lds(const ldsim_ctx* ctx, int Mt) { return Mt > 0 && Mt <= 64 && ctx->light_truth_lds; }
+
+// the truth slots of a stage (light_truth_in_lds) on `st`: bounds, weight envelopes, light_truth_lds_kernel.  The scintillation and the
+// SiPM stage of one call share the bound and envelope buffers: both on the same stream.
+extern "C++" int light_response_truth(ldsim_ctx* ctx, hipStream_t st, bool response, const float* inc, const int64_t* tid, const double* tph,
+                                      int D, int T, int Mt, const double* weights, int C, int64_t* out_tid, double* out_tph) {
+  if (D <= 0 || T <= 0) return 0;
+  const double thr = ctx->h_consts.mc_truth_threshold;
+  const int nblk = (T + 63) / 64, nq = (C + 63) / 64 + 1;
+  const int64_t n = (int64_t)D * T;
+  int rc = ldsim_ensure_buf(ctx, &ctx->light_tmax, (size_t)(n + (int64_t)D * nblk) * 8);
+  if (rc) return rc;
+  if ((rc = ldsim_ensure_buf(ctx, &ctx->light_env, (size_t)(C + 64 + nq) * 8))) return rc;
+  double* tmax = (double*)ctx->light_tmax.p;
+  double* env = (double*)ctx->light_env.p;
+  double* env2 = env + C + 64;
+  hipLaunchKernelGGL(light_truth_bound_kernel, dim3((unsigned)nblk, (unsigned)D), dim3(64), 0, st, inc, tid, tph, T, Mt, response ? 1 : 0,
+                     tmax, tmax + n);
+  hipLaunchKernelGGL(light_env_kernel, dim3((unsigned)((C + 64 + 255) / 256)), dim3(256), 0, st, weights, C, response ? 1 : 0, env);
+  hipLaunchKernelGGL(light_env2_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, (const double*)env, C, env2);
+  HIPCHK(hipGetLastError());
+  const size_t lds = ((size_t)(response ? 1 : 2) * Mt * LT_S + 128) * 8 + (size_t)(response ? Mt : LT_TAB) * 64;
+  const double* bmax = tmax + n;
+  dim3 tg((unsigned)nblk, (unsigned)D);
+  if (response) {
+    if (lds > 65536) HIPCHK(hipFuncSetAttribute((const void*)light_truth_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(light_truth_lds_kernel<true>, tg, dim3(64), lds, st, tid, tph, T, Mt, weights, C, (const double*)env, thr, out_tid,
+                       out_tph, (const double*)tmax, bmax, (const double*)env2);
+  } else {
+    if (lds > 65536) HIPCHK(hipFuncSetAttribute((const void*)light_truth_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(light_truth_lds_kernel<false>, tg, dim3(64), lds, st, tid, tph, T, Mt, weights, C, (const double*)env, thr, out_tid,
+                       out_tph, (const double*)tmax, bmax, (const double*)env2);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const float* inc, const int64_t* tid,
                                        const double* tph, int D, int T, int Mt, const double* weights, int C,
                                        const double* gain, float* out, int64_t* out_tid, double* out_tph) {
   if (D <= 0 || T <= 0) return 0;
+  if (light_truth_in_lds(ctx, Mt)) {
+    // the plain sum by light_conv_kernel without truth, the truth slots by light_truth_lds_kernel (rows in LDS: no slot-major copies)
+    int rc = light_response_plain(ctx, ctx->stream, response, inc, D, T, weights, C, gain, out);
+    if (rc) return rc;
+    return light_response_truth(ctx, ctx->stream, response, inc, tid, tph, D, T, Mt, weights, C, out_tid, out_tph);
+  }
   dim3 grid((unsigned)((T + LR_THREADS - 1) / LR_THREADS), (unsigned)D), block(LR_THREADS);
   const double thr = ctx->h_consts.mc_truth_threshold;
   double* tmax = nullptr;
@@ -329,7 +729,8 @@ extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const floa
                        response ? 1 : 0, tmax);
     HIPCHK(hipGetLastError());
   }
-  // the output's truth rows: to slot-major, through the kernel, and back (2 x 2 passes over [D][T][Mt]: a few ms at 2.5 GB each)
+  // (more than 64 slots, or "light_truth_lds" 0:) the output's truth rows to slot-major, through light_conv_kernel, and back (2 x 2
+  // passes over [D][T][Mt]: a few ms at 2.5 GB each)
   int64_t* w_tid = nullptr;
   int64_t* in_sm = nullptr;
   double* w_tph = nullptr;

@@ -269,7 +269,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   for (DevBuf* b : {&ctx->light_nph, &ctx->light_t0, &ctx->light_vox, &ctx->light_out, &ctx->light_tid, &ctx->light_tph,
                     &ctx->light_opc, &ctx->light_trk, &ctx->light_scint, &ctx->light_scint_tid, &ctx->light_scint_tph,
                     &ctx->light_disc, &ctx->light_resp, &ctx->light_resp_tid, &ctx->light_resp_tph, &ctx->light_w[0],
-                    &ctx->light_w[1], &ctx->light_gain, &ctx->resp_pad, &ctx->light_tmax, &ctx->light_wtid, &ctx->light_wtph, &ctx->light_wtid2})
+                    &ctx->light_w[1], &ctx->light_gain, &ctx->resp_pad, &ctx->light_tmax, &ctx->light_env, &ctx->light_wtid, &ctx->light_wtph, &ctx->light_wtid2})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);
@@ -325,6 +325,7 @@ extern "C" int ldsim_set_option(ldsim_ctx* ctx, const char* name, double value) 
     if (!(value >= 0)) { ldsim_set_error("gform_max_support must be >= 0"); return LDSIM_EINVAL; }
     ctx->gform_max_support = value > 1e9 ? 1000000000 : (int)value;
   }
+  else if (!strcmp(name, "light_truth_lds")) ctx->light_truth_lds = value != 0;
   else if (!strcmp(name, "light_incidence_scalar")) ctx->light_incidence_scalar = value != 0;
   else if (!strcmp(name, "light_sum_no_list")) ctx->light_sum_no_list = value != 0;
   else if (!strcmp(name, "light_sum_async")) {

@@ -1022,6 +1022,96 @@ def test_light_response_full_window_vs_oracle():
     assert np.abs(resp).max() > 0
 
 
+def _truth_rows(rng, D, T, M, density, kind):
+    """[D][T][M] truth rows for the light response tests: `kind` 0 -- the front filled with distinct ids (what the stages produce),
+    1 -- some rows with a repeated id, 2 -- some rows with a hole (-1) in front of filled slots as well."""
+    ids = np.full((D, T, M), -1, dtype='i8')
+    ph = np.zeros((D, T, M))
+    for d in range(D):
+        for t in np.flatnonzero(rng.random(T) < density):
+            n = int(rng.integers(1, M + 1))
+            ids[d, t, :n] = rng.choice(3 * M, size=n, replace=False) + 10
+            ph[d, t, :n] = rng.uniform(0.05, 40.0, n) * rng.choice([1.0, 1.0, 1.0, 1e-3], n)
+            r = rng.random()
+            if kind >= 1 and n >= 3 and r < 0.3:
+                ids[d, t, n - 1] = ids[d, t, 0]
+            if kind >= 2 and n >= 3 and 0.3 <= r < 0.6:
+                ids[d, t, int(rng.integers(0, n - 1))] = -1
+    return ids, ph
+
+
+@pytest.mark.parametrize("M,T,kind", [(3, 200, 0), (50, 330, 0), (50, 200, 2), (64, 130, 1), (7, 330, 2)])
+def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
+    """The truth slots of both response stages by `light_truth_lds_kernel` (a wave's 64 output rows in LDS, the default) against the
+    oracle's literal walk, bit for bit, and against `light_conv_kernel`'s rows in memory (option light_truth_lds 0) where that path
+    is literal: a window shorter than the waveform (the bound max(itick - conv_ticks, 0)), a waveform that is no multiple of 64 ticks,
+    zero samples (the scintillation stage skips their truth, :166), negative photons in the SiPM stage's magnitude test, rows that
+    fill up and drop ids, and -- `kind` 1, 2 -- input rows with repeated ids / holes and output rows that arrive partly filled."""
+    import ctypes as C
+    H.load_cfg("module0")
+    light, sim = consts.light, consts.sim
+    keep = (tuple(light.LIGHT_WINDOW), sim.MC_TRUTH_THRESHOLD)
+    try:
+        light.LIGHT_WINDOW = (0.0, 150.3 * light.LIGHT_TICK_SIZE)
+        sim.MC_TRUTH_THRESHOLD = 0.02
+        rng = np.random.default_rng(100 * M + kind)
+        D = 3
+        inc = np.zeros((D, T), dtype='f4')
+        hit = rng.random((D, T)) < 0.5
+        inc[hit] = rng.uniform(1.0, 300.0, hit.sum()).astype('f4')
+        tid, tph = _truth_rows(rng, D, T, M, 0.12, kind)
+        grid = ((D, -(-T // 64)), (1, 64))
+
+        def start(filled):
+            o_id, o_ph = np.full((D, T, M), -1, dtype='i8'), np.zeros((D, T, M))
+            if filled:
+                o_id, o_ph = _truth_rows(rng, D, T, M, 0.3, kind)
+            return np.zeros((D, T), dtype='f4'), o_id, o_ph
+
+        for filled in ([False, True] if kind else [False]):
+            s0 = start(filled)
+            # oracle: the C restatement on copies of the same in / out arrays
+            ref = [a.copy() for a in s0]
+            O.lib().o_scintillation_effect(O._p(inc), O._p(tid), O._p(tph), C.c_int32(D), C.c_int32(T), C.c_int32(M), O._p(ref[0]),
+                                           O._p(ref[1]), O._p(ref[2]), C.byref(O._consts()))
+            got = {}
+            for mode in (1, 0):
+                lib.set_option("light_truth_lds", mode)
+                g = [a.copy() for a in s0]
+                light_sim.calc_scintillation_effect[grid[0], grid[1]](inc, tid, tph, g[0], g[1], g[2])
+                got[mode] = g
+            lib.set_option("light_truth_lds", 1)
+            for mode in (1, 0):
+                for k, name in enumerate(("scint", "ids", "photons")):
+                    assert np.array_equal(got[mode][k], ref[k]), f"scintillation stage, light_truth_lds {mode}, {name} (filled {filled})"
+            assert (ref[1][:, :, -1] != -1).any() or M > 10          # (small M: rows fill up and drop ids)
+            assert (ref[1] != s0[1]).any()
+            # SiPM stage on the scintillation stage's output (negative photons added: the magnitude test), literal rows in `tid`
+            s_in, s_id, s_ph = ref[0], ref[1].copy(), ref[2].copy()
+            neg = rng.random(s_ph.shape) < 0.2
+            s_ph[neg] = -s_ph[neg]
+            if kind:
+                s_id[:, ::7] = tid[:, ::7]
+            r0 = start(filled)
+            gain = np.ascontiguousarray(light.LIGHT_GAIN, dtype=np.float64)
+            imp = np.ascontiguousarray(light.IMPULSE_MODEL, dtype=np.float64)
+            rref = [a.copy() for a in r0]
+            O.lib().o_light_detector_response(O._p(s_in), O._p(s_id), O._p(s_ph), C.c_int32(D), C.c_int32(T), C.c_int32(M), O._p(gain),
+                                              O._p(imp), C.c_int32(imp.shape[0]), O._p(rref[0]), O._p(rref[1]), O._p(rref[2]),
+                                              C.byref(O._consts()))
+            for mode in ((1, 0) if kind == 0 else (1,)):      # (rows in memory: literal for distinct ids in front of the first -1 only)
+                lib.set_option("light_truth_lds", mode)
+                g = [a.copy() for a in r0]
+                light_sim.calc_light_detector_response[grid[0], grid[1]](s_in, s_id, s_ph, g[0], g[1], g[2])
+                lib.set_option("light_truth_lds", 1)
+                for k, name in enumerate(("response", "ids", "photons")):
+                    assert np.array_equal(g[k], rref[k]), f"SiPM stage, light_truth_lds {mode}, {name} (filled {filled})"
+            assert (rref[2] != r0[2]).any()
+    finally:
+        lib.set_option("light_truth_lds", 1)
+        light.LIGHT_WINDOW, sim.MC_TRUTH_THRESHOLD = keep
+
+
 def test_light_properties_baseline_event():
     """BASELINE.json config 5's light leg (ndlar, synthetic light set-up of SURVEY §8d: 48 channels per TPC) on one full
     event: channel masking, voxel bounds, and exact linearity of the photon sum -- doubling every n_photons_det doubles
