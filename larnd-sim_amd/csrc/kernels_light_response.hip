@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
   double* s_acc = s_lt;                                        // [Mt][LT_S]: the output photons
   int64_t* s_id = (int64_t*)(s_acc + (RESPONSE ? 0 : Mt * LT_S));      // scintillation: [Mt][LT_S] output ids (SiPM: the input ids, while the rows are classified only)
   double* s_w = s_acc + (RESPONSE ? 1 : 2) * Mt * LT_S;        // [128]: the weights the wave's ticks meet a block of input ticks with
-  unsigned char* s_byte = (unsigned char*)(s_w + 128);         // SiPM: [Mt][64] last input slot added to an output slot; scintillation: [LT_TAB][64] id hash -> slot
+  unsigned char* s_byte = (unsigned char*)(s_w + 128);         // SiPM: [64 ticks][64] last input slot added to an output slot; scintillation: [LT_TAB][64 ticks] id hash -> slot
   const int lane = threadIdx.x;
   const int d = blockIdx.y, i0 = blockIdx.x * 64, i = i0 + lane;
   const bool live = i < T;
@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
   bool literal = false;            // scintillation, wave-uniform: some row arrived with a hole in front of a filled slot
   int row_f = Mt;                  // SiPM: first -1 of the input row at the output tick
   bool regular = true;             // SiPM: distinct ids in front of it, -1 behind
+  unsigned long long m_reg = 0;    // SiPM, wave-uniform: the ticks with such a row
 
   auto id_hash = [](int64_t id) { return (int)(((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> 57); };
   auto load_rows = [&]() {
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
         if (e < 64 * Mt) ids[b * LT_S + t] = v[u];
       }
     }
-    const int nbyte = (RESPONSE ? Mt : LT_TAB) * 64;
+    const int nbyte = (RESPONSE ? 64 : LT_TAB) * 64;
     for (int e = lane * 4; e < nbyte; e += 256) *(unsigned*)(s_byte + e) = 0xFFFFFFFFu;
     wave_lds_sync();
     if (RESPONSE) {
@@ -411,6 +412,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
         for (int e = 0; e < b; e++)
           if (ids[e * LT_S + lane] == idb) { regular = false; break; }
       }
+      m_reg = __ballot(regular);
       wave_lds_sync();
     } else {
       bool seen_empty = false, clean = true;
@@ -523,11 +525,53 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
         // the input tick's slots: lane a holds slot a
         const unsigned long long empty = __ballot(lane < Mt && my_id == -1);
         const int nfill = empty ? __ffsll((long long)empty) - 1 : Mt;          // (the walk stops at the first empty slot)
+        if (RESPONSE) {
+          // SiPM stage, the walk turned round: lane a holds slot a of the input tick and the loop runs over the wave's output ticks
+          // that can pass -- a term reaches ~13 of the wave's 64 ticks but most of the tick's slots, and the target slot needs no
+          // search: min(a, f) for a row of distinct ids with its first -1 at f.  Terms of different slots below f meet different
+          // words; those at or above f all meet slot f and are added one by one, in ascending a like the reference's loop.
+          changed = true;            // (what was touched is in s_byte)
+          for (unsigned long long mw = __ballot(walk); mw; mw &= mw - 1) {
+            const int ti = __ffsll((long long)mw) - 1;
+            const double w_i = wave_lane_f64(w, ti);
+            const int rf = __builtin_amdgcn_readlane(row_f, ti);
+            const double v = w_i * my_ph;
+            const bool pass = lane < nfill && !(fabs(v) < truth_threshold);
+            unsigned long long serial;
+            if ((m_reg >> ti) & 1ull) {
+              if (pass && lane < rf) {
+                atomicAdd(&s_acc[lane * LT_S + ti], v);
+                s_byte[ti * 64 + lane] = (unsigned char)lane;
+              }
+              serial = rf < Mt ? __ballot(pass && lane >= rf) : 0ull;
+              for (; serial; serial &= serial - 1) {
+                const int a = __ffsll((long long)serial) - 1;
+                if (lane == a) {
+                  atomicAdd(&s_acc[rf * LT_S + ti], v);
+                  s_byte[ti * 64 + rf] = (unsigned char)a;
+                }
+              }
+            } else {
+              // :331-335 literally: the slot test reads the INPUT ids at [idet, itick] -- lane e holds that row's slot e
+              const int64_t idb = lane < Mt ? tid[rbase + (int64_t)ti * Mt + lane] : (int64_t)0;
+              for (serial = __ballot(pass); serial; serial &= serial - 1) {
+                const int a = __ffsll((long long)serial) - 1;
+                const int64_t ida = wave_lane_i64(idb, a);
+                const unsigned long long hit = __ballot(lane < Mt && (idb == ida || idb == -1));
+                if (hit && lane == a) {
+                  const int b = __ffsll((long long)hit) - 1;
+                  atomicAdd(&s_acc[b * LT_S + ti], v);
+                  s_byte[ti * 64 + b] = (unsigned char)a;
+                }
+              }
+            }
+          }
+          continue;
+        }
         const double wmax = wave_max_f64(walk ? fabs(w) : 0.0);
         // the slots some lane's product can pass on, in ascending order
         unsigned long long cand;
-        if (RESPONSE) cand = __ballot(lane < nfill && !(wmax * fabs(my_ph) < truth_threshold));
-        else if (__ballot(walk && w < 0.0)) cand = nfill >= 64 ? ~0ull : ((1ull << nfill) - 1ull);
+        if (__ballot(walk && w < 0.0)) cand = nfill >= 64 ? ~0ull : ((1ull << nfill) - 1ull);
         else cand = __ballot(lane < nfill && !(my_ph >= 0.0 ? wmax * my_ph < truth_threshold : truth_threshold > 0.0));
         for (; cand; cand &= cand - 1) {
           const int a = __ffsll((long long)cand) - 1;
@@ -535,27 +579,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
           const double v = w * ph;
           const bool pass = walk && !(RESPONSE ? (fabs(v) < truth_threshold) : (v < truth_threshold));
           if (!__ballot(pass)) continue;
-          if (RESPONSE) {
-            if (pass) {
-              int b = Mt;
-              if (regular) {
-                b = min(a, row_f);
-              } else {
-                // :331-335 literally: the slot test reads the INPUT ids at [idet, itick]
-                const int64_t* grow = tid + rbase + (int64_t)lane * Mt;
-                const int64_t ida = grow[a];
-                for (int e = 0; e < Mt; e++) {
-                  const int64_t idb = grow[e];
-                  if (idb == ida || idb == -1) { b = e; break; }
-                }
-              }
-              if (b < Mt) {
-                atomicAdd(&s_acc[b * LT_S + lane], v);
-                s_byte[b * 64 + lane] = (unsigned char)a;
-                changed = true;
-              }
-            }
-          } else {
+          if (!RESPONSE) {
             const int64_t id = wave_lane_i64(my_id, a);
             if (literal) {
               if (pass) {
@@ -570,13 +594,29 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
                 }
               }
             } else {
+              // the first entry of the probe sequence without a branch (both reads unconditional, from valid addresses): it holds
+              // the id (two terms of three) or is empty (the rest); an entry with another id goes on along the sequence below
               const int h0 = id_hash(id);
-              bool need = pass;
-              for (int k = 0; k < LT_TAB && __ballot(need); k++) {
+              const unsigned p0 = s_byte[h0 * 64 + lane];
+              const bool has = p0 != LT_NONE;
+              const int64_t cur = s_id[(has ? (int)p0 : 0) * LT_S + lane];
+              const bool fresh = pass && !has && filled < Mt;
+              bool need = pass && has && cur != id;
+              const int pos = has ? (int)p0 : filled;
+              if (fresh) {                               // not in the row: its first empty slot, if it has one
+                s_id[pos * LT_S + lane] = id;
+                s_byte[h0 * 64 + lane] = (unsigned char)pos;
+                filled++;
+              }
+              if (fresh || (pass && has && cur == id)) {
+                atomicAdd(&s_acc[pos * LT_S + lane], v);
+                changed = true;
+              }
+              for (int k = 1; k < LT_TAB && __ballot(need); k++) {
                 const int idx = (h0 + k) & (LT_TAB - 1);
                 if (need) {
                   const unsigned p = s_byte[idx * 64 + lane];
-                  if (p == LT_NONE) {                   // not in the row: its first empty slot, if it has one
+                  if (p == LT_NONE) {
                     if (filled < Mt) {
                       s_id[filled * LT_S + lane] = id;
                       s_byte[idx * 64 + lane] = (unsigned char)filled;
@@ -607,7 +647,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
   for (int e = lane; e < nrow; e += 64) {
     const int t = e / Mt, b = e - t * Mt;
     if (RESPONSE) {
-      const unsigned la = s_byte[b * 64 + t];
+      const unsigned la = s_byte[t * 64 + b];
       if (la != LT_NONE) {
         out_tid[rbase + e] = tid[rbase + (int64_t)t * Mt + (int)la];
         out_tph[rbase + e] = s_acc[b * LT_S + t];
@@ -691,7 +731,7 @@ extern "C++" int light_response_truth(ldsim_ctx* ctx, hipStream_t st, bool respo
   hipLaunchKernelGGL(light_env_kernel, dim3((unsigned)((C + 64 + 255) / 256)), dim3(256), 0, st, weights, C, response ? 1 : 0, env);
   hipLaunchKernelGGL(light_env2_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, (const double*)env, C, env2);
   HIPCHK(hipGetLastError());
-  const size_t lds = ((size_t)(response ? 1 : 2) * Mt * LT_S + 128) * 8 + (size_t)(response ? Mt : LT_TAB) * 64;
+  const size_t lds = ((size_t)(response ? 1 : 2) * Mt * LT_S + 128) * 8 + (size_t)(response ? 64 : LT_TAB) * 64;
   const double* bmax = tmax + n;
   dim3 tg((unsigned)nblk, (unsigned)D);
   if (response) {
