@@ -120,8 +120,16 @@ def profiled_traffic(config, kernel):
     try:
         with open(TRAFFIC_FILE) as f:
             tab = json.load(f)
-        e = tab[config][kernel]
-        return float(e["bytes_per_launch"]), e.get("source", os.path.basename(TRAFFIC_FILE))
+        if kernel in tab[config]:
+            e = tab[config][kernel]
+            return float(e["bytes_per_launch"]), e.get("source", os.path.basename(TRAFFIC_FILE))
+        # a kernel with further template arguments ("gcorr_kernel<1>" is launched as gcorr_kernel<1, false> for all pairs and as
+        # gcorr_kernel<1, true> for the listed LDS classes): the chain launch's traffic is the sum over its variants
+        parts = [v for k, v in tab[config].items() if kernel.endswith(">") and k.startswith(kernel[:-1] + ",")]
+        if not parts:
+            raise KeyError(kernel)
+        return (float(sum(v["bytes_per_launch"] for v in parts)),
+                parts[0].get("source", os.path.basename(TRAFFIC_FILE)) + f"; sum over {len(parts)} variants of {kernel}")
     except Exception:
         return None, f"no PMC pass for {config}/{kernel} in profiles/{os.path.basename(TRAFFIC_FILE)} (tools/pmc_traffic.py writes it)"
 
