@@ -366,8 +366,11 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
     const double* __restrict__ block_max /* [D][ceil(T / 64)] */, const double* __restrict__ env2) {
   extern __shared__ double s_lt[];
   double* s_acc = s_lt;                                        // [Mt][LT_S]: the output photons
-  int64_t* s_id = (int64_t*)(s_acc + (RESPONSE ? 0 : Mt * LT_S));      // scintillation: [Mt][LT_S] output ids (SiPM: the input ids, while the rows are classified only)
-  double* s_w = s_acc + (RESPONSE ? 1 : 2) * Mt * LT_S;        // [128]: the weights the wave's ticks meet a block of input ticks with
+  // scintillation: [Mt][LT_S] output ids, 32 bits each (ids 0 .. 2^32 - 2; all ones = -1 = empty) -- 48 instead of 61 KB per wave at 50
+  // slots, three waves per CU instead of two.  A wave that meets an id outside that range (none in the reference's use: segment / track
+  // indices) writes its rows back and goes on in memory, literally (`in_memory` below).
+  unsigned* s_id = (unsigned*)(s_acc + Mt * LT_S);
+  double* s_w = RESPONSE ? s_acc + Mt * LT_S : (double*)(s_id + ((Mt * LT_S + 1) & ~1));        // [128]: the weights the wave's ticks meet a block of input ticks with
   unsigned char* s_byte = (unsigned char*)(s_w + 128);         // SiPM: [64 ticks][64] last input slot added to an output slot; scintillation: [LT_TAB][64 ticks] id hash -> slot
   const int lane = threadIdx.x;
   const int d = blockIdx.y, i0 = blockIdx.x * 64, i = i0 + lane;
@@ -378,6 +381,9 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
   bool loaded = false, changed = false;
   int filled = 0;                  // scintillation: slots in front of the row's first -1
   bool literal = false;            // scintillation, wave-uniform: some row arrived with a hole in front of a filled slot
+  bool in_memory = false;          // scintillation, wave-uniform: an id that does not fit 32 bits was met -- the rows are walked in memory
+  auto narrow = [](int64_t id) { return (unsigned long long)(id + 1) <= 0xFFFFFFFFull; };          // -1 .. 2^32 - 2
+  auto wide_id = [](unsigned u) { return u == 0xFFFFFFFFu ? (int64_t)-1 : (int64_t)u; };
   int row_f = Mt;                  // SiPM: first -1 of the input row at the output tick
   bool regular = true;             // SiPM: distinct ids in front of it, -1 behind
   unsigned long long m_reg = 0;    // SiPM, wave-uniform: the ticks with such a row
@@ -385,8 +391,9 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
   auto id_hash = [](int64_t id) { return (int)(((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> 57); };
   auto load_rows = [&]() {
     // ids first (SiPM: into the accumulators' place), the per-row state from them, then the photons
-    int64_t* ids = RESPONSE ? (int64_t*)s_acc : s_id;
+    int64_t* ids = (int64_t*)s_acc;
     const int64_t* gid = RESPONSE ? tid : out_tid;
+    bool all_narrow = true;
     for (int e0 = lane; e0 < 64 * Mt; e0 += 512) {          // (eight words per lane in flight)
       int64_t v[8];
 #pragma unroll
@@ -394,8 +401,15 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int e = e0 + 64 * u, t = e / Mt, b = e - t * Mt;
-        if (e < 64 * Mt) ids[b * LT_S + t] = v[u];
+        if (e < 64 * Mt) {
+          if (RESPONSE) ids[b * LT_S + t] = v[u];
+          else { s_id[b * LT_S + t] = (unsigned)v[u]; all_narrow = all_narrow && narrow(v[u]); }
+        }
       }
+    }
+    if (!RESPONSE && __ballot(!all_narrow)) {          // (nothing is in LDS that memory does not hold)
+      in_memory = true;
+      return;
     }
     const int nbyte = (RESPONSE ? 64 : LT_TAB) * 64;
     for (int e = lane * 4; e < nbyte; e += 256) *(unsigned*)(s_byte + e) = 0xFFFFFFFFu;
@@ -418,20 +432,20 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
       bool seen_empty = false, clean = true;
       filled = 0;
       for (int b = 0; b < Mt; b++) {
-        if (ids[b * LT_S + lane] == -1) seen_empty = true;
+        if (s_id[b * LT_S + lane] == 0xFFFFFFFFu) seen_empty = true;
         else if (seen_empty) clean = false;
         else filled = b + 1;
       }
       literal = __ballot(live && !clean) != 0ull;
       if (!literal) {
         for (int b = 0; b < filled; b++) {              // the ids the row arrives with (a repeated one keeps its first slot)
-          const int64_t id = ids[b * LT_S + lane];
-          const int h0 = id_hash(id);
+          const unsigned id32 = s_id[b * LT_S + lane];
+          const int h0 = id_hash((int64_t)id32);
           for (int k = 0; k < LT_TAB; k++) {
             const int idx = (h0 + k) & (LT_TAB - 1);
             const unsigned p = s_byte[idx * 64 + lane];
             if (p == LT_NONE) { s_byte[idx * 64 + lane] = (unsigned char)b; break; }
-            if (ids[(int)p * LT_S + lane] == id) break;
+            if (s_id[(int)p * LT_S + lane] == id32) break;
           }
         }
       }
@@ -449,6 +463,43 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
     wave_lds_sync();
   };
 
+  // write back what was touched, in the reference's layout (neighbouring lanes: neighbouring words)
+  auto store_rows = [&]() {
+    if (!loaded || in_memory || !__ballot(changed)) return;
+    unsigned char* s_fill = s_byte;          // scintillation: slots to write per tick (in the id table's place: it is not read again; the weights' are)
+    wave_lds_sync();
+    if (!RESPONSE) s_fill[lane] = (unsigned char)(changed ? (literal ? Mt : filled) : 0);
+    wave_lds_sync();
+    for (int e = lane; e < nrow; e += 64) {
+      const int t = e / Mt, b = e - t * Mt;
+      if (RESPONSE) {
+        const unsigned la = s_byte[t * 64 + b];
+        if (la != LT_NONE) {
+          out_tid[rbase + e] = tid[rbase + (int64_t)t * Mt + (int)la];
+          out_tph[rbase + e] = s_acc[b * LT_S + t];
+        }
+      } else if (b < (int)s_fill[t]) {
+        out_tid[rbase + e] = wide_id(s_id[b * LT_S + t]);
+        out_tph[rbase + e] = s_acc[b * LT_S + t];
+      }
+    }
+  };
+  // an accepted term of the scintillation stage on the rows in memory, literally (:180-183) -- after an id that does not fit the rows
+  // in LDS; loads past the L1 (the wave's own stores, of other lanes, may sit behind a stale line)
+  auto term_in_memory = [&](int64_t id, double v) {
+    unsigned long long* orow = (unsigned long long*)out_tid + rbase + (int64_t)lane * Mt;
+    unsigned long long* prow = (unsigned long long*)out_tph + rbase + (int64_t)lane * Mt;
+    for (int b = 0; b < Mt; b++) {
+      const int64_t cur = (int64_t)__hip_atomic_load(orow + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == id || cur == -1) {
+        const unsigned long long pb = __hip_atomic_load(prow + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sum = __longlong_as_double((long long)pb) + v;
+        __hip_atomic_store(orow + b, (unsigned long long)id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prow + b, (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  };
   // Screening in two levels: 64 blocks of 64 input ticks per trip to memory (lane = block: its largest bound times the largest
   // weight the wave meets it with), then the ticks of a block that passed (lane = tick) -- fetched, with the weights the wave meets
   // the block with, one passing block ahead of the one being walked; the truth slots of a tick that passed one tick ahead.
@@ -525,6 +576,11 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
         // the input tick's slots: lane a holds slot a
         const unsigned long long empty = __ballot(lane < Mt && my_id == -1);
         const int nfill = empty ? __ffsll((long long)empty) - 1 : Mt;          // (the walk stops at the first empty slot)
+        if (!RESPONSE && !in_memory && __ballot(lane < nfill && !narrow(my_id))) {
+          store_rows();
+          __threadfence();
+          in_memory = true;
+        }
         if (RESPONSE) {
           // SiPM stage, the walk turned round: lane a holds slot a of the input tick and the loop runs over the wave's output ticks
           // that can pass -- a term reaches ~13 of the wave's 64 ticks but most of the tick's slots, and the target slot needs no
@@ -581,12 +637,15 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
           if (!__ballot(pass)) continue;
           if (!RESPONSE) {
             const int64_t id = wave_lane_i64(my_id, a);
-            if (literal) {
+            if (in_memory) {
+              if (pass) term_in_memory(id, v);
+            } else if (literal) {
               if (pass) {
+                const unsigned id32 = (unsigned)id;
                 for (int b = 0; b < Mt; b++) {                                  // :180-183
-                  const int64_t cur = s_id[b * LT_S + lane];
-                  if (cur == id || cur == -1) {
-                    s_id[b * LT_S + lane] = id;
+                  const unsigned cur = s_id[b * LT_S + lane];
+                  if (cur == id32 || cur == 0xFFFFFFFFu) {
+                    s_id[b * LT_S + lane] = id32;
                     atomicAdd(&s_acc[b * LT_S + lane], v);
                     changed = true;
                     break;
@@ -599,16 +658,17 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
               const int h0 = id_hash(id);
               const unsigned p0 = s_byte[h0 * 64 + lane];
               const bool has = p0 != LT_NONE;
-              const int64_t cur = s_id[(has ? (int)p0 : 0) * LT_S + lane];
+              const unsigned id32 = (unsigned)id;
+              const unsigned cur = s_id[(has ? (int)p0 : 0) * LT_S + lane];
               const bool fresh = pass && !has && filled < Mt;
-              bool need = pass && has && cur != id;
+              bool need = pass && has && cur != id32;
               const int pos = has ? (int)p0 : filled;
               if (fresh) {                               // not in the row: its first empty slot, if it has one
-                s_id[pos * LT_S + lane] = id;
+                s_id[pos * LT_S + lane] = id32;
                 s_byte[h0 * 64 + lane] = (unsigned char)pos;
                 filled++;
               }
-              if (fresh || (pass && has && cur == id)) {
+              if (fresh || (pass && has && cur == id32)) {
                 atomicAdd(&s_acc[pos * LT_S + lane], v);
                 changed = true;
               }
@@ -618,14 +678,14 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
                   const unsigned p = s_byte[idx * 64 + lane];
                   if (p == LT_NONE) {
                     if (filled < Mt) {
-                      s_id[filled * LT_S + lane] = id;
+                      s_id[filled * LT_S + lane] = id32;
                       s_byte[idx * 64 + lane] = (unsigned char)filled;
                       atomicAdd(&s_acc[filled * LT_S + lane], v);
                       filled++;
                       changed = true;
                     }
                     need = false;
-                  } else if (s_id[(int)p * LT_S + lane] == id) {
+                  } else if (s_id[(int)p * LT_S + lane] == id32) {
                     atomicAdd(&s_acc[(int)p * LT_S + lane], v);
                     changed = true;
                     need = false;
@@ -638,25 +698,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
       }
     }
   }
-  if (!loaded || !__ballot(changed)) return;
-  // write back what was touched, in the reference's layout (neighbouring lanes: neighbouring words)
-  unsigned char* s_fill = (unsigned char*)s_w;          // scintillation: slots to write per tick
-  wave_lds_sync();
-  if (!RESPONSE) s_fill[lane] = (unsigned char)(changed ? (literal ? Mt : filled) : 0);
-  wave_lds_sync();
-  for (int e = lane; e < nrow; e += 64) {
-    const int t = e / Mt, b = e - t * Mt;
-    if (RESPONSE) {
-      const unsigned la = s_byte[t * 64 + b];
-      if (la != LT_NONE) {
-        out_tid[rbase + e] = tid[rbase + (int64_t)t * Mt + (int)la];
-        out_tph[rbase + e] = s_acc[b * LT_S + t];
-      }
-    } else if (b < (int)s_fill[t]) {
-      out_tid[rbase + e] = s_id[b * LT_S + t];
-      out_tph[rbase + e] = s_acc[b * LT_S + t];
-    }
-  }
+  store_rows();
 }
 
 // [detector][tick][slot] <-> [detector][slot][tick] of an 8-byte array, TR_TICKS ticks of one detector per workgroup through LDS
@@ -731,7 +773,8 @@ extern "C++" int light_response_truth(ldsim_ctx* ctx, hipStream_t st, bool respo
   hipLaunchKernelGGL(light_env_kernel, dim3((unsigned)((C + 64 + 255) / 256)), dim3(256), 0, st, weights, C, response ? 1 : 0, env);
   hipLaunchKernelGGL(light_env2_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, (const double*)env, C, env2);
   HIPCHK(hipGetLastError());
-  const size_t lds = ((size_t)(response ? 1 : 2) * Mt * LT_S + 128) * 8 + (size_t)(response ? 64 : LT_TAB) * 64;
+  const size_t lds = response ? ((size_t)Mt * LT_S + 128) * 8 + 64 * 64
+                              : ((size_t)Mt * LT_S + 128) * 8 + (((size_t)Mt * LT_S + 1) & ~(size_t)1) * 4 + (size_t)LT_TAB * 64;
   const double* bmax = tmax + n;
   dim3 tg((unsigned)nblk, (unsigned)D);
   if (response) {

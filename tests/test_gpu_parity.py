@@ -1024,7 +1024,9 @@ def test_light_response_full_window_vs_oracle():
 
 def _truth_rows(rng, D, T, M, density, kind):
     """[D][T][M] truth rows for the light response tests: `kind` 0 -- the front filled with distinct ids (what the stages produce),
-    1 -- some rows with a repeated id, 2 -- some rows with a hole (-1) in front of filled slots as well."""
+    1 -- some rows with a repeated id, 2 -- some rows with a hole (-1) in front of filled slots as well, 3 -- ids that do not fit 32
+    bits (2^40 + k, -7) in the later half of the ticks (the scintillation stage keeps its rows' ids as 32-bit words in LDS and has
+    to fall back to the rows in memory when it meets one)."""
     ids = np.full((D, T, M), -1, dtype='i8')
     ph = np.zeros((D, T, M))
     for d in range(D):
@@ -1033,14 +1035,16 @@ def _truth_rows(rng, D, T, M, density, kind):
             ids[d, t, :n] = rng.choice(3 * M, size=n, replace=False) + 10
             ph[d, t, :n] = rng.uniform(0.05, 40.0, n) * rng.choice([1.0, 1.0, 1.0, 1e-3], n)
             r = rng.random()
-            if kind >= 1 and n >= 3 and r < 0.3:
+            if kind in (1, 2) and n >= 3 and r < 0.3:
                 ids[d, t, n - 1] = ids[d, t, 0]
-            if kind >= 2 and n >= 3 and 0.3 <= r < 0.6:
+            if kind == 2 and n >= 3 and 0.3 <= r < 0.6:
                 ids[d, t, int(rng.integers(0, n - 1))] = -1
+            if kind == 3 and t > T // 2 and r < 0.5:
+                ids[d, t, 0] = (1 << 40) + ids[d, t, 0] if r < 0.3 else -7
     return ids, ph
 
 
-@pytest.mark.parametrize("M,T,kind", [(3, 200, 0), (50, 330, 0), (50, 200, 2), (64, 130, 1), (7, 330, 2)])
+@pytest.mark.parametrize("M,T,kind", [(3, 200, 0), (50, 330, 0), (50, 200, 2), (64, 130, 1), (7, 330, 2), (20, 330, 3)])
 def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
     """The truth slots of both response stages by `light_truth_lds_kernel` (a wave's 64 output rows in LDS, the default) against the
     oracle's literal walk, bit for bit, and against `light_conv_kernel`'s rows in memory (option light_truth_lds 0) where that path
@@ -1099,7 +1103,7 @@ def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
             O.lib().o_light_detector_response(O._p(s_in), O._p(s_id), O._p(s_ph), C.c_int32(D), C.c_int32(T), C.c_int32(M), O._p(gain),
                                               O._p(imp), C.c_int32(imp.shape[0]), O._p(rref[0]), O._p(rref[1]), O._p(rref[2]),
                                               C.byref(O._consts()))
-            for mode in ((1, 0) if kind == 0 else (1,)):      # (rows in memory: literal for distinct ids in front of the first -1 only)
+            for mode in ((1, 0) if kind in (0, 3) else (1,)):      # (rows in memory: literal for distinct ids in front of the first -1 only)
                 lib.set_option("light_truth_lds", mode)
                 g = [a.copy() for a in r0]
                 light_sim.calc_light_detector_response[grid[0], grid[1]](s_in, s_id, s_ph, g[0], g[1], g[2])
