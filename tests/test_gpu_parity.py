@@ -1044,8 +1044,9 @@ def _truth_rows(rng, D, T, M, density, kind):
     return ids, ph
 
 
-@pytest.mark.parametrize("M,T,kind", [(3, 200, 0), (50, 330, 0), (50, 200, 2), (64, 130, 1), (7, 330, 2), (20, 330, 3)])
-def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
+@pytest.mark.parametrize("M,T,kind,win", [(3, 200, 0, 150.3), (50, 330, 0, 150.3), (50, 200, 2, 150.3), (64, 130, 1, 150.3),
+                                          (7, 330, 2, 150.3), (20, 330, 3, 150.3), (1, 70, 0, 2.5), (5, 40, 2, 0.0)])
+def test_light_truth_rows_in_lds_vs_oracle(M, T, kind, win):
     """The truth slots of both response stages by `light_truth_lds_kernel` (a wave's 64 output rows in LDS, the default) against the
     oracle's literal walk, bit for bit, and against `light_conv_kernel`'s rows in memory (option light_truth_lds 0) where that path
     is literal: a window shorter than the waveform (the bound max(itick - conv_ticks, 0)), a waveform that is no multiple of 64 ticks,
@@ -1056,7 +1057,7 @@ def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
     light, sim = consts.light, consts.sim
     keep = (tuple(light.LIGHT_WINDOW), sim.MC_TRUTH_THRESHOLD)
     try:
-        light.LIGHT_WINDOW = (0.0, 150.3 * light.LIGHT_TICK_SIZE)
+        light.LIGHT_WINDOW = (0.0, win * light.LIGHT_TICK_SIZE)          # (conv_ticks = ceil(win): 151, 3 or 0)
         sim.MC_TRUTH_THRESHOLD = 0.02
         rng = np.random.default_rng(100 * M + kind)
         D = 3
@@ -1088,7 +1089,7 @@ def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
             for mode in (1, 0):
                 for k, name in enumerate(("scint", "ids", "photons")):
                     assert np.array_equal(got[mode][k], ref[k]), f"scintillation stage, light_truth_lds {mode}, {name} (filled {filled})"
-            assert (ref[1][:, :, -1] != -1).any() or M > 10          # (small M: rows fill up and drop ids)
+            assert (ref[1][:, :, -1] != -1).any() or M > 10 or win < 3          # (small M: rows fill up and drop ids)
             assert (ref[1] != s0[1]).any()
             # SiPM stage on the scintillation stage's output (negative photons added: the magnitude test), literal rows in `tid`
             s_in, s_id, s_ph = ref[0], ref[1].copy(), ref[2].copy()
@@ -1110,7 +1111,7 @@ def test_light_truth_rows_in_lds_vs_oracle(M, T, kind):
                 lib.set_option("light_truth_lds", 1)
                 for k, name in enumerate(("response", "ids", "photons")):
                     assert np.array_equal(g[k], rref[k]), f"SiPM stage, light_truth_lds {mode}, {name} (filled {filled})"
-            assert (rref[2] != r0[2]).any()
+            assert (rref[2] != r0[2]).any() or win < 3
     finally:
         lib.set_option("light_truth_lds", 1)
         light.LIGHT_WINDOW, sim.MC_TRUTH_THRESHOLD = keep
