@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     __syncthreads();
     for (int k = threadIdx.x; k < nj; k += LR_THREADS) {
       s_x[k] = x[jc + k];
-      if (Mt > 0) s_tmax[k] = truth_max[(int64_t)d * T + jc + k];
+      // (without truth slots the bound's place holds the samples as doubles: the unrolled blocks below read them from there)
+      s_tmax[k] = Mt > 0 ? truth_max[(int64_t)d * T + jc + k] : (double)x[jc + k];
     }
     // (SiPM stage without truth slots: the weights staged as LIGHT_GAIN[row] * w, the product the reference forms first, :320)
     const bool premul = RESPONSE && Mt <= 0;
@@ -126,6 +127,23 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
           // all 64 ticks of the block (the SiPM stage, and lit stretches of the scintillation stage): lane numbers and weight
           // offsets are constants -- no bit scan, no address arithmetic per term; what is left is the sample, the weight and the
           // three dependent operations of the f4 sum (5-6 instructions per term instead of ~12)
+          if (Mt <= 0) {
+            // the sample as a double from LDS (one address for the whole wave: a broadcast read) instead of v_readlane + v_cvt_f64_f32:
+            // f64-class vector instructions take 8 cycles per wave on this part and the term is down to four of them (product, the
+            // sum's operand widened, sum, narrowed) -- 44 -> 36 cycles per term
+            const double* xd = s_tmax + (jb - jc);
+#pragma unroll
+            for (int t8 = 0; t8 < 64; t8 += 8) {
+              double w8[8], x8[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) w8[u] = wl[-(t8 + u)];
+#pragma unroll
+              for (int u = 0; u < 8; u++) x8[u] = xd[t8 + u];
+#pragma unroll
+              for (int u = 0; u < 8; u++) acc = (float)((double)acc + w8[u] * x8[u]);
+            }
+            continue;
+          }
 #pragma unroll
           for (int t8 = 0; t8 < 64; t8 += 8) {
             double w8[8];
