@@ -128,17 +128,20 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
           // offsets are constants -- no bit scan, no address arithmetic per term; what is left is the sample, the weight and the
           // three dependent operations of the f4 sum (5-6 instructions per term instead of ~12)
           if (Mt <= 0) {
-            // the sample as a double from LDS (one address for the whole wave: a broadcast read) instead of v_readlane + v_cvt_f64_f32:
-            // four vector instructions per term instead of six (product, the sum's operand widened, sum, narrowed) -- SiPM stage of a
-            // 2x2 batch 14.4 -> 12.3 ms
+            // the sample arrives as a double -- no v_cvt_f64_f32 per term (the conversions are the slow instructions of the term: with
+            // it gone the SiPM stage of a 2x2 batch runs 15.6 -> 11.8 ms).  SiPM stage (every block is of this kind): lane t holds
+            // tick jb + t's sample widened once, two v_readlane per term; from LDS by a broadcast read instead the stage is bound by
+            // the LDS (13.5 ms: two 8-byte reads per term and lane).  Scintillation stage (few such blocks): the broadcast read,
+            // 1.82 against 1.91 ms.
             const double* xd = s_tmax + (jb - jc);
+            const double xd_l = (double)x_l;
 #pragma unroll
             for (int t8 = 0; t8 < 64; t8 += 8) {
               double w8[8], x8[8];
 #pragma unroll
               for (int u = 0; u < 8; u++) w8[u] = wl[-(t8 + u)];
 #pragma unroll
-              for (int u = 0; u < 8; u++) x8[u] = xd[t8 + u];
+              for (int u = 0; u < 8; u++) x8[u] = RESPONSE ? wave_lane_f64(xd_l, t8 + u) : xd[t8 + u];
 #pragma unroll
               for (int u = 0; u < 8; u++) acc = (float)((double)acc + w8[u] * x8[u]);
             }
