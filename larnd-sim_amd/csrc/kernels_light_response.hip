@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
     double truth_threshold, float* __restrict__ out, int64_t* __restrict__ out_tid /* [D][Mt][T]: slot-major working copy */,
     double* __restrict__ out_tph /* [D][Mt][T] */,
     const double* __restrict__ truth_max /* [D][T]: light_truth_max_kernel, or NULL when Mt == 0 */,
-    const int64_t* __restrict__ tid_sm /* RESPONSE: the input ids slot-major, [D][Mt][T] (read at the OUTPUT tick) */) {
+    const int64_t* __restrict__ tid_sm /* RESPONSE: the input ids slot-major, [D][Mt][T] (read at the OUTPUT tick) */,
+    const double* __restrict__ inc_f64 /* [D][T]: `inc` widened (light_widen_kernel), or NULL */) {
   __shared__ float s_x[JCHUNK];
   __shared__ double s_w[JCHUNK + LR_THREADS];
   // largest photon count (RESPONSE: magnitude) among the filled truth slots of input tick j, -1 when it has none: a pair
@@ -135,6 +136,22 @@ __global__ void __launch_bounds__(LR_THREADS) light_conv_kernel(
             // 1.82 against 1.91 ms.
             const double* xd = s_tmax + (jb - jc);
             const double xd_l = (double)x_l;
+            if (inc_f64) {
+              // (the widened samples from memory at a wave-uniform address: scalar loads, eight doubles per request straight into
+              // scalar registers -- no vector instruction and no LDS read for the sample)
+              const double* xg = inc_f64 + (int64_t)d * T + jb;
+#pragma unroll
+              for (int t8 = 0; t8 < 64; t8 += 8) {
+                double w8[8], x8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w8[u] = wl[-(t8 + u)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) x8[u] = xg[t8 + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = (float)((double)acc + w8[u] * x8[u]);
+              }
+              continue;
+            }
 #pragma unroll
             for (int t8 = 0; t8 < 64; t8 += 8) {
               double w8[8], x8[8];
@@ -756,18 +773,31 @@ __global__ void __launch_bounds__(256) light_truth_transpose_kernel(const unsign
   }
 }
 
+__global__ void light_widen_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ xd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) xd[e] = (double)x[e];
+}
+
 // the plain sum of a stage (no truth slots) on `st`
 extern "C++" int light_response_plain(ldsim_ctx* ctx, hipStream_t st, bool response, const float* inc, int D, int T, const double* weights,
                                       int C, const double* gain, float* out) {
   if (D <= 0 || T <= 0) return 0;
   dim3 grid((unsigned)((T + LR_THREADS - 1) / LR_THREADS), (unsigned)D), block(LR_THREADS);
   const double thr = ctx->h_consts.mc_truth_threshold;
+  const double* xd = nullptr;
+  if (response) {          // (the SiPM stage's blocks of 64 input ticks all take part: the samples once more as doubles)
+    const int64_t n = (int64_t)D * T;
+    int rc = ldsim_ensure_buf(ctx, &ctx->light_xd, (size_t)n * 8 + 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(light_widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, inc, n, (double*)ctx->light_xd.p);
+    xd = (const double*)ctx->light_xd.p;
+  }
   if (response)
     hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, st, inc, (const int64_t*)nullptr, (const double*)nullptr, D, T, 0, weights,
-                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr);
+                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr, xd);
   else
     hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, st, inc, (const int64_t*)nullptr, (const double*)nullptr, D, T, 0, weights,
-                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr);
+                       C, gain, thr, out, (int64_t*)nullptr, (double*)nullptr, (const double*)nullptr, (const int64_t*)nullptr, xd);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -860,10 +890,10 @@ extern "C++" int light_response_launch(ldsim_ctx* ctx, bool response, const floa
   }
   if (response)
     hipLaunchKernelGGL(light_conv_kernel<true>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain, thr,
-                       out, w_tid, w_tph, tmax, in_sm);
+                       out, w_tid, w_tph, tmax, in_sm, (const double*)nullptr);
   else
     hipLaunchKernelGGL(light_conv_kernel<false>, grid, block, 0, ctx->stream, inc, tid, tph, D, T, Mt, weights, C, gain,
-                       thr, out, w_tid, w_tph, tmax, (const int64_t*)nullptr);
+                       thr, out, w_tid, w_tph, tmax, (const int64_t*)nullptr, (const double*)nullptr);
   HIPCHK(hipGetLastError());
   if (Mt > 0) {
     dim3 tg((unsigned)((T + TR_TICKS - 1) / TR_TICKS), (unsigned)D);

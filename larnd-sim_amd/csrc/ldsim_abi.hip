@@ -269,7 +269,7 @@ extern "C" int ldsim_ctx_destroy(ldsim_ctx* ctx) {
   for (DevBuf* b : {&ctx->light_nph, &ctx->light_t0, &ctx->light_vox, &ctx->light_out, &ctx->light_tid, &ctx->light_tph,
                     &ctx->light_opc, &ctx->light_trk, &ctx->light_scint, &ctx->light_scint_tid, &ctx->light_scint_tph,
                     &ctx->light_disc, &ctx->light_resp, &ctx->light_resp_tid, &ctx->light_resp_tph, &ctx->light_w[0],
-                    &ctx->light_w[1], &ctx->light_gain, &ctx->resp_pad, &ctx->light_tmax, &ctx->light_env, &ctx->light_wtid, &ctx->light_wtph, &ctx->light_wtid2})
+                    &ctx->light_w[1], &ctx->light_gain, &ctx->resp_pad, &ctx->light_tmax, &ctx->light_env, &ctx->light_xd, &ctx->light_wtid, &ctx->light_wtph, &ctx->light_wtid2})
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->light_tmp)
     if (b.p) (void)hipFree(b.p);

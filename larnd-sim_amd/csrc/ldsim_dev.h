@@ -129,6 +129,7 @@ struct ldsim_ctx {
   // overlapped download of the chain's results (ldsim_chain_download_async): a second stream copies launch k's per-pixel
   // arrays to the host while launch k + 1 computes into the other set of output buffers
   DevBuf light_wtid, light_wtph, light_wtid2;            // slot-major working copies of a response stage's output truth rows
+  DevBuf light_xd;                           // the SiPM stage's input samples widened to doubles (light_widen_kernel)
   DevBuf light_env;                          // per offset of a wave's first tick from an input tick: the largest weight its 64 ticks meet it with (light_env_kernel)
   int light_truth_lds = 1;                   // truth slots of the light response stages by light_truth_lds_kernel (0: inside light_conv_kernel, slot-major copies)
   DevBuf light_tmax;                         // per (detector, tick) bound on the truth slots' photons (light_truth_max_kernel)
