@@ -663,6 +663,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
           continue;
         }
         const double wmax = wave_max_f64(walk ? fabs(w) : 0.0);
+        changed = changed || walk;          // (a superset of the rows that change: what is written back for the others is what they hold)
         // the slots some lane's product can pass on, in ascending order
         unsigned long long cand;
         if (__ballot(walk && w < 0.0)) cand = nfill >= 64 ? ~0ull : ((1ull << nfill) - 1ull);
@@ -706,10 +707,7 @@ __global__ void __launch_bounds__(64) light_truth_lds_kernel(
                 s_byte[h0 * 64 + lane] = (unsigned char)pos;
                 filled++;
               }
-              if (fresh || (pass && has && cur == id32)) {
-                atomicAdd(&s_acc[pos * LT_S + lane], v);
-                changed = true;
-              }
+              if (fresh || (pass && has && cur == id32)) atomicAdd(&s_acc[pos * LT_S + lane], v);
               for (int k = 1; k < LT_TAB && __ballot(need); k++) {
                 const int idx = (h0 + k) & (LT_TAB - 1);
                 if (need) {
